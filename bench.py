@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py — split-read DP aligns/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path (pack -> DP fill -> combine/replay/emit) over one batch of
+synthetic candidates that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
+(10k synthetic fusions x 100 reads, 2x76 bp => Lref 389, 1M aligns).  With N>1 ranks every rank
+holds its own batch of the same shape (fusions are independent, no data-path collective: weak
+scaling); the only collective is the barrier/max-reduction of the timing.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
+    """Times the CPU oracle (a literal port of the reference's algorithm, oracle/dsa_oracle.c) on a
+    bounded sample of the same workload, single thread."""
+    from oracle import dosplitalign_oracle as ora
+    n = 256
+    t0 = time.perf_counter()
+    ora.align_batch(ref, fus, reads, pairs[:n])
+    dt = time.perf_counter() - t0
+    per = dt / n
+    n2 = int(max(n, min(len(pairs), budget_s / max(per, 1e-9))))
+    t0 = time.perf_counter()
+    ora.align_batch(ref, fus, reads, pairs[:n2])
+    dt = time.perf_counter() - t0
+    return {"value": n2 / dt, "unit": "aligns/s", "cores": 1, "kind": "port",
+            "sample": "first %d aligns of the same batch, oracle/dsa_oracle.c single thread, %.1f s" % (n2, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--fusions", type=int, default=10000)
+    ap.add_argument("--reads", type=int, default=100)
+    ap.add_argument("--lq", type=int, default=76)
+    ap.add_argument("--lr", type=int, default=389)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from defuse_amd import dsa, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank: its own shard of candidate fusions (different seed => different data, same shape)
+    ref, fus, reads, pairs = synth.make_batch(args.fusions, args.reads, lq=args.lq, lr=args.lr, seed=2 + rank)
+    ctx = dsa.Context(local_rank)
+    ctx.upload(ref, fus, reads, pairs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_rec = 0
+    for _ in range(args.warmup):
+        n_rec = ctx.run()
+    barrier()
+    fill_ms, pack_ms, finish_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_rec = ctx.run()                      # synchronous: returns after the last kernel finished
+        t = ctx.timing()
+        fill_ms.append(t.fill_ms / max(1, t.fill_launches))
+        pack_ms.append(t.pack_ms)
+        finish_ms.append(t.finish_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([len(pairs) * args.steps, n_rec], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_aligns = int(nn[0].item())
+    else:
+        total_aligns = len(pairs) * args.steps
+
+    if rank == 0:
+        t = ctx.timing()
+        rec_per_align = n_rec / len(pairs)
+        bytes_per_align = synth.algorithmic_bytes_per_align(args.lq, args.lr, args.reads, rec_per_align)
+        launch_ms = float(np.mean(fill_ms))
+        aligns_per_launch = len(pairs) / max(1, t.fill_launches)
+        achieved = bytes_per_align * aligns_per_launch / (launch_ms * 1e-3) / 1e9
+        cells = synth.cells_per_align(args.lq, args.lr)
+        out = {
+            "metric": "split-read DP aligns/sec", "value": total_aligns / elapsed, "unit": "aligns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "%dk synthetic candidate fusions x %d reads, 2x%d bp (Lref %d), split-read DP + split search, bit-exact"
+                                   % (args.fusions // 1000, args.reads, args.lq, args.lr),
+                       "aligns_per_step_per_gpu": len(pairs), "cells_per_align": cells,
+                       "records_per_align": round(rec_per_align, 4), "parallelism": "fusion-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_fill", "kernel_ms": launch_ms,
+                         "algorithmic_bytes_per_align": round(bytes_per_align, 2),
+                         "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9},
+            "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)) * max(1, t.fill_launches),
+                         "finish": float(np.mean(finish_ms))},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref, fus, reads, pairs)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

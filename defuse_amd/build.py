@@ -1,0 +1,56 @@
+"""Builds the in-tree native artefacts: the HIP C-ABI library (gfx950) and the tool binaries.
+
+    python -m defuse_amd.build            # everything
+    python -m defuse_amd.build --lib      # only libdefuse_dsa.so
+
+hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels with gpurun.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdefuse_dsa.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_lib(force=False):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "defuse_dsa.h")]
+    if force or _newer(LIB, srcs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+              "-o", LIB, os.path.join(CSRC, "dsa_api.hip")])
+    return LIB
+
+
+def build_oracle(force=False):
+    out = os.path.join(ROOT, "oracle", "libdsa_oracle.so")
+    srcs = [os.path.join(ROOT, "oracle", "dsa_oracle.c"), os.path.join(ROOT, "include", "defuse_dsa.h")]
+    if force or _newer(out, srcs):
+        _run(["make", "-C", os.path.join(ROOT, "oracle"), "-B"])
+    return out
+
+
+def main(argv):
+    force = "--force" in argv
+    build_lib(force)
+    if "--lib" not in argv:
+        build_oracle(force)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,462 @@
+// dsa_api.hip — extern "C" ABI of include/defuse_dsa.h on top of the gfx950 kernels.
+//
+// Replaces the per-candidate call SplitAlignmentTask::Align (tools/SplitAlignment.cpp:371-444 of the
+// reference) for whole batches.  There is deliberately no CPU fallback in this file: without a HIP
+// device dsa_create fails and every other entry point needs a ctx.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dsa_kernels.hpp"
+
+using namespace dsa;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Slice {
+    int64_t pair_begin = 0, pair_end = 0;
+    std::vector<WTask> wtasks;
+    Geom g{};
+};
+
+}  // namespace
+
+struct dsa_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    size_t scratch_budget = (size_t)16 << 30;
+
+    // resident batch
+    int64_t n_pairs = 0, ref_bytes_len = 0, read_bytes_len = 0;
+    int32_t n_fusions = 0;
+    DevBuf<uint8_t> d_ref, d_reads;
+    DevBuf<dsa_fusion> d_fusions;
+    DevBuf<dsa_pair> d_pairs;
+    DevBuf<int32_t> d_min_score;
+    std::vector<Slice> slices;
+    int64_t total_cells = 0;
+
+    // scratch
+    DevBuf<WTask> d_wtasks;
+    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax;
+    DevBuf<PairState> d_state;
+    DevBuf<int64_t> d_task_count, d_task_offset, d_rec_count, d_rec_offset;
+    DevBuf<ReplayTask> d_tasks;
+    DevBuf<uint64_t> d_colmask;
+    DevBuf<uint8_t> d_scan_tmp;
+    DevBuf<dsa_record> d_records;
+    int64_t n_records = 0;
+    bool have_results = false;
+
+    hipEvent_t ev[8] = {};
+    dsa_timing timing{};
+};
+
+namespace {
+
+int fail(dsa_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPC(call)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(ctx, DSA_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                       \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// minScore exactly as the reference writes it (tools/SplitAlignment.cpp:379):
+// (int)((float)len * (float)matchScore * 0.90)
+int min_score_for(int lq)
+{
+    float f = (float)lq * (float)DSA_MATCH;
+    return (int)((double)f * 0.90);
+}
+
+size_t slice_scratch_bytes(int64_t n_wtasks, int lq1, int nch)
+{
+    size_t rows = (size_t)n_wtasks * lq1 * WAVE * 4;
+    return rows + 2 * rows * (size_t)nch;
+}
+
+// Build the wave-task list.  A block is up to 128 consecutive pairs that share one fusion; each
+// block becomes two wave tasks (matrix 0, matrix 1).  Slices bound the scratch footprint.
+int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
+{
+    ctx->slices.clear();
+    ctx->total_cells = 0;
+    Slice cur;
+    cur.pair_begin = 0;
+    int lq1 = 1, nch = 1;
+    auto flush = [&](int64_t end) {
+        if (cur.wtasks.empty()) return;
+        cur.pair_end = end;
+        cur.g.n_wtasks = (int32_t)cur.wtasks.size();
+        cur.g.n_blocks = cur.g.n_wtasks / 2;
+        cur.g.lq1 = lq1;
+        cur.g.nch = nch;
+        cur.g.lrp = nch * W;
+        cur.g.n_fusions = ctx->n_fusions;
+        cur.g.n_pairs = end - cur.pair_begin;
+        ctx->slices.push_back(std::move(cur));
+        cur = Slice();
+        cur.pair_begin = end;
+        lq1 = 1;
+        nch = 1;
+    };
+    int64_t p = 0;
+    while (p < n_pairs) {
+        const int f = pairs[p].fusion_idx;
+        int64_t e = p;
+        int lqmax = 0;
+        while (e < n_pairs && e - p < PAIRS_PER_WTASK && pairs[e].fusion_idx == f) {
+            lqmax = std::max(lqmax, (int)pairs[e].read_len);
+            ctx->total_cells += (int64_t)(fusions[f].ref0_len + 1 + fusions[f].ref1_len + 1) * (pairs[e].read_len + 1);
+            ++e;
+        }
+        const int nlq1 = std::max(lq1, lqmax + 1);
+        const int nnch = std::max(nch, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
+        if (!cur.wtasks.empty() &&
+            slice_scratch_bytes((int64_t)cur.wtasks.size() + 2, nlq1, nnch) > ctx->scratch_budget) {
+            flush(p);
+            continue;   // re-evaluate this block against a fresh slice
+        }
+        lq1 = nlq1;
+        nch = nnch;
+        for (int m = 0; m < 2; ++m) {
+            WTask wt;
+            wt.pair_base = (int32_t)(p - cur.pair_begin);
+            wt.n_pairs = (int32_t)(e - p);
+            wt.fusion_idx = f;
+            wt.matrix = m;
+            wt.lr = m ? fusions[f].ref1_len : fusions[f].ref0_len;
+            wt.lq_max = lqmax;
+            wt.n_chunks = cdiv(wt.lr, W);
+            wt.pad_ = 0;
+            cur.wtasks.push_back(wt);
+        }
+        p = e;
+    }
+    flush(n_pairs);
+    return DSA_OK;
+}
+
+int exclusive_scan(dsa_ctx* ctx, const int64_t* in, int64_t* out, int64_t n)
+{
+    size_t tmp = 0;
+    HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, ctx->stream));
+    HIPC(ctx->d_scan_tmp.reserve(tmp));
+    HIPC(hipcub::DeviceScan::ExclusiveSum(ctx->d_scan_tmp.p, tmp, in, out, (int)n, ctx->stream));
+    return DSA_OK;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+int run_slice(dsa_ctx* ctx, const Slice& s)
+{
+    const Geom g = s.g;
+    hipStream_t st = ctx->stream;
+    const int64_t np = g.n_pairs;
+    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
+
+    const size_t n_rows = (size_t)g.n_wtasks * g.lq1 * WAVE;
+    HIPC(ctx->d_wtasks.reserve(s.wtasks.size()));
+    HIPC(ctx->d_refcodes.reserve((size_t)g.n_fusions * 2 * g.lrp));
+    HIPC(ctx->d_rowcodes.reserve(n_rows));
+    HIPC(ctx->d_bnd.reserve(n_rows * g.nch));
+    HIPC(ctx->d_cmax.reserve(n_rows * g.nch));
+    HIPC(ctx->d_state.reserve(np));
+    HIPC(ctx->d_task_count.reserve(np + 1));
+    HIPC(ctx->d_task_offset.reserve(np + 1));
+    HIPC(ctx->d_rec_count.reserve(np + 1));
+    HIPC(ctx->d_rec_offset.reserve(np + 1));
+    HIPC(hipMemcpyAsync(ctx->d_wtasks.p, s.wtasks.data(), s.wtasks.size() * sizeof(WTask), hipMemcpyHostToDevice, st));
+
+    // ---- pack -------------------------------------------------------------------------------
+    HIPC(hipEventRecord(ctx->ev[0], st));
+    {
+        int64_t total = (int64_t)g.n_fusions * 2 * g.lrp;
+        hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p,
+                           ctx->d_fusions.p, ctx->d_refcodes.p, g);
+        total = (int64_t)n_rows;
+        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
+                           ctx->d_wtasks.p, ctx->d_rowcodes.p, g);
+    }
+    HIPC(hipEventRecord(ctx->ev[1], st));
+    // ---- fill -------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(g.n_wtasks, 4)), dim3(256), 0, st, ctx->d_wtasks.p,
+                       ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, g);
+    HIPC(hipEventRecord(ctx->ev[2], st));
+    HIPC(hipGetLastError());
+    // ---- finish -----------------------------------------------------------------------------
+    const int64_t n_slots = (int64_t)g.n_blocks * PAIRS_PER_WTASK;
+    const unsigned slot_grid = (unsigned)((n_slots + 255) / 256);
+    HIPC(hipMemsetAsync(ctx->d_task_count.p, 0, (np + 1) * sizeof(int64_t), st));
+    HIPC(hipMemsetAsync(ctx->d_rec_count.p, 0, (np + 1) * sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_combine<false>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
+                       ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_task_count.p,
+                       (const int64_t*)nullptr, (ReplayTask*)nullptr, g);
+    if (int rc = exclusive_scan(ctx, ctx->d_task_count.p, ctx->d_task_offset.p, np + 1)) return rc;
+    int64_t n_tasks = 0;
+    HIPC(hipMemcpyAsync(&n_tasks, ctx->d_task_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    HIPC(ctx->d_tasks.reserve((size_t)n_tasks + 1));
+    HIPC(ctx->d_colmask.reserve((size_t)n_tasks + 1));
+    hipLaunchKernelGGL(k_combine<true>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
+                       ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_task_count.p,
+                       (const int64_t*)ctx->d_task_offset.p, ctx->d_tasks.p, g);
+    if (n_tasks > 0)
+        hipLaunchKernelGGL(k_replay, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, st, ctx->d_tasks.p, n_tasks,
+                           ctx->d_wtasks.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_colmask.p, g);
+    hipLaunchKernelGGL(k_emit<false>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
+                       ctx->d_state.p, ctx->d_task_count.p, ctx->d_tasks.p, ctx->d_colmask.p, ctx->d_rec_count.p,
+                       (const int64_t*)nullptr, (dsa_record*)nullptr, g);
+    if (int rc = exclusive_scan(ctx, ctx->d_rec_count.p, ctx->d_rec_offset.p, np + 1)) return rc;
+    int64_t n_rec = 0;
+    HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
+        // grow, keeping what earlier slices wrote
+        DevBuf<dsa_record> bigger;
+        HIPC(bigger.reserve((size_t)(ctx->n_records + n_rec) * 2 + 1024));
+        if (ctx->n_records)
+            HIPC(hipMemcpyAsync(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, st));
+        HIPC(hipStreamSynchronize(st));
+        ctx->d_records.release();
+        ctx->d_records = bigger;
+    }
+    hipLaunchKernelGGL(k_emit<true>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
+                       ctx->d_state.p, ctx->d_task_count.p, ctx->d_tasks.p, ctx->d_colmask.p, ctx->d_rec_count.p,
+                       (const int64_t*)ctx->d_rec_offset.p, ctx->d_records.p + ctx->n_records, g);
+    HIPC(hipEventRecord(ctx->ev[3], st));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(st));
+    ctx->n_records += n_rec;
+    ctx->timing.pack_ms += elapsed(ctx->ev[0], ctx->ev[1]);
+    ctx->timing.fill_ms += elapsed(ctx->ev[1], ctx->ev[2]);
+    ctx->timing.finish_ms += elapsed(ctx->ev[2], ctx->ev[3]);
+    ctx->timing.total_ms += elapsed(ctx->ev[0], ctx->ev[3]);
+    ctx->timing.fill_launches += 1;
+    ctx->timing.n_replay_tasks += n_tasks;
+    return DSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsa_version(void) { return "defuse_amd dsa 0.1 (gfx950)"; }
+
+int dsa_create(dsa_ctx** out, int device)
+{
+    if (!out) return DSA_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DSA_E_DEVICE;
+    dsa_ctx* ctx = new dsa_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
+        delete ctx;
+        return DSA_E_DEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    for (auto& e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return DSA_E_DEVICE;
+        }
+    if (const char* mb = getenv("DEFUSE_DSA_SCRATCH_MB")) {
+        long v = atol(mb);
+        if (v > 0) ctx->scratch_budget = (size_t)v << 20;
+    }
+    *out = ctx;
+    return DSA_OK;
+}
+
+void dsa_destroy(dsa_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
+    ctx->d_min_score.release(); ctx->d_wtasks.release(); ctx->d_refcodes.release(); ctx->d_rowcodes.release();
+    ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_state.release(); ctx->d_task_count.release();
+    ctx->d_task_offset.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release(); ctx->d_tasks.release();
+    ctx->d_colmask.release(); ctx->d_scan_tmp.release(); ctx->d_records.release();
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int dsa_get_limits(const dsa_ctx*, dsa_limits* out)
+{
+    if (!out) return DSA_E_ARG;
+    out->max_read_len = 8000;       // V = H + 2j <= 4*Lq must fit int16
+    out->max_ref_len = 255 * W;     // chunk index is 8 bits in ReplayTask
+    out->tile_cols = W;
+    return DSA_OK;
+}
+
+const char* dsa_last_error(const dsa_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int dsa_set_stream(dsa_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return DSA_E_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return DSA_OK;
+}
+
+int dsa_synchronize(dsa_ctx* ctx)
+{
+    if (!ctx) return DSA_E_ARG;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return DSA_OK;
+}
+
+int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions,
+               int32_t n_fusions, const uint8_t* read_bytes, int64_t read_bytes_len, const dsa_pair* pairs,
+               int64_t n_pairs)
+{
+    if (!ctx) return DSA_E_ARG;
+    if (n_fusions < 0 || n_pairs < 0 || ref_bytes_len < 0 || read_bytes_len < 0)
+        return fail(ctx, DSA_E_ARG, "negative size");
+    if ((n_fusions && !fusions) || (n_pairs && !pairs) || (ref_bytes_len && !ref_bytes) || (read_bytes_len && !read_bytes))
+        return fail(ctx, DSA_E_ARG, "null pointer with non-zero size");
+    dsa_limits lim;
+    dsa_get_limits(ctx, &lim);
+    for (int32_t f = 0; f < n_fusions; ++f) {
+        const dsa_fusion& fu = fusions[f];
+        if (fu.ref0_len < 0 || fu.ref1_len < 0 || fu.ref0_off < 0 || fu.ref1_off < 0 ||
+            (int64_t)fu.ref0_off + fu.ref0_len > ref_bytes_len || (int64_t)fu.ref1_off + fu.ref1_len > ref_bytes_len)
+            return fail(ctx, DSA_E_ARG, "fusion %d: reference window outside ref_bytes", f);
+        if (fu.ref0_len > lim.max_ref_len || fu.ref1_len > lim.max_ref_len)
+            return fail(ctx, DSA_E_LIMIT, "fusion %d: reference window longer than %d", f, lim.max_ref_len);
+    }
+    int lqmax = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const dsa_pair& pr = pairs[p];
+        if (pr.fusion_idx < 0 || pr.fusion_idx >= n_fusions) return fail(ctx, DSA_E_ARG, "pair %lld: bad fusion_idx", (long long)p);
+        if (pr.read_len < 0 || pr.read_off < 0 || (int64_t)pr.read_off + pr.read_len > read_bytes_len)
+            return fail(ctx, DSA_E_ARG, "pair %lld: read outside read_bytes", (long long)p);
+        if (pr.read_len > lim.max_read_len) return fail(ctx, DSA_E_LIMIT, "pair %lld: read longer than %d", (long long)p, lim.max_read_len);
+        lqmax = std::max(lqmax, (int)pr.read_len);
+    }
+    HIPC(hipSetDevice(ctx->device));
+    ctx->have_results = false;
+    ctx->n_records = 0;
+    ctx->n_pairs = n_pairs;
+    ctx->n_fusions = n_fusions;
+    ctx->ref_bytes_len = ref_bytes_len;
+    ctx->read_bytes_len = read_bytes_len;
+    HIPC(ctx->d_ref.reserve((size_t)ref_bytes_len + 1));
+    HIPC(ctx->d_reads.reserve((size_t)read_bytes_len + 1));
+    HIPC(ctx->d_fusions.reserve((size_t)n_fusions + 1));
+    HIPC(ctx->d_pairs.reserve((size_t)n_pairs + 1));
+    hipStream_t st = ctx->stream;
+    if (ref_bytes_len) HIPC(hipMemcpyAsync(ctx->d_ref.p, ref_bytes, ref_bytes_len, hipMemcpyHostToDevice, st));
+    if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
+    if (n_fusions) HIPC(hipMemcpyAsync(ctx->d_fusions.p, fusions, n_fusions * sizeof(dsa_fusion), hipMemcpyHostToDevice, st));
+    if (n_pairs) HIPC(hipMemcpyAsync(ctx->d_pairs.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+    std::vector<int32_t> tab(lqmax + 1);
+    for (int l = 0; l <= lqmax; ++l) tab[l] = min_score_for(l);
+    HIPC(ctx->d_min_score.reserve(tab.size()));
+    HIPC(hipMemcpyAsync(ctx->d_min_score.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return build_slices(ctx, fusions, pairs, n_pairs);
+}
+
+int dsa_run(dsa_ctx* ctx, int64_t* out_n)
+{
+    if (!ctx) return DSA_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    ctx->n_records = 0;
+    ctx->timing = dsa_timing{};
+    ctx->timing.cells = ctx->total_cells;
+    for (const Slice& s : ctx->slices)
+        if (int rc = run_slice(ctx, s)) return rc;
+    ctx->timing.n_records = ctx->n_records;
+    ctx->have_results = true;
+    if (out_n) *out_n = ctx->n_records;
+    return DSA_OK;
+}
+
+int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n)
+{
+    if (!ctx || !ctx->have_results) return fail(ctx, DSA_E_ARG, "dsa_download before dsa_run");
+    if (out_n) *out_n = ctx->n_records;
+    if (ctx->n_records > out_cap) return fail(ctx, DSA_E_CAPACITY, "need room for %lld records", (long long)ctx->n_records);
+    if (ctx->n_records) {
+        if (!out) return fail(ctx, DSA_E_ARG, "null output");
+        HIPC(hipMemcpyAsync(out, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+    }
+    return DSA_OK;
+}
+
+int dsa_get_timing(const dsa_ctx* ctx, dsa_timing* out)
+{
+    if (!ctx || !out) return DSA_E_ARG;
+    *out = ctx->timing;
+    return DSA_OK;
+}
+
+int dsa_align_batch(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions,
+                    int32_t n_fusions, const uint8_t* read_bytes, int64_t read_bytes_len, const dsa_pair* pairs,
+                    int64_t n_pairs, dsa_record* out, int64_t out_cap, int64_t* out_n)
+{
+    if (int rc = dsa_upload(ctx, ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs))
+        return rc;
+    int64_t n = 0;
+    if (int rc = dsa_run(ctx, &n)) return rc;
+    return dsa_download(ctx, out, out_cap, out_n);
+}
+
+}  // extern "C"

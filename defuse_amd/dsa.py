@@ -1,0 +1,161 @@
+"""ctypes binding of include/defuse_dsa.h (libdefuse_dsa.so, HIP/gfx950).
+
+No CPU fallback: if the library is missing or there is no GPU, construction raises.
+The numpy structured dtypes mirror the C structs byte for byte.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdefuse_dsa.so")
+
+FUSION_DTYPE = np.dtype([("fusion_id", "<i4"), ("ref0_off", "<i4"), ("ref0_len", "<i4"),
+                         ("ref1_off", "<i4"), ("ref1_len", "<i4")])
+PAIR_DTYPE = np.dtype([("fusion_idx", "<i4"), ("read_off", "<i4"), ("read_len", "<i4"), ("frag", "<i4"),
+                       ("read_end", "u1"), ("revcomp", "u1"), ("pad_", "u1", (2,))])
+RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "revcomp", "ref_first",
+                                             "ref_second", "read_first", "read_second", "score")])
+assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 36
+
+EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_align_batch",
+           "dsa_upload", "dsa_run", "dsa_download", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
+
+DSA_E_CAPACITY = -1
+
+
+class Limits(ctypes.Structure):
+    _fields_ = [("max_read_len", ctypes.c_int32), ("max_ref_len", ctypes.c_int32), ("tile_cols", ctypes.c_int32)]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("pack_ms", ctypes.c_float), ("fill_ms", ctypes.c_float), ("finish_ms", ctypes.c_float),
+                ("total_ms", ctypes.c_float), ("fill_launches", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("cells", ctypes.c_int64), ("n_records", ctypes.c_int64), ("n_replay_tasks", ctypes.c_int64)]
+
+
+class DsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dsa error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libdefuse_dsa.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s missing: run `python -m defuse_amd.build`" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        lib.dsa_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+        lib.dsa_destroy.argtypes = [vp]
+        lib.dsa_destroy.restype = None
+        lib.dsa_get_limits.argtypes = [vp, ctypes.POINTER(Limits)]
+        lib.dsa_last_error.argtypes = [vp]
+        lib.dsa_last_error.restype = ctypes.c_char_p
+        lib.dsa_version.restype = ctypes.c_char_p
+        batch = [vp, vp, i64, vp, i32, vp, i64, vp, i64]
+        lib.dsa_align_batch.argtypes = batch + [vp, i64, ctypes.POINTER(i64)]
+        lib.dsa_upload.argtypes = batch
+        lib.dsa_run.argtypes = [vp, ctypes.POINTER(i64)]
+        lib.dsa_download.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
+        lib.dsa_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
+        lib.dsa_set_stream.argtypes = [vp, vp]
+        lib.dsa_synchronize.argtypes = [vp]
+        _lib = lib
+    return _lib
+
+
+def _check_arrays(ref_bytes, fusions, read_bytes, pairs):
+    ref_bytes = np.ascontiguousarray(ref_bytes, dtype=np.uint8)
+    read_bytes = np.ascontiguousarray(read_bytes, dtype=np.uint8)
+    fusions = np.ascontiguousarray(fusions, dtype=FUSION_DTYPE)
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+    return ref_bytes, fusions, read_bytes, pairs
+
+
+class Context:
+    """One dsa_ctx (one device).  Mirrors the staged C API: upload -> run -> download."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.dsa_create(ctypes.byref(self.h), int(device))
+        if rc != 0:
+            raise DsaError(rc, "dsa_create failed (no HIP device %d?)" % device)
+        self._keep = None
+
+    def close(self):
+        if self.h:
+            self.lib.dsa_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        raise DsaError(rc, self.lib.dsa_last_error(self.h).decode())
+
+    def limits(self):
+        lim = Limits()
+        self.lib.dsa_get_limits(self.h, ctypes.byref(lim))
+        return lim
+
+    def set_stream(self, stream_ptr):
+        self.lib.dsa_set_stream(self.h, ctypes.c_void_p(stream_ptr))
+
+    def upload(self, ref_bytes, fusions, read_bytes, pairs):
+        ref_bytes, fusions, read_bytes, pairs = _check_arrays(ref_bytes, fusions, read_bytes, pairs)
+        rc = self.lib.dsa_upload(self.h, ref_bytes.ctypes.data, ref_bytes.size, fusions.ctypes.data, len(fusions),
+                                 read_bytes.ctypes.data, read_bytes.size, pairs.ctypes.data, len(pairs))
+        if rc != 0:
+            self._err(rc)
+
+    def run(self):
+        n = ctypes.c_int64(0)
+        rc = self.lib.dsa_run(self.h, ctypes.byref(n))
+        if rc != 0:
+            self._err(rc)
+        return n.value
+
+    def download(self):
+        n = ctypes.c_int64(0)
+        rc = self.lib.dsa_download(self.h, None, 0, ctypes.byref(n))
+        if rc not in (0, DSA_E_CAPACITY):
+            self._err(rc)
+        out = np.zeros(n.value, dtype=RECORD_DTYPE)
+        if n.value:
+            rc = self.lib.dsa_download(self.h, out.ctypes.data, n.value, ctypes.byref(n))
+            if rc != 0:
+                self._err(rc)
+        return out
+
+    def timing(self):
+        t = Timing()
+        self.lib.dsa_get_timing(self.h, ctypes.byref(t))
+        return t
+
+    def align_batch(self, ref_bytes, fusions, read_bytes, pairs):
+        """dsa_align_batch: host arrays in, numpy record array out."""
+        ref_bytes, fusions, read_bytes, pairs = _check_arrays(ref_bytes, fusions, read_bytes, pairs)
+        cap = max(1024, 2 * len(pairs))
+        while True:
+            out = np.zeros(cap, dtype=RECORD_DTYPE)
+            n = ctypes.c_int64(0)
+            rc = self.lib.dsa_align_batch(self.h, ref_bytes.ctypes.data, ref_bytes.size, fusions.ctypes.data,
+                                          len(fusions), read_bytes.ctypes.data, read_bytes.size, pairs.ctypes.data,
+                                          len(pairs), out.ctypes.data, cap, ctypes.byref(n))
+            if rc == 0:
+                return out[:n.value].copy()
+            if rc == DSA_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            self._err(rc)

@@ -1,0 +1,80 @@
+"""Synthetic candidate batches for the split-read DP (BASELINE.json configs).
+
+make_batch() builds what dosplitalign's candidate enumeration would hand to the aligner for a set
+of synthetic fusions: per fusion two reference windows of `lr` random bases and `reads_per_fusion`
+reads of `lq` bases that cross the fusion junction at read offset 4..lq-4, with 1 % substitutions
+and 0.5 % of the reads carrying one 'N'.  Deterministic in (seed, sizes); numpy only.
+"""
+import numpy as np
+
+from .dsa import FUSION_DTYPE, PAIR_DTYPE
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def window_length(ufrag, sfrag, min_read, max_read, region_len):
+    """Lr of SURVEY 8(a): breakLen + maxRead with the reference's integer arithmetic
+    (tools/SplitAlignment.cpp:37-38,61-76,637-655)."""
+    max_frag = int(ufrag + 3 * sfrag)
+    push = min(max_read, int(0.5 * region_len))
+    return max_frag - region_len - min_read + 2 * push + max_read
+
+
+def make_batch(n_fusions, reads_per_fusion, lq=76, lr=389, seed=2, sub_rate=0.01, n_rate=0.005,
+               decoy_frac=0.0):
+    """Returns (ref_bytes, fusions, read_bytes, pairs) as numpy arrays in the C-ABI layout.
+
+    decoy_frac: fraction of reads replaced by random sequence (candidates that do not align)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    F, P = int(n_fusions), int(reads_per_fusion)
+    ref = _ACGT[rng.integers(0, 4, size=(F, 2, lr), dtype=np.uint8)]
+    ref_bytes = ref.reshape(-1)
+    fusions = np.zeros(F, dtype=FUSION_DTYPE)
+    fusions["fusion_id"] = np.arange(F, dtype=np.int32)
+    fusions["ref0_off"] = np.arange(F, dtype=np.int64) * 2 * lr
+    fusions["ref0_len"] = lr
+    fusions["ref1_off"] = np.arange(F, dtype=np.int64) * 2 * lr + lr
+    fusions["ref1_len"] = lr
+    # junction: read = ref0[first-a:first] + ref1[s1:s1+lq-a]
+    first = rng.integers(lq, lr, size=F)               # prefix length of window 0 kept by the fusion
+    s1 = rng.integers(0, lr - lq + 1, size=F)          # first base of window 1 kept by the fusion
+    n = F * P
+    fidx = np.repeat(np.arange(F, dtype=np.int64), P)
+    a = rng.integers(4, lq - 4 + 1, size=n)
+    k = np.arange(lq, dtype=np.int64)[None, :]
+    left = k < a[:, None]
+    src = np.where(left,
+                   (fidx * 2 * lr + first[fidx] - a)[:, None] + k,
+                   (fidx * 2 * lr + lr + s1[fidx] - a)[:, None] + k)
+    reads = ref_bytes[src]
+    sub = rng.random(size=reads.shape) < sub_rate
+    if sub.any():
+        cur = np.searchsorted(_ACGT, reads[sub])  # A,C,G,T are sorted ascending in ASCII
+        reads[sub] = _ACGT[(cur + rng.integers(1, 4, size=cur.size)) % 4]
+    has_n = rng.random(size=n) < n_rate
+    if has_n.any():
+        rows = np.nonzero(has_n)[0]
+        reads[rows, rng.integers(0, lq, size=rows.size)] = ord("N")
+    if decoy_frac > 0:
+        dec = np.nonzero(rng.random(size=n) < decoy_frac)[0]
+        reads[dec] = _ACGT[rng.integers(0, 4, size=(dec.size, lq), dtype=np.uint8)]
+    pairs = np.zeros(n, dtype=PAIR_DTYPE)
+    pairs["fusion_idx"] = fidx
+    pairs["read_off"] = np.arange(n, dtype=np.int64) * lq
+    pairs["read_len"] = lq
+    pairs["frag"] = np.arange(n, dtype=np.int32)
+    pairs["read_end"] = (np.arange(n) & 1).astype(np.uint8)
+    pairs["revcomp"] = ((np.arange(n) >> 1) & 1).astype(np.uint8)
+    return ref_bytes.copy(), fusions, reads.reshape(-1).copy(), pairs
+
+
+def cells_per_align(lq, lr):
+    return 2 * (lr + 1) * (lq + 1)
+
+
+def algorithmic_bytes_per_align(lq, lr, reads_per_fusion, records_per_align):
+    """2-bit bases + 1-bit non-ACGT mask, references amortised over the reads of a
+    fusion, a 12-byte work descriptor in and one 36-byte record out per emitted alignment."""
+    c4 = lambda x: -(-x // 4)
+    c8 = lambda x: -(-x // 8)
+    return c4(lq) + c8(lq) + 2.0 * (c4(lr) + c8(lr)) / reads_per_fusion + 12 + 36.0 * records_per_align

@@ -1,0 +1,131 @@
+/*
+ * defuse_dsa.h — C ABI of the MI355X split-read alignment path ("dsa" = defuse split align).
+ *
+ * The reference (amcpherson/defuse) has no FFI: its boundary is the process boundary of the
+ * `dosplitalign` tool.  Inside that tool the hot path is one C++ call,
+ *
+ *     SplitAlignmentTask::Align(aligner, readInfo, readSeq)        tools/SplitAlignment.cpp:371-444
+ *       -> SplitReadAligner::Align(read, ref1, ref2)               tools/SplitReadAligner.cpp:77-89
+ *            -> FillMatrix x2                                      tools/SplitReadAligner.cpp:24-75
+ *       -> SplitReadAligner::GetAlignments(minScore,true,false,false)  tools/SplitReadAligner.cpp:156-298
+ *       -> refSplit de-duplication, score=min(score1,score2)       tools/SplitAlignment.cpp:381-400
+ *
+ * executed once per candidate (fusion, read, revComp) inside SplitReadRealigner::DoAlignment
+ * (tools/SplitAlignment.cpp:266-303).  dsa_align_batch() below replaces exactly that call for a
+ * whole batch of candidates; the entries of dsa_record are the nine integer columns that
+ * SplitAlignment::WriteAlignment prints (tools/SplitAlignment.cpp:305-317).
+ *
+ * Plain C types only: no torch, no HIP types.  All pointers given to the *_batch entry points are
+ * HOST pointers unless the name says "_dev".  Every function returns 0 on success and a negative
+ * DSA_E* code on failure; nothing throws across this boundary.  A ctx is bound to one device and
+ * must not be used from two threads at once (one ctx per thread is fine).
+ */
+#ifndef DEFUSE_DSA_H_
+#define DEFUSE_DSA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSA_OK            0
+#define DSA_E_CAPACITY  (-1)   /* out_cap too small; *out_n holds the required count            */
+#define DSA_E_DEVICE    (-2)   /* HIP error (no device, launch failure, out of memory)          */
+#define DSA_E_ARG       (-3)   /* inconsistent arguments (offsets out of range, negative sizes) */
+#define DSA_E_LIMIT     (-4)   /* a length exceeds what the kernels support (see dsa_limits)    */
+
+/* Scoring is fixed by the reference (tools/SplitAlignment.cpp:25-29, :234):
+ * match +2, mismatch -1, gap -2, minSplitScore = minAnchor*match = 8, endGaps=false. */
+#define DSA_MATCH       2
+#define DSA_MISMATCH  (-1)
+#define DSA_GAP       (-2)
+#define DSA_MIN_SPLIT   8
+
+typedef struct dsa_ctx dsa_ctx;
+
+/* One candidate fusion = SplitAlignmentTask: two reference windows, mSplitAlignSeq[0] and [1]
+ * (tools/SplitAlignment.h:69), given as offsets into one concatenated byte buffer.  Bytes are
+ * compared raw (tools/SplitReadAligner.cpp:51), so 'N'=='N' matches and case matters. */
+typedef struct dsa_fusion {
+    int32_t fusion_id;            /* mFusionID, copied to the records                            */
+    int32_t ref0_off, ref0_len;   /* mSplitAlignSeq[0] (as fetched, forward)                     */
+    int32_t ref1_off, ref1_len;   /* mSplitAlignSeq[1] (as fetched; the kernel reverses it)      */
+} dsa_fusion;
+
+/* One candidate (fusion, read) = one call of SplitAlignmentTask::Align.  The read bytes are already
+ * oriented (reverse-complemented by the caller iff revcomp, tools/SplitAlignment.cpp:286-290). */
+typedef struct dsa_pair {
+    int32_t fusion_idx;           /* index into fusions[]                                        */
+    int32_t read_off, read_len;   /* into read_bytes                                             */
+    int32_t frag;                 /* ReadID.fragmentIndex                                        */
+    uint8_t read_end;             /* ReadID.readEnd (0/1)                                        */
+    uint8_t revcomp;              /* SplitReadInfo.revComp                                       */
+    uint8_t pad_[2];
+} dsa_pair;
+
+/* One output line of dosplitalign (tools/SplitAlignment.cpp:305-317). */
+typedef struct dsa_record {
+    int32_t fusion_id, frag, read_end, revcomp;
+    int32_t ref_first, ref_second;      /* refSplit  */
+    int32_t read_first, read_second;    /* readSplit */
+    int32_t score;                      /* min(score1, score2) */
+} dsa_record;
+
+typedef struct dsa_limits {
+    int32_t max_read_len;         /* longest read the DP kernels accept                          */
+    int32_t max_ref_len;          /* longest reference window                                    */
+    int32_t tile_cols;            /* DP tile width (reference columns per register tile)         */
+} dsa_limits;
+
+/* Timings of the most recent dsa_run / dsa_align_batch, measured with HIP events on the ctx stream. */
+typedef struct dsa_timing {
+    float   pack_ms;              /* byte -> code packing kernels                                */
+    float   fill_ms;              /* the DP fill kernel(s) — the dominant kernel                 */
+    float   finish_ms;            /* combine + tile replay + emit kernels                        */
+    float   total_ms;             /* first kernel start -> last kernel end                       */
+    int32_t fill_launches;        /* number of DP fill launches in fill_ms                       */
+    int32_t pad_;
+    int64_t cells;                /* DP cells filled: sum over pairs of 2*(Lref+1)*(Lread+1)     */
+    int64_t n_records;
+    int64_t n_replay_tasks;       /* tiles re-run to enumerate tied columns                      */
+} dsa_timing;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int  dsa_create(dsa_ctx** out, int device);     /* device = HIP ordinal; fails (DSA_E_DEVICE) without a GPU */
+void dsa_destroy(dsa_ctx* ctx);
+int  dsa_get_limits(const dsa_ctx* ctx, dsa_limits* out);
+const char* dsa_last_error(const dsa_ctx* ctx); /* human-readable text for the last failure      */
+const char* dsa_version(void);
+
+/* ---- one-shot: host buffers in, host records out ----------------------------------------- */
+/* Records are ordered by pair index, then in the reference's emission order (read split a
+ * ascending, ref1 column ascending, ref2 column ascending), after refSplit de-duplication. */
+int dsa_align_batch(dsa_ctx* ctx,
+                    const uint8_t* ref_bytes, int64_t ref_bytes_len,
+                    const dsa_fusion* fusions, int32_t n_fusions,
+                    const uint8_t* read_bytes, int64_t read_bytes_len,
+                    const dsa_pair* pairs, int64_t n_pairs,
+                    dsa_record* out, int64_t out_cap, int64_t* out_n);
+
+/* ---- staged: keep the batch resident in HBM, run it repeatedly (bench, multi-pass callers) - */
+/* pairs must be grouped by fusion_idx (all pairs of one fusion contiguous) for best throughput;
+ * correctness does not depend on it. */
+int dsa_upload(dsa_ctx* ctx,
+               const uint8_t* ref_bytes, int64_t ref_bytes_len,
+               const dsa_fusion* fusions, int32_t n_fusions,
+               const uint8_t* read_bytes, int64_t read_bytes_len,
+               const dsa_pair* pairs, int64_t n_pairs);
+int dsa_run(dsa_ctx* ctx, int64_t* out_n);                       /* all kernels, records stay on device */
+int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n);
+int dsa_get_timing(const dsa_ctx* ctx, dsa_timing* out);
+/* Use an existing HIP stream (e.g. torch's current stream) instead of the ctx's own; pass the
+ * hipStream_t as an opaque pointer, NULL restores the private stream. */
+int dsa_set_stream(dsa_ctx* ctx, void* hip_stream);
+int dsa_synchronize(dsa_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFUSE_DSA_H_ */

@@ -1,0 +1,146 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMOKE = os.path.join(ROOT, "tests", "golden", "smoke")
+
+
+@pytest.fixture(scope="module")
+def ora(built):
+    from oracle import dosplitalign_oracle as o
+    return o
+
+
+def as_tuples(recs):
+    return [tuple(int(x) for x in r) for r in recs]
+
+
+def check_batch(gpu_ctx, ora, batch):
+    got = gpu_ctx.align_batch(*batch)
+    exp = ora.align_batch(*batch)
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert got.tobytes() == exp.tobytes()
+    return got
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_parity_mixed(gpu_ctx, ora, seed):
+    got = check_batch(gpu_ctx, ora, cases.mixed_batch(seed))
+    assert len(got) > 50
+
+
+def test_parity_long_reads_many_tiles(gpu_ctx, ora):
+    # 2x150-like geometry: Lq=150, Lr ~ 585 -> 10 tiles; also reads longer than one tile
+    got = check_batch(gpu_ctx, ora, cases.mixed_batch(11, n_fusions=4, reads_per_fusion=30, lq=150, lr=(500, 600)))
+    assert len(got) > 20
+
+
+def test_parity_ties(gpu_ctx, ora):
+    got = check_batch(gpu_ctx, ora, cases.tie_batch(4))
+    # the tie cases must really produce multi-record pairs
+    frags, counts = np.unique(got["frag"], return_counts=True)
+    assert counts.max() > 10
+
+
+def test_parity_edges(gpu_ctx, ora):
+    check_batch(gpu_ctx, ora, cases.edge_batch())
+
+
+def test_empty_batch(gpu_ctx):
+    from defuse_amd import dsa
+    out = gpu_ctx.align_batch(np.zeros(0, np.uint8), np.zeros(0, dsa.FUSION_DTYPE), np.zeros(0, np.uint8),
+                              np.zeros(0, dsa.PAIR_DTYPE))
+    assert len(out) == 0
+
+
+def test_bad_arguments(gpu_ctx):
+    from defuse_amd import dsa
+    ref, fus, reads, pairs = cases.edge_batch()
+    bad = pairs.copy()
+    bad["fusion_idx"][0] = len(fus)
+    with pytest.raises(dsa.DsaError) as e:
+        gpu_ctx.align_batch(ref, fus, reads, bad)
+    assert e.value.code == -3
+    bad = pairs.copy()
+    bad["read_off"][3] = reads.size
+    with pytest.raises(dsa.DsaError):
+        gpu_ctx.align_batch(ref, fus, reads, bad)
+
+
+def test_smoke_vector_through_gpu(gpu_ctx, ora):
+    """The reference's known-answer vector, candidates enumerated by the host-logic restatement,
+    DP on the GPU."""
+    from defuse_amd import dsa
+    d = SMOKE + "/"
+    tasks = ora.create_tasks(d + "ref.fa", d + "exons.txt", 300, 30, 50, 50, ora.read_align_region_pairs(d + "regions.txt"))
+    reads = {}
+    ora.read_fastq(d + "reads.1.fastq", reads)
+    ora.read_fastq(d + "reads.2.fastq", reads)
+    bb = cases.BatchBuilder()
+    fidx = {}
+    for t, frag, rend, revcomp, seq in ora.enumerate_candidates(tasks, reads, d + "improper.sam"):
+        if t.fusion_id not in fidx:
+            fidx[t.fusion_id] = bb.add_fusion(t.seq[0], t.seq[1], fusion_id=t.fusion_id)
+        bb.add_read(fidx[t.fusion_id], seq, frag=frag, read_end=rend, revcomp=revcomp)
+    got = gpu_ctx.align_batch(*bb.arrays())
+    exp = [tuple(int(x) for x in l.split()) for l in open(d + "expected.split.align.txt")]
+    assert as_tuples(got) == exp
+
+
+def test_slicing_gives_same_records(built, ora):
+    """A tiny scratch budget forces several slices; the concatenation must not change anything."""
+    from defuse_amd import dsa
+    batch = cases.mixed_batch(21, n_fusions=10, reads_per_fusion=150, lq=40, lr=(80, 200))
+    os.environ["DEFUSE_DSA_SCRATCH_MB"] = "1"
+    try:
+        ctx = dsa.Context(0)
+    finally:
+        del os.environ["DEFUSE_DSA_SCRATCH_MB"]
+    got = ctx.align_batch(*batch)
+    assert ctx.timing().fill_launches > 1
+    ctx.close()
+    exp = ora.align_batch(*batch)
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_full_size_properties(gpu_ctx, ora):
+    """BASELINE config 2 at full size (10k fusions x 100 reads, 2x76): size-independent properties
+    plus an oracle check on a random sample of fusions."""
+    from defuse_amd import synth
+    lq, lr, F, P = 76, 389, 10000, 100
+    ref, fus, reads, pairs = synth.make_batch(F, P, lq=lq, lr=lr, seed=2)
+    gpu_ctx.upload(ref, fus, reads, pairs)
+    n = gpu_ctx.run()
+    got = gpu_ctx.download()
+    assert n == len(got) and n > 0.9 * F * P
+    t = gpu_ctx.timing()
+    assert t.cells == F * P * synth.cells_per_align(lq, lr)
+    # structural invariants of SplitReadAligner::GetAlignments output
+    assert (got["read_first"] + got["read_second"] == lq).all()
+    assert (got["score"] >= 8).all() and (got["score"] <= 2 * np.maximum(got["read_first"], got["read_second"])).all()
+    assert (got["ref_first"] >= 1).all() and (got["ref_first"] <= lr).all()
+    assert (got["ref_second"] >= -1).all() and (got["ref_second"] < lr - 1).all()
+    assert (np.diff(got["frag"]) >= 0).all()                       # ordered by pair
+    key = np.stack([got["frag"], got["ref_first"], got["ref_second"]], axis=1)
+    assert len(np.unique(key, axis=0)) == len(key)                 # refSplit de-duplicated per pair
+    # idempotence: a second run over the resident batch gives identical bytes
+    assert gpu_ctx.run() == n
+    assert gpu_ctx.download().tobytes() == got.tobytes()
+    # oracle on a sample of whole fusions
+    rng = np.random.default_rng(0)
+    sample = np.sort(rng.choice(F, size=12, replace=False))
+    sel = np.isin(pairs["fusion_idx"], sample)
+    exp = ora.align_batch(ref, fus, reads, pairs[sel])
+    sub = got[np.isin(got["fusion_id"], sample)]
+    assert sub.tobytes() == exp.tobytes()
+    # order independence: the same fusions presented in reverse order give the same records per pair
+    order = np.argsort(-pairs["fusion_idx"][sel], kind="stable")
+    rev = gpu_ctx.align_batch(ref, fus, reads, pairs[sel][order])
+    assert sorted(as_tuples(rev)) == sorted(as_tuples(exp))
