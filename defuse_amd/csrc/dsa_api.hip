@@ -45,7 +45,9 @@ struct DevBuf {
 
 struct Slice {
     int64_t pair_begin = 0, pair_end = 0;
-    std::vector<WTask> wtasks;
+    std::vector<WaveInfo> waves;     // one per 64 pairs
+    std::vector<WgInfo> wgs;         // one per 256 pairs
+    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GMAX fusions)
     Geom g{};
 };
 
@@ -69,12 +71,17 @@ struct dsa_ctx {
     int64_t total_cells = 0;
 
     // scratch
-    DevBuf<WTask> d_wtasks;
+    DevBuf<WaveInfo> d_waves;
+    DevBuf<WgInfo> d_wgs;
+    DevBuf<uint32_t> d_wg_generic;
     DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax;
     DevBuf<PairState> d_state;
-    DevBuf<int64_t> d_task_count, d_task_offset, d_rec_count, d_rec_offset;
+    DevBuf<KeptRow> d_kept;
+    DevBuf<int64_t> d_rec_count, d_rec_offset;
     DevBuf<ReplayTask> d_tasks;
-    DevBuf<uint64_t> d_colmask;
+    DevBuf<uint64_t> d_masks;
+    DevBuf<Counters> d_ctr;
+    DevBuf<int16_t> d_mscratch;
     DevBuf<uint8_t> d_scan_tmp;
     DevBuf<dsa_record> d_records;
     int64_t n_records = 0;
@@ -115,71 +122,73 @@ int min_score_for(int lq)
     return (int)((double)f * 0.90);
 }
 
-size_t slice_scratch_bytes(int64_t n_wtasks, int lq1, int nch)
+size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 {
-    size_t rows = (size_t)n_wtasks * lq1 * WAVE * 4;
+    size_t rows = (size_t)n_waves * lq1 * WAVE * 4;
     return rows + 2 * rows * (size_t)nch;
 }
 
-// Build the wave-task list.  A block is up to 128 consecutive pairs that share one fusion; each
-// block becomes two wave tasks (matrix 0, matrix 1).  Slices bound the scratch footprint.
+// Slices bound the scratch footprint; inside a slice pair p lives in wave p/64, lane p%64.
+// Per wave the loop bounds, per workgroup (256 pairs) the distinct fusions for the fast path.
 int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
 {
     ctx->slices.clear();
     ctx->total_cells = 0;
-    Slice cur;
-    cur.pair_begin = 0;
-    int lq1 = 1, nch = 1;
-    auto flush = [&](int64_t end) {
-        if (cur.wtasks.empty()) return;
-        cur.pair_end = end;
-        cur.g.n_wtasks = (int32_t)cur.wtasks.size();
-        cur.g.n_blocks = cur.g.n_wtasks / 2;
+    int64_t p = 0;
+    while (p < n_pairs) {
+        Slice cur;
+        cur.pair_begin = p;
+        int lq1 = 1, nch = 1;
+        while (p < n_pairs) {
+            // one workgroup worth of pairs at a time
+            const int64_t e = std::min<int64_t>(n_pairs, p + WG_LANES);
+            int nlq1 = lq1, nnch = nch;
+            for (int64_t q = p; q < e; ++q) {
+                const dsa_fusion& fu = fusions[pairs[q].fusion_idx];
+                nlq1 = std::max(nlq1, (int)pairs[q].read_len + 1);
+                nnch = std::max(nnch, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
+            }
+            const int64_t waves_after = (int64_t)cur.waves.size() + cdiv((int)(e - p), WAVE);
+            if (!cur.waves.empty() && slice_scratch_bytes(waves_after, nlq1, nnch) > ctx->scratch_budget) break;
+            lq1 = nlq1;
+            nch = nnch;
+            WgInfo wg{};
+            bool too_many = false;
+            for (int64_t wq = p; wq < e; wq += WAVE) {
+                WaveInfo wi{0, 0};
+                const int64_t we = std::min<int64_t>(e, wq + WAVE);
+                for (int64_t q = wq; q < we; ++q) {
+                    const int f = pairs[q].fusion_idx;
+                    const dsa_fusion& fu = fusions[f];
+                    wi.lq_max = std::max(wi.lq_max, (int)pairs[q].read_len);
+                    wi.nch_max = std::max(wi.nch_max, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
+                    ctx->total_cells += (int64_t)(fu.ref0_len + 1 + fu.ref1_len + 1) * (pairs[q].read_len + 1);
+                    bool found = false;
+                    for (int k = 0; k < wg.n_groups; ++k) found |= wg.group_f[k] == f;
+                    if (!found) {
+                        if (wg.n_groups < GMAX)
+                            wg.group_f[wg.n_groups++] = f;
+                        else
+                            too_many = true;
+                    }
+                }
+                cur.waves.push_back(wi);
+            }
+            if (too_many) wg.n_groups = 0;
+            cur.wgs.push_back(wg);
+            cur.wg_flags.push_back(too_many ? 1u : 0u);
+            p = e;
+        }
+        cur.pair_end = p;
+        cur.g.n_waves = (int32_t)cur.waves.size();
+        cur.g.n_wgs = (int32_t)cur.wgs.size();
         cur.g.lq1 = lq1;
         cur.g.nch = nch;
         cur.g.lrp = nch * W;
         cur.g.n_fusions = ctx->n_fusions;
-        cur.g.n_pairs = end - cur.pair_begin;
+        cur.g.n_pairs = cur.pair_end - cur.pair_begin;
         ctx->slices.push_back(std::move(cur));
-        cur = Slice();
-        cur.pair_begin = end;
-        lq1 = 1;
-        nch = 1;
-    };
-    int64_t p = 0;
-    while (p < n_pairs) {
-        const int f = pairs[p].fusion_idx;
-        int64_t e = p;
-        int lqmax = 0;
-        while (e < n_pairs && e - p < PAIRS_PER_WTASK && pairs[e].fusion_idx == f) {
-            lqmax = std::max(lqmax, (int)pairs[e].read_len);
-            ctx->total_cells += (int64_t)(fusions[f].ref0_len + 1 + fusions[f].ref1_len + 1) * (pairs[e].read_len + 1);
-            ++e;
-        }
-        const int nlq1 = std::max(lq1, lqmax + 1);
-        const int nnch = std::max(nch, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
-        if (!cur.wtasks.empty() &&
-            slice_scratch_bytes((int64_t)cur.wtasks.size() + 2, nlq1, nnch) > ctx->scratch_budget) {
-            flush(p);
-            continue;   // re-evaluate this block against a fresh slice
-        }
-        lq1 = nlq1;
-        nch = nnch;
-        for (int m = 0; m < 2; ++m) {
-            WTask wt;
-            wt.pair_base = (int32_t)(p - cur.pair_begin);
-            wt.n_pairs = (int32_t)(e - p);
-            wt.fusion_idx = f;
-            wt.matrix = m;
-            wt.lr = m ? fusions[f].ref1_len : fusions[f].ref0_len;
-            wt.lq_max = lqmax;
-            wt.n_chunks = cdiv(wt.lr, W);
-            wt.pad_ = 0;
-            cur.wtasks.push_back(wt);
-        }
-        p = e;
     }
-    flush(n_pairs);
     return DSA_OK;
 }
 
@@ -199,6 +208,19 @@ float elapsed(hipEvent_t a, hipEvent_t b)
     return ms;
 }
 
+int grow_records(dsa_ctx* ctx, size_t need)
+{
+    if (need <= ctx->d_records.cap) return DSA_OK;
+    DevBuf<dsa_record> bigger;
+    HIPC(bigger.reserve(need + need / 2 + 1024));
+    if (ctx->n_records)
+        HIPC(hipMemcpyAsync(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    ctx->d_records.release();
+    ctx->d_records = bigger;
+    return DSA_OK;
+}
+
 int run_slice(dsa_ctx* ctx, const Slice& s)
 {
     const Geom g = s.g;
@@ -206,85 +228,108 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
 
-    const size_t n_rows = (size_t)g.n_wtasks * g.lq1 * WAVE;
-    HIPC(ctx->d_wtasks.reserve(s.wtasks.size()));
-    HIPC(ctx->d_refcodes.reserve((size_t)g.n_fusions * 2 * g.lrp));
+    const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
+    HIPC(ctx->d_waves.reserve(s.waves.size()));
+    HIPC(ctx->d_wgs.reserve(s.wgs.size()));
+    HIPC(ctx->d_wg_generic.reserve(s.wg_flags.size()));
+    HIPC(ctx->d_refcodes.reserve((size_t)g.n_fusions * g.lrp));
     HIPC(ctx->d_rowcodes.reserve(n_rows));
     HIPC(ctx->d_bnd.reserve(n_rows * g.nch));
     HIPC(ctx->d_cmax.reserve(n_rows * g.nch));
     HIPC(ctx->d_state.reserve(np));
-    HIPC(ctx->d_task_count.reserve(np + 1));
-    HIPC(ctx->d_task_offset.reserve(np + 1));
     HIPC(ctx->d_rec_count.reserve(np + 1));
     HIPC(ctx->d_rec_offset.reserve(np + 1));
-    HIPC(hipMemcpyAsync(ctx->d_wtasks.p, s.wtasks.data(), s.wtasks.size() * sizeof(WTask), hipMemcpyHostToDevice, st));
+    HIPC(ctx->d_ctr.reserve(1));
+    HIPC(ctx->d_kept.reserve((size_t)np * 2 + 1024));
+    HIPC(ctx->d_tasks.reserve((size_t)np * 4 + 1024));
+    HIPC(ctx->d_masks.reserve((size_t)np * 8 + 1024));
+    if (int rc = grow_records(ctx, (size_t)ctx->n_records + (size_t)np * 2 + 1024)) return rc;
+    HIPC(hipMemcpyAsync(ctx->d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 
     // ---- pack -------------------------------------------------------------------------------
     HIPC(hipEventRecord(ctx->ev[0], st));
     {
-        int64_t total = (int64_t)g.n_fusions * 2 * g.lrp;
+        int64_t total = (int64_t)g.n_fusions * g.lrp;
         hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p,
                            ctx->d_fusions.p, ctx->d_refcodes.p, g);
         total = (int64_t)n_rows;
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
-                           ctx->d_wtasks.p, ctx->d_rowcodes.p, g);
+                           ctx->d_rowcodes.p, ctx->d_wg_generic.p, g);
     }
     HIPC(hipEventRecord(ctx->ev[1], st));
-    // ---- fill -------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(g.n_wtasks, 4)), dim3(256), 0, st, ctx->d_wtasks.p,
-                       ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, g);
+    // ---- fill: every workgroup is run by exactly one of the two kernels ---------------------------
+    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p, ctx->d_wgs.p,
+                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, g);
+    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p,
+                       ctx->d_fusions.p, ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p,
+                       ctx->d_cmax.p, g);
     HIPC(hipEventRecord(ctx->ev[2], st));
     HIPC(hipGetLastError());
-    // ---- finish -----------------------------------------------------------------------------
-    const int64_t n_slots = (int64_t)g.n_blocks * PAIRS_PER_WTASK;
-    const unsigned slot_grid = (unsigned)((n_slots + 255) / 256);
-    HIPC(hipMemsetAsync(ctx->d_task_count.p, 0, (np + 1) * sizeof(int64_t), st));
-    HIPC(hipMemsetAsync(ctx->d_rec_count.p, 0, (np + 1) * sizeof(int64_t), st));
-    hipLaunchKernelGGL(k_combine<false>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
-                       ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_task_count.p,
-                       (const int64_t*)nullptr, (ReplayTask*)nullptr, g);
-    if (int rc = exclusive_scan(ctx, ctx->d_task_count.p, ctx->d_task_offset.p, np + 1)) return rc;
-    int64_t n_tasks = 0;
-    HIPC(hipMemcpyAsync(&n_tasks, ctx->d_task_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    HIPC(ctx->d_tasks.reserve((size_t)n_tasks + 1));
-    HIPC(ctx->d_colmask.reserve((size_t)n_tasks + 1));
-    hipLaunchKernelGGL(k_combine<true>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
-                       ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_task_count.p,
-                       (const int64_t*)ctx->d_task_offset.p, ctx->d_tasks.p, g);
-    if (n_tasks > 0)
-        hipLaunchKernelGGL(k_replay, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, st, ctx->d_tasks.p, n_tasks,
-                           ctx->d_wtasks.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_colmask.p, g);
-    hipLaunchKernelGGL(k_emit<false>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
-                       ctx->d_state.p, ctx->d_task_count.p, ctx->d_tasks.p, ctx->d_colmask.p, ctx->d_rec_count.p,
-                       (const int64_t*)nullptr, (dsa_record*)nullptr, g);
-    if (int rc = exclusive_scan(ctx, ctx->d_rec_count.p, ctx->d_rec_offset.p, np + 1)) return rc;
+    // ---- finish: combine -> replay -> emit, no host round trip unless a buffer overflowed --------
+    // combine keeps m1(a), m2(b) of every pair of the block in LDS: 2*(Lq+1) int16 per thread
+    const int cthreads = g.lq1 <= 128 ? 128 : 64;
+    const size_t lds_need = (size_t)2 * g.lq1 * cthreads * sizeof(int16_t);
+    if (lds_need > 64 * 1024) return fail(ctx, DSA_E_LIMIT, "reads longer than 255 are not supported");
+    const unsigned pair_grid = (unsigned)((np + 255) / 256);
+    Counters ctr{};
     int64_t n_rec = 0;
-    HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
-        // grow, keeping what earlier slices wrote
-        DevBuf<dsa_record> bigger;
-        HIPC(bigger.reserve((size_t)(ctx->n_records + n_rec) * 2 + 1024));
-        if (ctx->n_records)
-            HIPC(hipMemcpyAsync(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, st));
+    bool redo_combine = true;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (redo_combine) {
+            HIPC(hipMemsetAsync(ctx->d_ctr.p, 0, sizeof(Counters), st));
+            if (cthreads == 128)
+                hipLaunchKernelGGL(k_combine<128>, dim3((unsigned)((np + 127) / 128)), dim3(128), lds_need, st, pairs,
+                                   ctx->d_fusions.p, ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
+                                   (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
+                                   (uint64_t)ctx->d_masks.cap, ctx->d_ctr.p, g);
+            else
+                hipLaunchKernelGGL(k_combine<64>, dim3((unsigned)((np + 63) / 64)), dim3(64), lds_need, st, pairs,
+                                   ctx->d_fusions.p, ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
+                                   (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
+                                   (uint64_t)ctx->d_masks.cap, ctx->d_ctr.p, g);
+            hipLaunchKernelGGL(k_replay, dim3(256 * 8), dim3(256), 0, st, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
+                               ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, pairs,
+                               ctx->d_fusions.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_masks.p,
+                               (uint64_t)ctx->d_masks.cap, g);
+            hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
+                               ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p, (const int64_t*)nullptr,
+                               (dsa_record*)nullptr, (uint64_t)0, g);
+            HIPC(hipMemsetAsync(ctx->d_rec_count.p + np, 0, sizeof(int64_t), st));
+            if (int rc = exclusive_scan(ctx, ctx->d_rec_count.p, ctx->d_rec_offset.p, np + 1)) return rc;
+        }
+        hipLaunchKernelGGL(k_emit<true>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
+                           ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p,
+                           (const int64_t*)ctx->d_rec_offset.p, ctx->d_records.p + ctx->n_records,
+                           (uint64_t)(ctx->d_records.cap - ctx->n_records), g);
+        HIPC(hipEventRecord(ctx->ev[3], st));
+        HIPC(hipMemcpyAsync(&ctr, ctx->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
-        ctx->d_records.release();
-        ctx->d_records = bigger;
+        HIPC(hipGetLastError());
+        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap;
+        if (redo_combine) {
+            HIPC(ctx->d_kept.reserve(ctr.n_kept + 1024));
+            HIPC(ctx->d_tasks.reserve(ctr.n_tasks + 1024));
+            HIPC(ctx->d_masks.reserve(ctr.n_masks + 1024));
+            continue;
+        }
+        if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
+            if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
+            continue;
+        }
+        break;
     }
-    hipLaunchKernelGGL(k_emit<true>, dim3(slot_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_wtasks.p,
-                       ctx->d_state.p, ctx->d_task_count.p, ctx->d_tasks.p, ctx->d_colmask.p, ctx->d_rec_count.p,
-                       (const int64_t*)ctx->d_rec_offset.p, ctx->d_records.p + ctx->n_records, g);
-    HIPC(hipEventRecord(ctx->ev[3], st));
-    HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(st));
+    if (redo_combine || (size_t)(ctx->n_records + n_rec) > ctx->d_records.cap)
+        return fail(ctx, DSA_E_DEVICE, "finish stage did not converge");
     ctx->n_records += n_rec;
     ctx->timing.pack_ms += elapsed(ctx->ev[0], ctx->ev[1]);
     ctx->timing.fill_ms += elapsed(ctx->ev[1], ctx->ev[2]);
     ctx->timing.finish_ms += elapsed(ctx->ev[2], ctx->ev[3]);
     ctx->timing.total_ms += elapsed(ctx->ev[0], ctx->ev[3]);
     ctx->timing.fill_launches += 1;
-    ctx->timing.n_replay_tasks += n_tasks;
+    ctx->timing.n_replay_tasks += (int64_t)ctr.n_tasks;
     return DSA_OK;
 }
 
@@ -326,10 +371,11 @@ void dsa_destroy(dsa_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
-    ctx->d_min_score.release(); ctx->d_wtasks.release(); ctx->d_refcodes.release(); ctx->d_rowcodes.release();
-    ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_state.release(); ctx->d_task_count.release();
-    ctx->d_task_offset.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release(); ctx->d_tasks.release();
-    ctx->d_colmask.release(); ctx->d_scan_tmp.release(); ctx->d_records.release();
+    ctx->d_min_score.release(); ctx->d_waves.release(); ctx->d_wgs.release(); ctx->d_wg_generic.release();
+    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release();
+    ctx->d_state.release(); ctx->d_kept.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release();
+    ctx->d_tasks.release(); ctx->d_masks.release(); ctx->d_ctr.release(); ctx->d_mscratch.release();
+    ctx->d_scan_tmp.release(); ctx->d_records.release();
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -339,7 +385,7 @@ void dsa_destroy(dsa_ctx* ctx)
 int dsa_get_limits(const dsa_ctx*, dsa_limits* out)
 {
     if (!out) return DSA_E_ARG;
-    out->max_read_len = 8000;       // V = H + 2j <= 4*Lq must fit int16
+    out->max_read_len = 255;        // combine keeps 2*(Lq+1) int16 per pair in LDS; V = H+2j <= 4*Lq fits int16
     out->max_ref_len = 255 * W;     // chunk index is 8 bits in ReplayTask
     out->tile_cols = W;
     return DSA_OK;
