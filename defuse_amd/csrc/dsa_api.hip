@@ -74,7 +74,7 @@ struct dsa_ctx {
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
-    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax;
+    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax;
     DevBuf<PairState> d_state;
     DevBuf<KeptRow> d_kept;
     DevBuf<int64_t> d_rec_count, d_rec_offset;
@@ -125,7 +125,7 @@ int min_score_for(int lq)
 size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 {
     size_t rows = (size_t)n_waves * lq1 * WAVE * 4;
-    return rows + 2 * rows * (size_t)nch;
+    return 2 * rows + 2 * rows * (size_t)nch;
 }
 
 // Slices bound the scratch footprint; inside a slice pair p lives in wave p/64, lane p%64.
@@ -236,6 +236,7 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(ctx->d_rowcodes.reserve(n_rows));
     HIPC(ctx->d_bnd.reserve(n_rows * g.nch));
     HIPC(ctx->d_cmax.reserve(n_rows * g.nch));
+    HIPC(ctx->d_rmax.reserve(n_rows));
     HIPC(ctx->d_state.reserve(np));
     HIPC(ctx->d_rec_count.reserve(np + 1));
     HIPC(ctx->d_rec_offset.reserve(np + 1));
@@ -261,17 +262,14 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(hipEventRecord(ctx->ev[1], st));
     // ---- fill: every workgroup is run by exactly one of the two kernels ---------------------------
     hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p, ctx->d_wgs.p,
-                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, g);
+                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, ctx->d_rmax.p, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p,
                        ctx->d_fusions.p, ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p,
-                       ctx->d_cmax.p, g);
+                       ctx->d_cmax.p, ctx->d_rmax.p, g);
     HIPC(hipEventRecord(ctx->ev[2], st));
     HIPC(hipGetLastError());
     // ---- finish: combine -> replay -> emit, no host round trip unless a buffer overflowed --------
-    // combine keeps m1(a), m2(b) of every pair of the block in LDS: 2*(Lq+1) int16 per thread
-    const int cthreads = g.lq1 <= 128 ? 128 : 64;
-    const size_t lds_need = (size_t)2 * g.lq1 * cthreads * sizeof(int16_t);
-    if (lds_need > 64 * 1024) return fail(ctx, DSA_E_LIMIT, "reads longer than 255 are not supported");
+    if (g.lq1 > 7601) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");
     const unsigned pair_grid = (unsigned)((np + 255) / 256);
     Counters ctr{};
     int64_t n_rec = 0;
@@ -279,20 +277,14 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (redo_combine) {
             HIPC(hipMemsetAsync(ctx->d_ctr.p, 0, sizeof(Counters), st));
-            if (cthreads == 128)
-                hipLaunchKernelGGL(k_combine<128>, dim3((unsigned)((np + 127) / 128)), dim3(128), lds_need, st, pairs,
-                                   ctx->d_fusions.p, ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
-                                   (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
-                                   (uint64_t)ctx->d_masks.cap, ctx->d_ctr.p, g);
-            else
-                hipLaunchKernelGGL(k_combine<64>, dim3((unsigned)((np + 63) / 64)), dim3(64), lds_need, st, pairs,
-                                   ctx->d_fusions.p, ctx->d_cmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
-                                   (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
-                                   (uint64_t)ctx->d_masks.cap, ctx->d_ctr.p, g);
+            hipLaunchKernelGGL(k_combine, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_cmax.p,
+                               ctx->d_rmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
+                               (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
+                               (uint64_t)(ctx->d_masks.cap / 2), ctx->d_ctr.p, g);
             hipLaunchKernelGGL(k_replay, dim3(256 * 8), dim3(256), 0, st, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
                                ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, pairs,
                                ctx->d_fusions.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_masks.p,
-                               (uint64_t)ctx->d_masks.cap, g);
+                               (uint64_t)(ctx->d_masks.cap / 2), g);
             hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
                                ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p, (const int64_t*)nullptr,
                                (dsa_record*)nullptr, (uint64_t)0, g);
@@ -308,11 +300,11 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
         HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         HIPC(hipGetLastError());
-        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap;
+        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap / 2;
         if (redo_combine) {
             HIPC(ctx->d_kept.reserve(ctr.n_kept + 1024));
             HIPC(ctx->d_tasks.reserve(ctr.n_tasks + 1024));
-            HIPC(ctx->d_masks.reserve(ctr.n_masks + 1024));
+            HIPC(ctx->d_masks.reserve(2 * ctr.n_masks + 1024));
             continue;
         }
         if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
@@ -372,7 +364,7 @@ void dsa_destroy(dsa_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
     ctx->d_min_score.release(); ctx->d_waves.release(); ctx->d_wgs.release(); ctx->d_wg_generic.release();
-    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release();
+    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_rmax.release();
     ctx->d_state.release(); ctx->d_kept.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release();
     ctx->d_tasks.release(); ctx->d_masks.release(); ctx->d_ctr.release(); ctx->d_mscratch.release();
     ctx->d_scan_tmp.release(); ctx->d_records.release();
@@ -385,7 +377,7 @@ void dsa_destroy(dsa_ctx* ctx)
 int dsa_get_limits(const dsa_ctx*, dsa_limits* out)
 {
     if (!out) return DSA_E_ARG;
-    out->max_read_len = 255;        // combine keeps 2*(Lq+1) int16 per pair in LDS; V = H+2j <= 4*Lq fits int16
+    out->max_read_len = 7600;       // V + 1024 = H + 2j + 1024 <= 4*Lq + 1024 must stay a finite fp16 pattern (< 0x7C00)
     out->max_ref_len = 255 * W;     // chunk index is 8 bits in ReplayTask
     out->tile_cols = W;
     return DSA_OK;

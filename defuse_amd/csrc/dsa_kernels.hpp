@@ -15,11 +15,17 @@
 //   * the matrices are swept in column tiles of W=64 reference positions held in 64 VGPRs; rows
 //     (read bases) are the outer runtime loop.  State V(i,j) = H(i,j) + 2j makes the "left" move free:
 //         V(i,j) = max( V(i-1,j-1) + (eq ? 4 : 1),  V(i-1,j) - 2,  V(i,j-1) )
-//     pass 1 (descending i, in place)  X[i] = max(X[i-1] + d(i), X[i])
-//     pass 2 (ascending i)             X[i] = max(X[i], X[i-1] - 2)
+//     one ascending pass per row, in place:  X[i] = max3(Xold[i-1] + d(i), Xold[i], Xnew[i-1] - 2)
+//   * instruction mix chosen from measured gfx950 issue rates (profiles/microbench): 32-bit add/sub/xor
+//     issue in 2 cycles, every packed (VOP3P) op and every 32-bit min/max in 4.  So the two int16
+//     fields are added with plain v_add_u32 (SWAR: fields are kept in [1024, 31743] so no carry or
+//     borrow ever crosses), and both maxima of a cell pair come from ONE v_pk_maximum3_f16: positive
+//     normal fp16 bit patterns order exactly like the integers they spell, and maximum3 returns one
+//     of its inputs unchanged.  Per column (2 cells): 2 adds + 1 max3 + 1/2 max3 for the row maximum
+//     = 10 issue cycles, against 20 for the obvious pk_add/pk_max formulation.
 //   * fast path (reads over {A,C,G,T,N}): the substitution term d(i) of both matrices comes out of
-//     a per-(fusion,tile) score table in LDS with one ds_read_b128 per 4 columns: 5 packed VALU ops
-//     per 2 cells.  Generic path (any bytes): d(i) from xor/min: 8 ops.
+//     a per-(fusion,tile) score table in LDS with one ds_read_b128 per 4 columns.  Generic path (any
+//     bytes): d(i) from xor + pk_min.
 //   * per (tile,row) the kernel stores the tile's row maximum and the tile's last column (the
 //     boundary the next tile starts from).  The finish kernels pick the winning rows and replay only
 //     the winning tiles from the stored boundaries to enumerate tied columns — exact, at a few
@@ -47,16 +53,32 @@ constexpr int NCOMBO = NCLS * NCLS;
 constexpr int TROW = W + 4;           // table row stride in dwords (+4: rotate banks between rows)
 constexpr int GMAX = 4;               // max distinct fusions per workgroup on the fast path
 constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
-constexpr int T_PADCOL = -12000;      // substitution term of padded reference columns
+// Stored values are V + 1024 per int16 field: always a positive normal fp16 bit pattern.
+constexpr uint32_t BIAS16 = 0x0400u;
+constexpr uint32_t BIAS2 = 0x04000400u;
+constexpr uint32_t TWO2 = 0x00020002u;
+constexpr uint32_t FOUR2 = 0x00040004u;
 
-typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
-__device__ __forceinline__ v2u as_v2u(uint32_t x) { return __builtin_bit_cast(v2u, x); }
-__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ v2u vminu(v2u a, v2u b) { return __builtin_elementwise_min(a, b); }
+// packed maxima on biased fields, via fp16 maximum (v_pk_maximum3_f16 on gfx950)
+__device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b)));
+}
+__device__ __forceinline__ uint32_t max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_bit_cast(uint32_t,
+                              __builtin_elementwise_maximum(
+                                  __builtin_elementwise_maximum(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b)),
+                                  __builtin_bit_cast(v2h, c)));
+}
+__device__ __forceinline__ uint32_t min3u(uint32_t x)   // per field min(x, 3)
+{
+    const v2u three = {3, 3};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u, x), three));
+}
 
 struct WaveInfo {
     int32_t lq_max;        // longest read among the wave's pairs
@@ -86,13 +108,15 @@ struct KeptRow {           // one winning read split of a pair that has columns 
     int16_t pad_;
 };
 
-// A tile to re-run: all kept rows of one pair in one (matrix, chunk).
+// A tile pair to re-run: all kept rows of one pair in tile chunk0 of M1 (lo half) and tile chunk1 of
+// M2 (hi half) in one sweep — both matrices share the row index, so they replay together.
+constexpr uint8_t NO_CHUNK = 0xFF;
 struct ReplayTask {
     uint32_t pair;         // slice-relative
-    uint32_t mask_begin;   // masks[mask_begin + k] for kept row k of the pair
-    uint16_t last_row;     // largest row (in this matrix) that needs a mask
-    uint8_t  matrix;
-    uint8_t  chunk;
+    uint32_t mask_begin;   // masks[(mask_begin + k)*2 + h] for kept row k of the pair, matrix h
+    uint16_t last_row;     // largest row either matrix needs
+    uint8_t  chunk0;       // NO_CHUNK = nothing to replay on that side
+    uint8_t  chunk1;
 };
 
 struct PairState {
@@ -100,8 +124,8 @@ struct PairState {
     int32_t n_kept;        // kept rows with columns on both sides
     uint32_t kept_begin;
     uint32_t task_begin;
-    uint32_t n_tasks0;     // tasks of matrix 0 come first, then matrix 1
-    uint32_t n_tasks1;
+    uint32_t n_tasks;
+    uint32_t pad_;
 };
 
 struct Counters {          // device-side allocation cursors (and overflow detection)
@@ -109,7 +133,8 @@ struct Counters {          // device-side allocation cursors (and overflow detec
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
-__device__ __forceinline__ int half_of(uint32_t v, int h) { return (int)(int16_t)(v >> (16 * h)); }
+// unbiased V of one field
+__device__ __forceinline__ int half_of(uint32_t v, int h) { return (int)((v >> (16 * h)) & 0xFFFFu) - (int)BIAS16; }
 
 // ---------------------------------------------------------------------------------------------
 // K0: byte -> packed code, code16 = byte<<8.
@@ -161,55 +186,52 @@ __global__ void k_pack_rows(const uint8_t* __restrict__ read_bytes, const dsa_pa
 
 // ---------------------------------------------------------------------------------------------
 // Row step, generic scoring (any byte alphabet): per-lane reference codes in VGPRs.
-// X[i] holds V(i0+i, j-1) on entry and V(i0+i, j) on exit.
-//   bprev = V(i0-1, j-1), bcur = V(i0-1, j)   (the previous tile's last column; 0 for tile 0)
+// X[i] holds V(i0+i, j-1) on entry and V(i0+i, j) on exit (biased).
+//   bprev = V(i0-1, j-1), bcur = V(i0-1, j)   (the previous tile's last column; V=0 for tile 0)
+// The next column's diagonal term is formed before X[i] is overwritten, so the update is in place.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void row_step(v2s (&X)[W], const uint32_t (&r)[W], uint32_t cj, v2s bprev, v2s bcur)
+__device__ __forceinline__ void row_step(uint32_t (&X)[W], const uint32_t (&r)[W], uint32_t cj, uint32_t bprev,
+                                         uint32_t bcur)
 {
-    const v2u three = {3, 3};
-    const v2s four = {4, 4};
-    const v2s two = {2, 2};
-    // pass 1: diagonal and left candidates, descending so X[i-1] is still the previous row
-#pragma unroll
-    for (int i = W - 1; i >= 1; --i) {
-        v2u t = vminu(as_v2u(cj ^ r[i]), three);
-        v2s a = (X[i - 1] - __builtin_bit_cast(v2s, t)) + four;
-        X[i] = vmax(a, X[i]);
-    }
-    {
-        v2u t = vminu(as_v2u(cj ^ r[0]), three);
-        v2s a = (bprev - __builtin_bit_cast(v2s, t)) + four;
-        X[0] = vmax(a, X[0]);
-    }
-    // pass 2: the gap-in-read chain along the reference
-    X[0] = vmax(X[0], bcur - two);
-#pragma unroll
-    for (int i = 1; i < W; ++i) X[i] = vmax(X[i], X[i - 1] - two);
-}
-
-// tile row maximum with four interleaved accumulators (dependent packed ops are 1 wait state
-// apart on gfx950, so keep them from sitting back to back).  MASKED: only columns < nv0 / nv1.
-template <bool MASKED>
-__device__ __forceinline__ v2s tile_row_max(const v2s (&X)[W], int nv0, int nv1)
-{
-    const v2s neg = {-32768, -32768};
-    v2s acc4[4] = {neg, neg, neg, neg};
+    uint32_t a = (bprev + FOUR2) - min3u(cj ^ r[0]);
+    uint32_t prev_new = bcur;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
-        v2s x = X[i];
-        if (MASKED) {
-            if (i >= nv0) x.x = -32768;
-            if (i >= nv1) x.y = -32768;
-        }
-        acc4[i & 3] = vmax(acc4[i & 3], x);
+        uint32_t a_next = 0;
+        if (i + 1 < W) a_next = (X[i] + FOUR2) - min3u(cj ^ r[i + 1]);
+        X[i] = max3(a, X[i], prev_new - TWO2);
+        prev_new = X[i];
+        a = a_next;
     }
-    return vmax(vmax(acc4[0], acc4[1]), vmax(acc4[2], acc4[3]));
+}
+
+// tile row maximum: one max3 per two columns, two interleaved accumulators.
+// MASKED: only columns < nv0 (lo field) / nv1 (hi field) count.
+template <bool MASKED>
+__device__ __forceinline__ uint32_t tile_row_max(const uint32_t (&X)[W], int nv0, int nv1)
+{
+    uint32_t acc0 = BIAS2, acc1 = BIAS2;      // V >= 0 everywhere, so V = 0 is neutral
+#pragma unroll
+    for (int i = 0; i < W; i += 4) {
+        uint32_t x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x[k] = X[i + k];
+            if (MASKED) {
+                if (i + k >= nv0) x[k] = (x[k] & 0xFFFF0000u) | BIAS16;
+                if (i + k >= nv1) x[k] = (x[k] & 0x0000FFFFu) | (BIAS16 << 16);
+            }
+        }
+        acc0 = max3(acc0, x[0], x[1]);
+        acc1 = max3(acc1, x[2], x[3]);
+    }
+    return max2(acc0, acc1);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K1g: generic DP fill.  One wave = 64 pairs; 4 waves per workgroup.  Runs only the workgroups
 // flagged generic (exotic read bytes or more than GMAX fusions in the workgroup).
-//   cmax[((w*nch + c)*lq1 + j)*64 + lane] = max over the tile's valid columns of V(.,j)   (2 x i16)
+//   cmax[((w*nch + c)*lq1 + j)*64 + lane] = max over the tile's valid columns of V(.,j)   (2 x u16, biased)
 //   bnd [((w*nch + c)*lq1 + j)*64 + lane] = V(last column of tile c, j)
 // ---------------------------------------------------------------------------------------------
 template <bool MASKED>
@@ -217,17 +239,34 @@ __device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const
                                                    const uint32_t* __restrict__ bi, uint32_t* __restrict__ cm,
                                                    uint32_t* __restrict__ bo, int lq, bool first, int nv0, int nv1)
 {
-    v2s X[W];
+    uint32_t X[W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) X[i] = (v2s){0, 0};
-    v2s bprev = {0, 0};
+    for (int i = 0; i < W; ++i) X[i] = BIAS2;
+    uint32_t bprev = BIAS2;
+    uint32_t cj_next = rows[WAVE];
+    uint32_t b_next = first ? BIAS2 : bi[WAVE];
     for (int j = 1; j <= lq; ++j) {
-        const uint32_t cj = rows[(int64_t)j * WAVE];
-        const v2s bcur = first ? (v2s){0, 0} : as_v2s(bi[(int64_t)j * WAVE]);
+        const uint32_t cj = cj_next;
+        const uint32_t bcur = b_next;
+        const int jn = j < lq ? j + 1 : j;          // prefetch the next row's operands
+        cj_next = rows[(int64_t)jn * WAVE];
+        b_next = first ? BIAS2 : bi[(int64_t)jn * WAVE];
         row_step(X, r, cj, bprev, bcur);
         bprev = bcur;
-        cm[(int64_t)j * WAVE] = as_u32(tile_row_max<MASKED>(X, nv0, nv1));
-        bo[(int64_t)j * WAVE] = as_u32(X[W - 1]);
+        cm[(int64_t)j * WAVE] = tile_row_max<MASKED>(X, nv0, nv1);
+        bo[(int64_t)j * WAVE] = X[W - 1];
+    }
+}
+
+// After the last tile: rmax[(w*lq1 + j)*64 + lane] = max over tiles of cmax (both halves), so the
+// combine kernel reads one dword per row instead of one per tile.  cmax of this wave is L2-hot.
+__device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
+                                               const Geom& g, int w, int lane, int nch_wave, int lq)
+{
+    for (int j = 1; j <= lq; ++j) {
+        uint32_t m = BIAS2;
+        for (int c = 0; c < nch_wave; ++c) m = max2(m, cmax[(((int64_t)w * g.nch + c) * g.lq1 + j) * WAVE + lane]);
+        rmax[((int64_t)w * g.lq1 + j) * WAVE + lane] = m;
     }
 }
 
@@ -237,7 +276,8 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                                                            const uint32_t* __restrict__ wg_generic,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes,
-                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax, Geom g)
+                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
+                                                           uint32_t* __restrict__ rmax, Geom g)
 {
     if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
@@ -263,15 +303,18 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         else
             sweep_tile_generic<true>(r, rows, bi, cm, bo, wi.lq_max, c == 0, nv0, nv1);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
+    reduce_row_max(cmax, rmax, g, w, lane, wi.nch_max, wi.lq_max);
 }
 
 // ---------------------------------------------------------------------------------------------
 // K1f: fast DP fill (reads over {A,C,G,T,N}).  Per workgroup and tile, the substitution terms of
 // every fusion present are tabulated in LDS:
 //     T[g][k1*5+k2][i] = { d(ref0_g[i], base[k1]), d(rev(ref1_g)[i], base[k2]) },  d = eq ? 4 : 1
-// where k1/k2 are the classes of the M1 / M2 read base of the row.  Padded reference columns get a
-// large negative term, which keeps them strictly below every row maximum, so the tile row maximum
-// needs no masking.  A row then costs one ds_read_b128 per 4 columns and 5 packed VALU ops per column.
+// where k1/k2 are the classes of the M1 / M2 read base of the row.  Padded reference columns get
+// d = 0 (worse than a mismatch): their values can then reach but never exceed the row maximum of the
+// valid columns, so the tile row maximum needs no masking (the replay masks exclude them by index).
+// A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t base_class(uint32_t byte)   // A,C,T,G,N -> 0,1,2,3,4
 {
@@ -285,7 +328,8 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                                                            const uint32_t* __restrict__ wg_generic,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes,
-                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax, Geom g)
+                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
+                                                           uint32_t* __restrict__ rmax, Geom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
     __shared__ int s_nch;
@@ -322,9 +366,9 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
             const uint32_t c0 = code & 0xFFFFu, c1 = code >> 16;
             const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};   // inverse of base_class
-            const int d0 = c0 == REF_PAD16 ? T_PADCOL : ((c0 >> 8) == cls_byte[combo / NCLS] ? 4 : 1);
-            const int d1 = c1 == REF_PAD16 ? T_PADCOL : ((c1 >> 8) == cls_byte[combo % NCLS] ? 4 : 1);
-            T[gi * TGROUP + combo * TROW + i] = (uint32_t)(uint16_t)d0 | ((uint32_t)(uint16_t)d1 << 16);
+            const uint32_t d0 = c0 == REF_PAD16 ? 0u : ((c0 >> 8) == cls_byte[combo / NCLS] ? 4u : 1u);
+            const uint32_t d1 = c1 == REF_PAD16 ? 0u : ((c1 >> 8) == cls_byte[combo % NCLS] ? 4u : 1u);
+            T[gi * TGROUP + combo * TROW + i] = d0 | (d1 << 16);
         }
         __syncthreads();
         if (!live || c >= wi.nch_max) continue;   // wave-uniform
@@ -332,35 +376,53 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
         uint32_t* cm = cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
         uint32_t* bo = bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
         const uint32_t* bi = bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE + lane;
-        v2s X[W];
+        uint32_t X[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = (v2s){0, 0};
-        v2s bprev = {0, 0};
-        const v2s two = {2, 2};
+        for (int i = 0; i < W; ++i) X[i] = BIAS2;
+        uint32_t bprev = BIAS2;
+        uint32_t cj_next = rows[WAVE];
+        uint32_t b_next = (c == 0) ? BIAS2 : bi[WAVE];
         for (int j = 1; j <= wi.lq_max; ++j) {
-            const uint32_t cj = rows[(int64_t)j * WAVE];
-            const v2s bcur = (c == 0) ? (v2s){0, 0} : as_v2s(bi[(int64_t)j * WAVE]);
+            const uint32_t cj = cj_next;
+            const uint32_t bcur = b_next;
+            const int jn = j < wi.lq_max ? j + 1 : j;      // prefetch the next row's operands
+            cj_next = rows[(int64_t)jn * WAVE];
+            b_next = (c == 0) ? BIAS2 : bi[(int64_t)jn * WAVE];
             const uint32_t combo = base_class((cj >> 8) & 0xFFu) * NCLS + base_class(cj >> 24);
             const uint4* trow = reinterpret_cast<const uint4*>(tb + combo * TROW);
-            // pass 1, descending, four columns per LDS read
+            // one ascending pass, four columns per LDS read; the diagonal term of the next column is
+            // formed from X[i] before X[i] is overwritten (in-place update, no copies)
+            uint4 v = trow[0];
+            uint32_t a = bprev + v.x;
+            uint32_t prev_new = bcur;
 #pragma unroll
-            for (int q = W / 4 - 1; q >= 0; --q) {
-                const uint4 v = trow[q];
-                X[4 * q + 3] = vmax(X[4 * q + 2] + as_v2s(v.w), X[4 * q + 3]);
-                X[4 * q + 2] = vmax(X[4 * q + 1] + as_v2s(v.z), X[4 * q + 2]);
-                X[4 * q + 1] = vmax(X[4 * q + 0] + as_v2s(v.y), X[4 * q + 1]);
-                if (q > 0)
-                    X[4 * q] = vmax(X[4 * q - 1] + as_v2s(v.x), X[4 * q]);
-                else
-                    X[0] = vmax(bprev + as_v2s(v.x), X[0]);
+            for (int q = 0; q < W / 4; ++q) {
+                uint4 vn = v;
+                if (q + 1 < W / 4) vn = trow[q + 1];
+                uint32_t an;
+                an = X[4 * q + 0] + v.y;
+                X[4 * q + 0] = max3(a, X[4 * q + 0], prev_new - TWO2);
+                a = an;
+                an = X[4 * q + 1] + v.z;
+                X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0] - TWO2);
+                a = an;
+                an = X[4 * q + 2] + v.w;
+                X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1] - TWO2);
+                a = an;
+                an = X[4 * q + 3] + vn.x;
+                X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2] - TWO2);
+                a = an;
+                prev_new = X[4 * q + 3];
+                v = vn;
             }
-            X[0] = vmax(X[0], bcur - two);
-#pragma unroll
-            for (int i = 1; i < W; ++i) X[i] = vmax(X[i], X[i - 1] - two);
             bprev = bcur;
-            cm[(int64_t)j * WAVE] = as_u32(tile_row_max<false>(X, W, W));
-            bo[(int64_t)j * WAVE] = as_u32(X[W - 1]);
+            cm[(int64_t)j * WAVE] = tile_row_max<false>(X, W, W);
+            bo[(int64_t)j * WAVE] = X[W - 1];
         }
+    }
+    if (live) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
+        reduce_row_max(cmax, rmax, g, w, lane, wi.nch_max, wi.lq_max);
     }
 }
 
@@ -369,18 +431,11 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 // ---------------------------------------------------------------------------------------------
 // Row maximum of one matrix of pair p in H units with FindMaxRowEntry's acceptance rule
 // (tools/SplitReadAligner.cpp:91-102): values below minSplitScore (8) count as 0.
-__device__ __forceinline__ int row_max_h(const uint32_t* __restrict__ cmax, const Geom& g, int64_t p, int h,
+__device__ __forceinline__ int row_max_h(const uint32_t* __restrict__ rmax, const Geom& g, int64_t p, int h,
                                          int n_chunks, int row)
 {
     if (row == 0 || n_chunks == 0) return 0;   // H(i,0)=0 < 8; empty reference: only column 0 (<=0)
-    const int64_t w = p >> 6;
-    const int lane = (int)(p & 63);
-    int v = -32768;
-    for (int c = 0; c < n_chunks; ++c) {
-        int x = half_of(cmax[((w * g.nch + c) * g.lq1 + row) * WAVE + lane], h);
-        v = x > v ? x : v;
-    }
-    v -= 2 * row;
+    const int v = half_of(rmax[((p >> 6) * g.lq1 + row) * WAVE + (p & 63)], h) - 2 * row;
     return v >= DSA_MIN_SPLIT ? v : 0;
 }
 
@@ -400,72 +455,65 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* cou
     return base + (incl - n);
 }
 
+__device__ __forceinline__ int nth_set_bit(uint64_t m, int n)   // index of the n-th (0-based) set bit, -1 if none
+{
+    for (int k = 0; k < n && m; ++k) m &= m - 1;
+    return m ? __builtin_ctzll(m) : -1;
+}
+
 // K2: per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
 // have columns on both sides, and the tiles that hold a row maximum for them.  Single pass; space
 // comes from device cursors (capacities are checked by the host afterwards).
-template <int COMBINE_THREADS>
-__global__ __launch_bounds__(COMBINE_THREADS) void k_combine(
+__global__ __launch_bounds__(256) void k_combine(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
-    const int32_t* __restrict__ min_score_tab, PairState* __restrict__ state, KeptRow* __restrict__ kept,
-    uint64_t kept_cap, ReplayTask* __restrict__ tasks, uint64_t task_cap, uint64_t mask_cap,
-    Counters* __restrict__ ctr, Geom g)
+    const uint32_t* __restrict__ rmax, const int32_t* __restrict__ min_score_tab, PairState* __restrict__ state,
+    KeptRow* __restrict__ kept, uint64_t kept_cap, ReplayTask* __restrict__ tasks, uint64_t task_cap,
+    uint64_t mask_cap, Counters* __restrict__ ctr, Geom g)
 {
-    extern __shared__ int16_t s_m[];   // [2][lq1][COMBINE_THREADS]: m1(a), m2(b) per thread
-    const int tid = threadIdx.x;
-    const int64_t p = (int64_t)blockIdx.x * COMBINE_THREADS + tid;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = p < g.n_pairs;
     int lq = 0, nc0 = 0, nc1 = 0, max_score = 0, n_kept = 0;
     unsigned n_t0 = 0, n_t1 = 0;
-    int16_t* m1s = s_m + tid;
-    int16_t* m2s = s_m + (size_t)g.lq1 * COMBINE_THREADS + tid;
-    constexpr int S = COMBINE_THREADS;
+    uint64_t tiles0 = 0, tiles1 = 0;     // tiles that attain the maximum at some kept row
+    bool small = true;                   // references with more than 64 tiles replay every tile (exact, not minimal)
+    int first_a = 0, last_a = 0;
     if (active) {
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
         lq = pr.read_len;
         nc0 = cdiv_dev(fu.ref0_len, W);
         nc1 = cdiv_dev(fu.ref1_len, W);
+        small = nc0 <= 64 && nc1 <= 64;
         const int min_score = min_score_tab[lq];
         for (int a = 0; a <= lq; ++a) {
-            m1s[(size_t)a * S] = (int16_t)row_max_h(cmax, g, p, 0, nc0, a);
-            m2s[(size_t)a * S] = (int16_t)row_max_h(cmax, g, p, 1, nc1, a);
-        }
-        for (int a = 0; a <= lq; ++a) {
-            const int s = m1s[(size_t)a * S] + m2s[(size_t)(lq - a) * S];
+            const int s = row_max_h(rmax, g, p, 0, nc0, a) + row_max_h(rmax, g, p, 1, nc1, lq - a);
             if (s >= min_score && s > max_score) max_score = s;
         }
         if (max_score != 0) {
-            for (int a = 0; a <= lq; ++a) {
-                const int m1 = m1s[(size_t)a * S], m2 = m2s[(size_t)(lq - a) * S];
-                if (m1 + m2 == max_score && m1 != 0 && m2 != 0) ++n_kept;   // an empty side emits nothing
-            }
-        }
-    }
-    // tiles that attain the maximum at some kept row (bitmaps; references with more than 64 tiles
-    // replay every tile instead: exact, just not minimal)
-    uint64_t tiles0 = 0, tiles1 = 0;
-    const bool small = nc0 <= 64 && nc1 <= 64;
-    if (active && n_kept > 0) {
-        const int64_t w = p >> 6;
-        const int lane = (int)(p & 63);
-        if (small) {
+            const int64_t w = p >> 6;
+            const int lane = (int)(p & 63);
+            first_a = lq;
             for (int a = 0; a <= lq; ++a) {
                 const int b = lq - a;
-                const int m1 = m1s[(size_t)a * S], m2 = m2s[(size_t)b * S];
-                if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;
-                for (int c = 0; c < nc0; ++c)
-                    if (half_of(cmax[((w * g.nch + c) * g.lq1 + a) * WAVE + lane], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
-                for (int c = 0; c < nc1; ++c)
-                    if (half_of(cmax[((w * g.nch + c) * g.lq1 + b) * WAVE + lane], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
+                const int m1 = row_max_h(rmax, g, p, 0, nc0, a), m2 = row_max_h(rmax, g, p, 1, nc1, b);
+                if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;   // an empty side emits nothing
+                if (n_kept == 0) first_a = a;
+                last_a = a;
+                ++n_kept;
+                if (small) {
+                    for (int c = 0; c < nc0; ++c)
+                        if (half_of(cmax[((w * g.nch + c) * g.lq1 + a) * WAVE + lane], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
+                    for (int c = 0; c < nc1; ++c)
+                        if (half_of(cmax[((w * g.nch + c) * g.lq1 + b) * WAVE + lane], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
+                }
             }
-            n_t0 = (unsigned)__builtin_popcountll(tiles0);
-            n_t1 = (unsigned)__builtin_popcountll(tiles1);
-        } else {
-            n_t0 = (unsigned)nc0;
-            n_t1 = (unsigned)nc1;
+            if (n_kept > 0) {
+                n_t0 = small ? (unsigned)__builtin_popcountll(tiles0) : (unsigned)nc0;
+                n_t1 = small ? (unsigned)__builtin_popcountll(tiles1) : (unsigned)nc1;
+            }
         }
     }
-    const unsigned n_tasks = n_t0 + n_t1;
+    const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
     const unsigned long long kb = wave_alloc(&ctr->n_kept, (unsigned)n_kept);
     const unsigned long long tb = wave_alloc(&ctr->n_tasks, n_tasks);
     const unsigned long long mb = wave_alloc(&ctr->n_masks, n_tasks * (unsigned)n_kept);
@@ -475,8 +523,8 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(
     st.n_kept = n_kept;
     st.kept_begin = (uint32_t)kb;
     st.task_begin = (uint32_t)tb;
-    st.n_tasks0 = n_t0;
-    st.n_tasks1 = n_t1;
+    st.n_tasks = n_tasks;
+    st.pad_ = 0;
     if (n_kept > 0 &&
         (kb + n_kept > kept_cap || tb + n_tasks > task_cap || mb + (unsigned long long)n_tasks * n_kept > mask_cap)) {
         st.n_kept = 0;     // overflow: the host sees the cursors, grows the buffers and reruns the finish stage
@@ -485,9 +533,9 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(
     }
     state[p] = st;
     if (n_kept == 0) return;
-    int k = 0, last_a = 0, first_a = lq;
-    for (int a = 0; a <= lq; ++a) {
-        const int m1 = m1s[(size_t)a * S], m2 = m2s[(size_t)(lq - a) * S];
+    int k = 0;
+    for (int a = first_a; a <= last_a; ++a) {
+        const int m1 = row_max_h(rmax, g, p, 0, nc0, a), m2 = row_max_h(rmax, g, p, 1, nc1, lq - a);
         if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;
         KeptRow kr;
         kr.a = (int16_t)a;
@@ -495,40 +543,35 @@ __global__ __launch_bounds__(COMBINE_THREADS) void k_combine(
         kr.m2 = (int16_t)m2;
         kr.pad_ = 0;
         kept[kb + k] = kr;
-        if (k == 0) first_a = a;
-        last_a = a;
         ++k;
     }
-    unsigned t = 0;
-    for (int m = 0; m < 2; ++m) {
-        const int nc = m ? nc1 : nc0;
-        const uint64_t tiles = m ? tiles1 : tiles0;
-        for (int c = 0; c < nc; ++c) {
-            if (small && !((tiles >> c) & 1ull)) continue;
-            ReplayTask rt;
-            rt.pair = (uint32_t)p;
-            rt.mask_begin = (uint32_t)(mb + (unsigned long long)t * n_kept);
-            rt.last_row = (uint16_t)(m ? (lq - first_a) : last_a);
-            rt.matrix = (uint8_t)m;
-            rt.chunk = (uint8_t)c;
-            tasks[tb + t] = rt;
-            ++t;
-        }
+    for (unsigned t = 0; t < n_tasks; ++t) {
+        const int c0 = small ? nth_set_bit(tiles0, (int)t) : (t < n_t0 ? (int)t : -1);
+        const int c1 = small ? nth_set_bit(tiles1, (int)t) : (t < n_t1 ? (int)t : -1);
+        ReplayTask rt;
+        rt.pair = (uint32_t)p;
+        rt.mask_begin = (uint32_t)(mb + (unsigned long long)t * n_kept);
+        const int r0 = c0 >= 0 ? last_a : 0, r1 = c1 >= 0 ? lq - first_a : 0;
+        rt.last_row = (uint16_t)(r0 > r1 ? r0 : r1);
+        rt.chunk0 = c0 >= 0 ? (uint8_t)c0 : NO_CHUNK;
+        rt.chunk1 = c1 >= 0 ? (uint8_t)c1 : NO_CHUNK;
+        tasks[tb + t] = rt;
     }
 }
 
-// K3: replay one tile per lane from the stored boundary; for every kept row of the pair report, as a
-// 64-bit mask, the valid columns whose value equals the row maximum.  Grid-stride over the device
-// task counter (no host round trip between combine and replay).
-__global__ __launch_bounds__(256) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
-                                                const Counters* __restrict__ ctr, const PairState* __restrict__ state,
-                                                const KeptRow* __restrict__ kept, uint64_t kept_cap,
-                                                const dsa_pair* __restrict__ pairs,
-                                                const dsa_fusion* __restrict__ fusions,
-                                                const uint32_t* __restrict__ refcodes,
-                                                const uint32_t* __restrict__ rowcodes,
-                                                const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
-                                                uint64_t mask_cap, Geom g)
+// K3: replay one tile pair per lane from the stored boundaries; for every kept row of the pair report,
+// as 64-bit masks, the valid columns whose value equals the row maximum (lo half: M1 tile chunk0,
+// hi half: M2 tile chunk1).  Grid-stride over the device task counter (no host round trip).
+__global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+                                                   const Counters* __restrict__ ctr,
+                                                   const PairState* __restrict__ state,
+                                                   const KeptRow* __restrict__ kept, uint64_t kept_cap,
+                                                   const dsa_pair* __restrict__ pairs,
+                                                   const dsa_fusion* __restrict__ fusions,
+                                                   const uint32_t* __restrict__ refcodes,
+                                                   const uint32_t* __restrict__ rowcodes,
+                                                   const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
+                                                   uint64_t mask_cap, Geom g)
 {
     const unsigned long long n_tasks = ctr->n_tasks;
     if (n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap) return;   // overflow run
@@ -537,50 +580,72 @@ __global__ __launch_bounds__(256) void k_replay(const ReplayTask* __restrict__ t
         const ReplayTask rt = tasks[t];
         const int64_t p = rt.pair;
         const int64_t w = p >> 6;
-        const int lane = (int)(p & 63), h = rt.matrix, c = rt.chunk;
+        const int lane = (int)(p & 63);
+        const bool has0 = rt.chunk0 != NO_CHUNK, has1 = rt.chunk1 != NO_CHUNK;
+        const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
-        const int lr = h ? fu.ref1_len : fu.ref0_len;
         const PairState st = state[p];
         const int lq = pr.read_len;
-        const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp + c * W;
+        const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp;
         const uint32_t* rows = rowcodes + w * g.lq1 * WAVE + lane;
-        const uint32_t* bi = bnd + (w * g.nch + (c - 1)) * g.lq1 * WAVE + lane;
+        const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE + lane;
+        const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE + lane;
         const KeptRow* kr = kept + st.kept_begin;
 
         uint32_t r[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) r[i] = rc[i];
-        v2s X[W];
+        for (int i = 0; i < W; ++i) {
+            const uint32_t lo = has0 ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
+            const uint32_t hi = has1 ? (rc[c1 * W + i] & 0xFFFF0000u) : (REF_PAD16 << 16);
+            r[i] = lo | hi;
+        }
+        uint32_t X[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = (v2s){0, 0};
-        v2s bprev = {0, 0};
+        for (int i = 0; i < W; ++i) X[i] = BIAS2;
+        uint32_t bprev = BIAS2;
         const int R = rt.last_row;
-        const int nvalid = min(W, lr - c * W);
-        // kept rows ascend in a: matrix 0 meets them in order k=0.., matrix 1 (row = lq-a) in reverse
-        int k = h ? st.n_kept - 1 : 0;
-        const int kstep = h ? -1 : 1;
+        const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
+        const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
+        // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
+        int k0 = 0, k1 = st.n_kept - 1;
+        uint32_t cj_next = rows[WAVE];
+        uint32_t b_next = (c0 > 0 ? (bi0[WAVE] & 0xFFFFu) : BIAS16) | (c1 > 0 ? (bi1[WAVE] & 0xFFFF0000u) : (BIAS16 << 16));
         for (int j = 1; j <= R; ++j) {
-            const uint32_t cj = rows[(int64_t)j * WAVE];
-            const v2s bcur = (c > 0) ? as_v2s(bi[(int64_t)j * WAVE]) : (v2s){0, 0};
+            const uint32_t cj = cj_next;
+            const uint32_t bcur = b_next;
+            const int jn = j < R ? j + 1 : j;
+            cj_next = rows[(int64_t)jn * WAVE];
+            b_next = (c0 > 0 ? (bi0[(int64_t)jn * WAVE] & 0xFFFFu) : BIAS16) |
+                     (c1 > 0 ? (bi1[(int64_t)jn * WAVE] & 0xFFFF0000u) : (BIAS16 << 16));
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
-            if (k >= 0 && k < st.n_kept) {
-                const KeptRow kk = kr[k];
-                const int row = h ? lq - kk.a : kk.a;
-                if (row == j) {
-                    const int target = (h ? kk.m2 : kk.m1) + 2 * j;
-                    uint64_t mask = 0;
+            const bool hit0 = has0 && k0 < st.n_kept && kr[k0].a == j;
+            const bool hit1 = has1 && k1 >= 0 && lq - kr[k1].a == j;
+            if (hit0) {
+                const uint32_t target = (uint32_t)(kr[k0].m1 + 2 * j) + BIAS16;
+                uint64_t mask = 0;
 #pragma unroll
-                    for (int i = 0; i < W; ++i) {
-                        const int v = h ? (int)X[i].y : (int)X[i].x;
-                        if (i < nvalid && v == target) mask |= (1ull << i);
-                    }
-                    masks[rt.mask_begin + k] = mask;
-                    k += kstep;
-                }
+                for (int i = 0; i < W; ++i)
+                    if (i < nv0 && (X[i] & 0xFFFFu) == target) mask |= (1ull << i);
+                masks[((uint64_t)rt.mask_begin + k0) * 2] = mask;
+                ++k0;
+            }
+            if (hit1) {
+                const uint32_t target = (uint32_t)(kr[k1].m2 + 2 * j) + BIAS16;
+                uint64_t mask = 0;
+#pragma unroll
+                for (int i = 0; i < W; ++i)
+                    if (i < nv1 && (X[i] >> 16) == target) mask |= (1ull << i);
+                masks[((uint64_t)rt.mask_begin + k1) * 2 + 1] = mask;
+                --k1;
             }
         }
+        // sides that were not replayed (or rows never reached) report no columns
+        if (!has0)
+            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
+        if (!has1)
+            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
     }
 }
 
@@ -588,11 +653,12 @@ __global__ __launch_bounds__(256) void k_replay(const ReplayTask* __restrict__ t
 // order (tools/SplitReadAligner.cpp:233-269), then the refSplit de-duplication of
 // tools/SplitAlignment.cpp:381-391 (first occurrence wins).  WRITE=false counts.
 __device__ __forceinline__ bool col_in(const ReplayTask* tasks, const uint64_t* masks, uint32_t tb, uint32_t te,
-                                       int k, int col /*1-based matrix column*/)
+                                       int k, int h, int col /*1-based matrix column*/)
 {
     const int c = (col - 1) / W, bit = (col - 1) % W;
     for (uint32_t q = tb; q < te; ++q)
-        if (tasks[q].chunk == c) return (masks[tasks[q].mask_begin + k] >> bit) & 1ull;
+        if ((h ? tasks[q].chunk1 : tasks[q].chunk0) == c)
+            return (masks[((uint64_t)tasks[q].mask_begin + k) * 2 + h] >> bit) & 1ull;
     return false;
 }
 
@@ -610,24 +676,26 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
     if (st.n_kept > 0) {
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
-        const uint32_t t0b = st.task_begin, t0e = t0b + st.n_tasks0, t1e = t0e + st.n_tasks1;
+        const uint32_t tb = st.task_begin, te = tb + st.n_tasks;
         int64_t wr = WRITE ? rec_offset[p] : 0;
         if (WRITE && (uint64_t)rec_offset[p + 1] > out_cap) return;   // host grows the buffer and reruns emit
         for (int k = 0; k < st.n_kept; ++k) {
             const KeptRow kr = kept[st.kept_begin + k];
-            for (uint32_t q1 = t0b; q1 < t0e; ++q1) {
-                uint64_t m1 = masks[tasks[q1].mask_begin + k];
+            for (uint32_t q1 = tb; q1 < te; ++q1) {        // tasks hold M1 tiles in ascending order
+                if (tasks[q1].chunk0 == NO_CHUNK) continue;
+                uint64_t m1 = masks[((uint64_t)tasks[q1].mask_begin + k) * 2];
                 while (m1) {
-                    const int i1 = tasks[q1].chunk * W + __builtin_ctzll(m1) + 1;
+                    const int i1 = tasks[q1].chunk0 * W + __builtin_ctzll(m1) + 1;
                     m1 &= m1 - 1;
-                    for (uint32_t q2 = t0e; q2 < t1e; ++q2) {
-                        uint64_t m2 = masks[tasks[q2].mask_begin + k];
+                    for (uint32_t q2 = tb; q2 < te; ++q2) {
+                        if (tasks[q2].chunk1 == NO_CHUNK) continue;
+                        uint64_t m2 = masks[((uint64_t)tasks[q2].mask_begin + k) * 2 + 1];
                         while (m2) {
-                            const int i2 = tasks[q2].chunk * W + __builtin_ctzll(m2) + 1;
+                            const int i2 = tasks[q2].chunk1 * W + __builtin_ctzll(m2) + 1;
                             m2 &= m2 - 1;
                             bool dup = false;     // same refSplit <=> same (i1,i2) at an earlier kept a
                             for (int k2 = 0; k2 < k && !dup; ++k2)
-                                dup = col_in(tasks, masks, t0b, t0e, k2, i1) && col_in(tasks, masks, t0e, t1e, k2, i2);
+                                dup = col_in(tasks, masks, tb, te, k2, 0, i1) && col_in(tasks, masks, tb, te, k2, 1, i2);
                             if (dup) continue;
                             if (WRITE) {
                                 dsa_record rec;
