@@ -149,7 +149,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
                 nnch = std::max(nnch, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
             }
             const int64_t waves_after = (int64_t)cur.waves.size() + cdiv((int)(e - p), WAVE);
-            if (!cur.waves.empty() && slice_scratch_bytes(waves_after, nlq1, nnch) > ctx->scratch_budget) break;
+            if (!cur.waves.empty() && slice_scratch_bytes(waves_after, (nlq1 + 3) & ~3, nnch) > ctx->scratch_budget) break;
             lq1 = nlq1;
             nch = nnch;
             WgInfo wg{};
@@ -182,7 +182,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
         cur.pair_end = p;
         cur.g.n_waves = (int32_t)cur.waves.size();
         cur.g.n_wgs = (int32_t)cur.wgs.size();
-        cur.g.lq1 = lq1;
+        cur.g.lq1 = (lq1 + 3) & ~3;     // row planes are stored four rows per 16-byte word
         cur.g.nch = nch;
         cur.g.lrp = nch * W;
         cur.g.n_fusions = ctx->n_fusions;
@@ -255,7 +255,7 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
         int64_t total = (int64_t)g.n_fusions * g.lrp;
         hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p,
                            ctx->d_fusions.p, ctx->d_refcodes.p, g);
-        total = (int64_t)n_rows;
+        total = (int64_t)n_rows / 4;
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
                            ctx->d_rowcodes.p, ctx->d_wg_generic.p, g);
     }

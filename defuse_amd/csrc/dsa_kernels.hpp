@@ -16,6 +16,9 @@
 //     (read bases) are the outer runtime loop.  State V(i,j) = H(i,j) + 2j makes the "left" move free:
 //         V(i,j) = max( V(i-1,j-1) + (eq ? 4 : 1),  V(i-1,j) - 2,  V(i,j-1) )
 //     one ascending pass per row, in place:  X[i] = max3(Xold[i-1] + d(i), Xold[i], Xnew[i-1] - 2)
+//     Register i of a tile holds V + 2i ("drift"), which turns the -2 of the along-the-reference move
+//     into 0: the serial chain of a row is then one max3 per column and nothing else; the drift is
+//     taken out again (one off-chain add) where columns are compared for the row maximum.
 //   * instruction mix chosen from measured gfx950 issue rates (profiles/microbench): 32-bit add/sub/xor
 //     issue in 2 cycles, every packed (VOP3P) op and every 32-bit min/max in 4.  So the two int16
 //     fields are added with plain v_add_u32 (SWAR: fields are kept in [1024, 31743] so no carry or
@@ -50,7 +53,9 @@ constexpr uint32_t ROW_PAD16 = 0x0055u;
 // fast path: read alphabet classes A,C,G,T,N -> 0..4 ; 25 (M1 base, M2 base) combinations per table
 constexpr int NCLS = 5;
 constexpr int NCOMBO = NCLS * NCLS;
-constexpr int TROW = W + 4;           // table row stride in dwords (+4: rotate banks between rows)
+constexpr int TROW = W + 4;           // table row stride in dwords: table row t starts at bank quad t mod 16, so
+                                      // the 16 rows of the A/C/G/T x A/C/G/T combinations never collide under
+                                      // ds_read_b128 (rows 16..24, the combinations with an N, are rare)
 constexpr int GMAX = 4;               // max distinct fusions per workgroup on the fast path
 constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
 // Stored values are V + 1024 per int16 field: always a positive normal fp16 bit pattern.
@@ -58,6 +63,8 @@ constexpr uint32_t BIAS16 = 0x0400u;
 constexpr uint32_t BIAS2 = 0x04000400u;
 constexpr uint32_t TWO2 = 0x00020002u;
 constexpr uint32_t FOUR2 = 0x00040004u;
+constexpr uint32_t SIX2 = 0x00060006u;
+__host__ __device__ constexpr uint32_t drift2(int i) { return (uint32_t)(2 * i) * 0x00010001u; }
 
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
@@ -133,6 +140,12 @@ struct Counters {          // device-side allocation cursors (and overflow detec
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+// Per-row planes ([rows][64 lanes] dwords: rowcodes, bnd, cmax, rmax) keep four consecutive rows of a
+// lane in one 16-byte word, so the fill kernels move them with dwordx4 loads and stores:
+// element (row j, lane) of a plane sits at rowidx(j, lane); geometry lq1 is a multiple of 4.
+__host__ __device__ __forceinline__ int64_t rowidx(int j, int lane) { return ((int64_t)(j >> 2) * WAVE + lane) * 4 + (j & 3); }
+constexpr uint32_t CODE_MASK = 0xFF00FF00u;   // rowcodes: byte codes; the low byte carries the fast-path table row
 // unbiased V of one field
 __device__ __forceinline__ int half_of(uint32_t v, int h) { return (int)((v >> (16 * h)) & 0xFFFFu) - (int)BIAS16; }
 
@@ -160,28 +173,54 @@ __device__ __forceinline__ bool is_fast_base(uint32_t b)
     return b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == 'N';
 }
 
+__device__ __forceinline__ uint32_t base_class(uint32_t byte)   // A,C,T,G,N -> 0,1,2,3,4
+{
+    uint32_t k = (byte >> 1) & 7u;       // A:0 C:1 T:2 G:3 N:7
+    return k > 4u ? 4u : k;
+}
+// table row of a (M1 class, M2 class) combination: the 16 N-free combinations first
+__device__ __forceinline__ uint32_t table_row(uint32_t k1, uint32_t k2)
+{
+    if (k1 < 4u && k2 < 4u) return 4u * k1 + k2;
+    return k1 == 4u ? 16u + k2 : 21u + k1;
+}
+__device__ __forceinline__ void table_row_classes(int t, int& k1, int& k2)   // inverse of table_row
+{
+    if (t < 16) { k1 = t >> 2; k2 = t & 3; }
+    else if (t < 21) { k1 = 4; k2 = t - 16; }
+    else { k1 = t - 21; k2 = 4; }
+}
+
+// one thread = four consecutive rows of one pair (one dwordx4 of the rowcodes plane)
 __global__ void k_pack_rows(const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
                             uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ wg_generic, Geom g)
 {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t total = (int64_t)g.n_waves * g.lq1 * WAVE;
+    const int lq4 = g.lq1 >> 2;
+    int64_t total = (int64_t)g.n_waves * lq4 * WAVE;
     if (t >= total) return;
     const int lane = (int)(t & 63);
-    const int j = (int)((t >> 6) % g.lq1);
-    const int w = (int)((t >> 6) / g.lq1);
+    const int gq = (int)((t >> 6) % lq4);
+    const int w = (int)((t >> 6) / lq4);
     const int64_t p = (int64_t)w * WAVE + lane;
-    uint32_t lo = ROW_PAD16, hi = ROW_PAD16;
-    if (p < g.n_pairs && j >= 1) {
-        const dsa_pair pr = pairs[p];
-        if (j <= pr.read_len) {
+    uint32_t out[4];
+    bool exotic = false;
+    dsa_pair pr{};
+    if (p < g.n_pairs) pr = pairs[p];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int j = 4 * gq + sidx;
+        uint32_t code = ROW_PAD16 | (ROW_PAD16 << 16);
+        if (p < g.n_pairs && j >= 1 && j <= pr.read_len) {
             const uint32_t b0 = read_bytes[(int64_t)pr.read_off + (j - 1)];
             const uint32_t b1 = read_bytes[(int64_t)pr.read_off + (pr.read_len - j)];
-            lo = b0 << 8;
-            hi = b1 << 8;
-            if (!is_fast_base(b0)) atomicOr(&wg_generic[w / WG_WAVES], 1u);   // b1 is some other row's b0
+            exotic |= !is_fast_base(b0);                       // b1 is some other row's b0
+            code = (b0 << 8) | (b1 << 24) | table_row(base_class(b0), base_class(b1));
         }
+        out[sidx] = code;
     }
-    rowcodes[t] = lo | (hi << 16);
+    reinterpret_cast<uint4*>(rowcodes)[t] = make_uint4(out[0], out[1], out[2], out[3]);
+    if (exotic) atomicOr(&wg_generic[w / WG_WAVES], 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -193,14 +232,16 @@ __global__ void k_pack_rows(const uint8_t* __restrict__ read_bytes, const dsa_pa
 __device__ __forceinline__ void row_step(uint32_t (&X)[W], const uint32_t (&r)[W], uint32_t cj, uint32_t bprev,
                                          uint32_t bcur)
 {
+    // X[i] carries drift 2i; bprev/bcur are drift-free.  Diagonal into column i>0 gains +2 of drift.
+    cj &= CODE_MASK;
     uint32_t a = (bprev + FOUR2) - min3u(cj ^ r[0]);
-    uint32_t prev_new = bcur;
+    uint32_t up = bcur - TWO2;
 #pragma unroll
     for (int i = 0; i < W; ++i) {
         uint32_t a_next = 0;
-        if (i + 1 < W) a_next = (X[i] + FOUR2) - min3u(cj ^ r[i + 1]);
-        X[i] = max3(a, X[i], prev_new - TWO2);
-        prev_new = X[i];
+        if (i + 1 < W) a_next = (X[i] + SIX2) - min3u(cj ^ r[i + 1]);
+        X[i] = max3(a, X[i], up);
+        up = X[i];                      // drift makes the next column's "up - 2" equal to this value
         a = a_next;
     }
 }
@@ -216,7 +257,7 @@ __device__ __forceinline__ uint32_t tile_row_max(const uint32_t (&X)[W], int nv0
         uint32_t x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            x[k] = X[i + k];
+            x[k] = X[i + k] - drift2(i + k);
             if (MASKED) {
                 if (i + k >= nv0) x[k] = (x[k] & 0xFFFF0000u) | BIAS16;
                 if (i + k >= nv1) x[k] = (x[k] & 0x0000FFFFu) | (BIAS16 << 16);
@@ -235,38 +276,57 @@ __device__ __forceinline__ uint32_t tile_row_max(const uint32_t (&X)[W], int nv0
 //   bnd [((w*nch + c)*lq1 + j)*64 + lane] = V(last column of tile c, j)
 // ---------------------------------------------------------------------------------------------
 template <bool MASKED>
-__device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const uint32_t* __restrict__ rows,
-                                                   const uint32_t* __restrict__ bi, uint32_t* __restrict__ cm,
-                                                   uint32_t* __restrict__ bo, int lq, bool first, int nv0, int nv1)
+__device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const uint4* __restrict__ rows4,
+                                                   const uint4* __restrict__ bi4, uint4* __restrict__ cm4,
+                                                   uint4* __restrict__ bo4, int lq, bool first, int nv0, int nv1)
 {
     uint32_t X[W];
 #pragma unroll
-    for (int i = 0; i < W; ++i) X[i] = BIAS2;
+    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+    const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
     uint32_t bprev = BIAS2;
-    uint32_t cj_next = rows[WAVE];
-    uint32_t b_next = first ? BIAS2 : bi[WAVE];
-    for (int j = 1; j <= lq; ++j) {
-        const uint32_t cj = cj_next;
-        const uint32_t bcur = b_next;
-        const int jn = j < lq ? j + 1 : j;          // prefetch the next row's operands
-        cj_next = rows[(int64_t)jn * WAVE];
-        b_next = first ? BIAS2 : bi[(int64_t)jn * WAVE];
-        row_step(X, r, cj, bprev, bcur);
-        bprev = bcur;
-        cm[(int64_t)j * WAVE] = tile_row_max<MASKED>(X, nv0, nv1);
-        bo[(int64_t)j * WAVE] = X[W - 1];
+    const int ngq = (lq >> 2) + 1;
+    uint4 rc_n = rows4[0];
+    uint4 b_n = first ? bias4 : bi4[0];
+    for (int gq = 0; gq < ngq; ++gq) {
+        const uint4 rc = rc_n, b = b_n;
+        const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
+        rc_n = rows4[(int64_t)gn * WAVE];
+        b_n = first ? bias4 : bi4[(int64_t)gn * WAVE];
+        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * gq + sidx;
+            if (j >= 1 && j <= lq) {                        // wave-uniform
+                row_step(X, r, rcv[sidx], bprev, bv[sidx]);
+                cmv[sidx] = tile_row_max<MASKED>(X, nv0, nv1);
+                bov[sidx] = X[W - 1] - drift2(W - 1);
+            }
+            bprev = bv[sidx];
+        }
+        cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
+        bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
     }
 }
 
-// After the last tile: rmax[(w*lq1 + j)*64 + lane] = max over tiles of cmax (both halves), so the
-// combine kernel reads one dword per row instead of one per tile.  cmax of this wave is L2-hot.
+// After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
+// dword per row instead of one per tile.  cmax of this wave is L2-hot.
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
                                                const Geom& g, int w, int lane, int nch_wave, int lq)
 {
-    for (int j = 1; j <= lq; ++j) {
-        uint32_t m = BIAS2;
-        for (int c = 0; c < nch_wave; ++c) m = max2(m, cmax[(((int64_t)w * g.nch + c) * g.lq1 + j) * WAVE + lane]);
-        rmax[((int64_t)w * g.lq1 + j) * WAVE + lane] = m;
+    const int ngq = (lq >> 2) + 1;
+    uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
+    for (int gq = 0; gq < ngq; ++gq) {
+        uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+        for (int c = 0; c < nch_wave; ++c) {
+            const uint4 v = (reinterpret_cast<const uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane)[(int64_t)gq * WAVE];
+            m.x = max2(m.x, v.x);
+            m.y = max2(m.y, v.y);
+            m.z = max2(m.z, v.z);
+            m.w = max2(m.w, v.w);
+        }
+        out[(int64_t)gq * WAVE] = m;
     }
 }
 
@@ -288,20 +348,20 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
     const int f = pairs[p].fusion_idx;
     const dsa_fusion fu = fusions[f];
     const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
-    const uint32_t* rows = rowcodes + (int64_t)w * g.lq1 * WAVE + lane;
+    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
 
     for (int c = 0; c < wi.nch_max; ++c) {
         uint32_t r[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) r[i] = rc[c * W + i];
         const int nv0 = fu.ref0_len - c * W, nv1 = fu.ref1_len - c * W;   // per lane; may be <= 0
-        uint32_t* cm = cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
-        uint32_t* bo = bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
-        const uint32_t* bi = bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE + lane;
+        uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
         if (__builtin_amdgcn_ballot_w64(nv0 < W || nv1 < W) == 0)
-            sweep_tile_generic<false>(r, rows, bi, cm, bo, wi.lq_max, c == 0, nv0, nv1);
+            sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
         else
-            sweep_tile_generic<true>(r, rows, bi, cm, bo, wi.lq_max, c == 0, nv0, nv1);
+            sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
     reduce_row_max(cmax, rmax, g, w, lane, wi.nch_max, wi.lq_max);
@@ -314,14 +374,9 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 // where k1/k2 are the classes of the M1 / M2 read base of the row.  Padded reference columns get
 // d = 0 (worse than a mismatch): their values can then reach but never exceed the row maximum of the
 // valid columns, so the tile row maximum needs no masking (the replay masks exclude them by index).
-// A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column.
+// A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column; four rows share one
+// dwordx4 load of row codes / boundary and one dwordx4 store of tile maxima / boundary.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t base_class(uint32_t byte)   // A,C,T,G,N -> 0,1,2,3,4
-{
-    uint32_t k = (byte >> 1) & 7u;       // A:0 C:1 T:2 G:3 N:7
-    return k > 4u ? 4u : k;
-}
-
 __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            const WaveInfo* __restrict__ winfo,
                                                            const WgInfo* __restrict__ wginfo,
@@ -355,7 +410,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     for (int k = 0; k < GMAX; ++k)
         if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
     const uint32_t* tb = T + gsel * TGROUP;
-    const uint32_t* rows = rowcodes + (int64_t)w * g.lq1 * WAVE + lane;
+    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
 
     for (int c = 0; c < nch_wg; ++c) {
         __syncthreads();                          // previous tile's tables no longer in use
@@ -366,58 +421,72 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
             const uint32_t c0 = code & 0xFFFFu, c1 = code >> 16;
             const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};   // inverse of base_class
-            const uint32_t d0 = c0 == REF_PAD16 ? 0u : ((c0 >> 8) == cls_byte[combo / NCLS] ? 4u : 1u);
-            const uint32_t d1 = c1 == REF_PAD16 ? 0u : ((c1 >> 8) == cls_byte[combo % NCLS] ? 4u : 1u);
-            T[gi * TGROUP + combo * TROW + i] = d0 | (d1 << 16);
+            int k1, k2;
+            table_row_classes(combo, k1, k2);
+            const uint32_t d0 = c0 == REF_PAD16 ? 0u : ((c0 >> 8) == cls_byte[k1] ? 4u : 1u);
+            const uint32_t d1 = c1 == REF_PAD16 ? 0u : ((c1 >> 8) == cls_byte[k2] ? 4u : 1u);
+            // +2 per field for i > 0: the diagonal move from column i-1 to i picks up the drift
+            T[gi * TGROUP + combo * TROW + i] = (d0 | (d1 << 16)) + (i > 0 ? TWO2 : 0u);
         }
         __syncthreads();
         if (!live || c >= wi.nch_max) continue;   // wave-uniform
 
-        uint32_t* cm = cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
-        uint32_t* bo = bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE + lane;
-        const uint32_t* bi = bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE + lane;
+        uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
         uint32_t X[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2;
+        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         uint32_t bprev = BIAS2;
-        uint32_t cj_next = rows[WAVE];
-        uint32_t b_next = (c == 0) ? BIAS2 : bi[WAVE];
-        for (int j = 1; j <= wi.lq_max; ++j) {
-            const uint32_t cj = cj_next;
-            const uint32_t bcur = b_next;
-            const int jn = j < wi.lq_max ? j + 1 : j;      // prefetch the next row's operands
-            cj_next = rows[(int64_t)jn * WAVE];
-            b_next = (c == 0) ? BIAS2 : bi[(int64_t)jn * WAVE];
-            const uint32_t combo = base_class((cj >> 8) & 0xFFu) * NCLS + base_class(cj >> 24);
-            const uint4* trow = reinterpret_cast<const uint4*>(tb + combo * TROW);
-            // one ascending pass, four columns per LDS read; the diagonal term of the next column is
-            // formed from X[i] before X[i] is overwritten (in-place update, no copies)
-            uint4 v = trow[0];
-            uint32_t a = bprev + v.x;
-            uint32_t prev_new = bcur;
+        const int ngq = (wi.lq_max >> 2) + 1;
+        uint4 rc_n = rows4[0];
+        uint4 b_n = (c == 0) ? bias4 : bi4[0];
+        for (int gq = 0; gq < ngq; ++gq) {
+            const uint4 rc = rc_n, b = b_n;
+            const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
+            rc_n = rows4[(int64_t)gn * WAVE];
+            b_n = (c == 0) ? bias4 : bi4[(int64_t)gn * WAVE];
+            const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+            uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
 #pragma unroll
-            for (int q = 0; q < W / 4; ++q) {
-                uint4 vn = v;
-                if (q + 1 < W / 4) vn = trow[q + 1];
-                uint32_t an;
-                an = X[4 * q + 0] + v.y;
-                X[4 * q + 0] = max3(a, X[4 * q + 0], prev_new - TWO2);
-                a = an;
-                an = X[4 * q + 1] + v.z;
-                X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0] - TWO2);
-                a = an;
-                an = X[4 * q + 2] + v.w;
-                X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1] - TWO2);
-                a = an;
-                an = X[4 * q + 3] + vn.x;
-                X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2] - TWO2);
-                a = an;
-                prev_new = X[4 * q + 3];
-                v = vn;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int j = 4 * gq + sidx;
+                const uint32_t bcur = bv[sidx];
+                if (j >= 1 && j <= wi.lq_max) {             // wave-uniform
+                    // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
+                    // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
+                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
+                    uint4 v = trow[0];
+                    uint32_t a = bprev + v.x;
+                    uint32_t up = bcur - TWO2;
+#pragma unroll
+                    for (int q = 0; q < W / 4; ++q) {
+                        uint4 vn = v;
+                        if (q + 1 < W / 4) vn = trow[q + 1];
+                        uint32_t an;
+                        an = X[4 * q + 0] + v.y;
+                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                        a = an;
+                        an = X[4 * q + 1] + v.z;
+                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                        a = an;
+                        an = X[4 * q + 2] + v.w;
+                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                        a = an;
+                        an = X[4 * q + 3] + vn.x;
+                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                        a = an;
+                        up = X[4 * q + 3];
+                        v = vn;
+                    }
+                    cmv[sidx] = tile_row_max<false>(X, W, W);
+                    bov[sidx] = X[W - 1] - drift2(W - 1);
+                }
+                bprev = bcur;
             }
-            bprev = bcur;
-            cm[(int64_t)j * WAVE] = tile_row_max<false>(X, W, W);
-            bo[(int64_t)j * WAVE] = X[W - 1];
+            cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
+            bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
         }
     }
     if (live) {
@@ -435,7 +504,7 @@ __device__ __forceinline__ int row_max_h(const uint32_t* __restrict__ rmax, cons
                                          int n_chunks, int row)
 {
     if (row == 0 || n_chunks == 0) return 0;   // H(i,0)=0 < 8; empty reference: only column 0 (<=0)
-    const int v = half_of(rmax[((p >> 6) * g.lq1 + row) * WAVE + (p & 63)], h) - 2 * row;
+    const int v = half_of(rmax[(p >> 6) * g.lq1 * WAVE + rowidx(row, (int)(p & 63))], h) - 2 * row;
     return v >= DSA_MIN_SPLIT ? v : 0;
 }
 
@@ -502,9 +571,9 @@ __global__ __launch_bounds__(256) void k_combine(
                 ++n_kept;
                 if (small) {
                     for (int c = 0; c < nc0; ++c)
-                        if (half_of(cmax[((w * g.nch + c) * g.lq1 + a) * WAVE + lane], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
+                        if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(a, lane)], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
                     for (int c = 0; c < nc1; ++c)
-                        if (half_of(cmax[((w * g.nch + c) * g.lq1 + b) * WAVE + lane], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
+                        if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(b, lane)], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
                 }
             }
             if (n_kept > 0) {
@@ -588,9 +657,9 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         const PairState st = state[p];
         const int lq = pr.read_len;
         const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp;
-        const uint32_t* rows = rowcodes + w * g.lq1 * WAVE + lane;
-        const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE + lane;
-        const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE + lane;
+        const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
+        const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
+        const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
         const KeptRow* kr = kept + st.kept_begin;
 
         uint32_t r[W];
@@ -602,22 +671,23 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         }
         uint32_t X[W];
 #pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2;
+        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
         uint32_t bprev = BIAS2;
         const int R = rt.last_row;
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
         int k0 = 0, k1 = st.n_kept - 1;
-        uint32_t cj_next = rows[WAVE];
-        uint32_t b_next = (c0 > 0 ? (bi0[WAVE] & 0xFFFFu) : BIAS16) | (c1 > 0 ? (bi1[WAVE] & 0xFFFF0000u) : (BIAS16 << 16));
+        uint32_t cj_next = rows[rowidx(1, lane)];
+        uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
+                          (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
         for (int j = 1; j <= R; ++j) {
             const uint32_t cj = cj_next;
             const uint32_t bcur = b_next;
             const int jn = j < R ? j + 1 : j;
-            cj_next = rows[(int64_t)jn * WAVE];
-            b_next = (c0 > 0 ? (bi0[(int64_t)jn * WAVE] & 0xFFFFu) : BIAS16) |
-                     (c1 > 0 ? (bi1[(int64_t)jn * WAVE] & 0xFFFF0000u) : (BIAS16 << 16));
+            cj_next = rows[rowidx(jn, lane)];
+            b_next = (c0 > 0 ? (bi0[rowidx(jn, lane)] & 0xFFFFu) : BIAS16) |
+                     (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
             const bool hit0 = has0 && k0 < st.n_kept && kr[k0].a == j;
@@ -627,7 +697,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                 uint64_t mask = 0;
 #pragma unroll
                 for (int i = 0; i < W; ++i)
-                    if (i < nv0 && (X[i] & 0xFFFFu) == target) mask |= (1ull << i);
+                    if (i < nv0 && (X[i] & 0xFFFFu) == target + 2u * i) mask |= (1ull << i);
                 masks[((uint64_t)rt.mask_begin + k0) * 2] = mask;
                 ++k0;
             }
@@ -636,7 +706,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                 uint64_t mask = 0;
 #pragma unroll
                 for (int i = 0; i < W; ++i)
-                    if (i < nv1 && (X[i] >> 16) == target) mask |= (1ull << i);
+                    if (i < nv1 && (X[i] >> 16) == target + 2u * i) mask |= (1ull << i);
                 masks[((uint64_t)rt.mask_begin + k1) * 2 + 1] = mask;
                 --k1;
             }

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdefuse_dsa.so")
+LIB_PATH = os.environ.get("DEFUSE_DSA_LIB") or os.path.join(_HERE, "libdefuse_dsa.so")
 
 FUSION_DTYPE = np.dtype([("fusion_id", "<i4"), ("ref0_off", "<i4"), ("ref0_len", "<i4"),
                          ("ref1_off", "<i4"), ("ref1_len", "<i4")])
