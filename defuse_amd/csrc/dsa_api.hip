@@ -74,12 +74,14 @@ struct dsa_ctx {
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
-    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax;
+    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
     DevBuf<PairState> d_state;
     DevBuf<KeptRow> d_kept;
     DevBuf<int64_t> d_rec_count, d_rec_offset;
     DevBuf<ReplayTask> d_tasks;
     DevBuf<uint64_t> d_masks;
+    DevBuf<uint32_t> d_gtasks;
+    DevBuf<int32_t> d_wgtile;
     DevBuf<Counters> d_ctr;
     DevBuf<int16_t> d_mscratch;
     DevBuf<uint8_t> d_scan_tmp;
@@ -125,7 +127,7 @@ int min_score_for(int lq)
 size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 {
     size_t rows = (size_t)n_waves * lq1 * WAVE * 4;
-    return 2 * rows + 2 * rows * (size_t)nch;
+    return 3 * rows + 2 * rows * (size_t)nch;
 }
 
 // Slices bound the scratch footprint; inside a slice pair p lives in wave p/64, lane p%64.
@@ -237,6 +239,7 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(ctx->d_bnd.reserve(n_rows * g.nch));
     HIPC(ctx->d_cmax.reserve(n_rows * g.nch));
     HIPC(ctx->d_rmax.reserve(n_rows));
+    HIPC(ctx->d_tmask.reserve(n_rows));
     HIPC(ctx->d_state.reserve(np));
     HIPC(ctx->d_rec_count.reserve(np + 1));
     HIPC(ctx->d_rec_offset.reserve(np + 1));
@@ -244,6 +247,8 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(ctx->d_kept.reserve((size_t)np * 2 + 1024));
     HIPC(ctx->d_tasks.reserve((size_t)np * 4 + 1024));
     HIPC(ctx->d_masks.reserve((size_t)np * 8 + 1024));
+    HIPC(ctx->d_gtasks.reserve((size_t)np * 2 + 1024));
+    HIPC(ctx->d_wgtile.reserve((size_t)g.n_wgs * GMAX + 16));
     if (int rc = grow_records(ctx, (size_t)ctx->n_records + (size_t)np * 2 + 1024)) return rc;
     HIPC(hipMemcpyAsync(ctx->d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(ctx->d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
@@ -262,10 +267,10 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(hipEventRecord(ctx->ev[1], st));
     // ---- fill: every workgroup is run by exactly one of the two kernels ---------------------------
     hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p, ctx->d_wgs.p,
-                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, ctx->d_rmax.p, g);
+                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p,
                        ctx->d_fusions.p, ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p,
-                       ctx->d_cmax.p, ctx->d_rmax.p, g);
+                       ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, g);
     HIPC(hipEventRecord(ctx->ev[2], st));
     HIPC(hipGetLastError());
     // ---- finish: combine -> replay -> emit, no host round trip unless a buffer overflowed --------
@@ -277,14 +282,20 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (redo_combine) {
             HIPC(hipMemsetAsync(ctx->d_ctr.p, 0, sizeof(Counters), st));
-            hipLaunchKernelGGL(k_combine, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_cmax.p,
-                               ctx->d_rmax.p, ctx->d_min_score.p, ctx->d_state.p, ctx->d_kept.p,
-                               (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
-                               (uint64_t)(ctx->d_masks.cap / 2), ctx->d_ctr.p, g);
-            hipLaunchKernelGGL(k_replay, dim3(256 * 8), dim3(256), 0, st, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
-                               ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, pairs,
-                               ctx->d_fusions.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_masks.p,
-                               (uint64_t)(ctx->d_masks.cap / 2), g);
+            hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(256), 0, st, pairs, ctx->d_fusions.p,
+                               ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, ctx->d_min_score.p, ctx->d_wgs.p, ctx->d_wg_generic.p,
+                               ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p,
+                               (uint64_t)ctx->d_tasks.cap, (uint64_t)(ctx->d_masks.cap / 2), ctx->d_gtasks.p,
+                               (uint64_t)ctx->d_gtasks.cap, ctx->d_wgtile.p, ctx->d_ctr.p, g);
+            hipLaunchKernelGGL(k_replay_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, ctx->d_tasks.p,
+                               (uint64_t)ctx->d_tasks.cap, ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p,
+                               (uint64_t)ctx->d_kept.cap, pairs, ctx->d_fusions.p, ctx->d_wgs.p, ctx->d_wgtile.p,
+                               ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_masks.p,
+                               (uint64_t)(ctx->d_masks.cap / 2), (uint64_t)ctx->d_gtasks.cap, g);
+            hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
+                               ctx->d_gtasks.p, (uint64_t)ctx->d_gtasks.cap, ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p,
+                               (uint64_t)ctx->d_kept.cap, pairs, ctx->d_fusions.p, ctx->d_refcodes.p, ctx->d_rowcodes.p,
+                               ctx->d_bnd.p, ctx->d_masks.p, (uint64_t)(ctx->d_masks.cap / 2), g);
             hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
                                ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p, (const int64_t*)nullptr,
                                (dsa_record*)nullptr, (uint64_t)0, g);
@@ -300,11 +311,13 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
         HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         HIPC(hipGetLastError());
-        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap / 2;
+        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap / 2 ||
+                       ctr.n_gtasks > ctx->d_gtasks.cap;
         if (redo_combine) {
             HIPC(ctx->d_kept.reserve(ctr.n_kept + 1024));
             HIPC(ctx->d_tasks.reserve(ctr.n_tasks + 1024));
             HIPC(ctx->d_masks.reserve(2 * ctr.n_masks + 1024));
+            HIPC(ctx->d_gtasks.reserve(ctr.n_gtasks + 1024));
             continue;
         }
         if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
@@ -364,9 +377,9 @@ void dsa_destroy(dsa_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
     ctx->d_min_score.release(); ctx->d_waves.release(); ctx->d_wgs.release(); ctx->d_wg_generic.release();
-    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_rmax.release();
+    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_rmax.release(); ctx->d_tmask.release();
     ctx->d_state.release(); ctx->d_kept.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release();
-    ctx->d_tasks.release(); ctx->d_masks.release(); ctx->d_ctr.release(); ctx->d_mscratch.release();
+    ctx->d_tasks.release(); ctx->d_masks.release(); ctx->d_gtasks.release(); ctx->d_wgtile.release(); ctx->d_ctr.release(); ctx->d_mscratch.release();
     ctx->d_scan_tmp.release(); ctx->d_records.release();
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);

@@ -121,10 +121,11 @@ constexpr uint8_t NO_CHUNK = 0xFF;
 struct ReplayTask {
     uint32_t pair;         // slice-relative
     uint32_t mask_begin;   // masks[(mask_begin + k)*2 + h] for kept row k of the pair, matrix h
-    uint16_t last_row;     // largest row either matrix needs
+    uint16_t last_row;     // largest row either matrix needs; bit 15 = replayed by the table-driven kernel
     uint8_t  chunk0;       // NO_CHUNK = nothing to replay on that side
     uint8_t  chunk1;
 };
+constexpr uint16_t TASK_FAST = 0x8000u;
 
 struct PairState {
     int32_t max_score;     // best m1+m2 (0 = no output)
@@ -136,7 +137,7 @@ struct PairState {
 };
 
 struct Counters {          // device-side allocation cursors (and overflow detection)
-    unsigned long long n_kept, n_tasks, n_masks, pad_;
+    unsigned long long n_kept, n_tasks, n_masks, n_gtasks;
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
@@ -311,12 +312,22 @@ __device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const
 }
 
 // After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
-// dword per row instead of one per tile.  cmax of this wave is L2-hot.
+// dword per row instead of one per tile; tmask = which tiles attain it (bit c: M1 tile c, bit 16+c:
+// M2 tile c; only meaningful while a reference has at most 16 tiles, the combine kernel falls back to
+// cmax otherwise).  cmax of this wave is L2-hot.
+constexpr int TMASK_TILES = 16;
+__device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
+{
+    const uint32_t x = v ^ m;
+    return ((x & 0xFFFFu) == 0u ? (1u << c) : 0u) | ((x >> 16) == 0u ? (1u << (16 + c)) : 0u);
+}
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
-                                               const Geom& g, int w, int lane, int nch_wave, int lq)
+                                               uint32_t* __restrict__ tmask, const Geom& g, int w, int lane,
+                                               int nch_wave, int lq)
 {
     const int ngq = (lq >> 2) + 1;
     uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
+    uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
     for (int gq = 0; gq < ngq; ++gq) {
         uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         for (int c = 0; c < nch_wave; ++c) {
@@ -327,6 +338,17 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
             m.w = max2(m.w, v.w);
         }
         out[(int64_t)gq * WAVE] = m;
+        if (nch_wave <= TMASK_TILES) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            for (int c = 0; c < nch_wave; ++c) {
+                const uint4 v = (reinterpret_cast<const uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane)[(int64_t)gq * WAVE];
+                t.x |= eq_bits(v.x, m.x, c);
+                t.y |= eq_bits(v.y, m.y, c);
+                t.z |= eq_bits(v.z, m.z, c);
+                t.w |= eq_bits(v.w, m.w, c);
+            }
+            tout[(int64_t)gq * WAVE] = t;
+        }
     }
 }
 
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
-                                                           uint32_t* __restrict__ rmax, Geom g)
+                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask, Geom g)
 {
     if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
@@ -364,7 +386,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
             sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-    reduce_row_max(cmax, rmax, g, w, lane, wi.nch_max, wi.lq_max);
+    reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -384,7 +406,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
-                                                           uint32_t* __restrict__ rmax, Geom g)
+                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask, Geom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
     __shared__ int s_nch;
@@ -491,23 +513,13 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     }
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, g, w, lane, wi.nch_max, wi.lq_max);
+        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Finish stage
 // ---------------------------------------------------------------------------------------------
-// Row maximum of one matrix of pair p in H units with FindMaxRowEntry's acceptance rule
-// (tools/SplitReadAligner.cpp:91-102): values below minSplitScore (8) count as 0.
-__device__ __forceinline__ int row_max_h(const uint32_t* __restrict__ rmax, const Geom& g, int64_t p, int h,
-                                         int n_chunks, int row)
-{
-    if (row == 0 || n_chunks == 0) return 0;   // H(i,0)=0 < 8; empty reference: only column 0 (<=0)
-    const int v = half_of(rmax[(p >> 6) * g.lq1 * WAVE + rowidx(row, (int)(p & 63))], h) - 2 * row;
-    return v >= DSA_MIN_SPLIT ? v : 0;
-}
-
 // wave-aggregated allocation: every lane asks for n items, one atomic per wave
 __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* counter, unsigned n)
 {
@@ -533,15 +545,35 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int n)   // index of the 
 // K2: per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
 // have columns on both sides, and the tiles that hold a row maximum for them.  Single pass; space
 // comes from device cursors (capacities are checked by the host afterwards).
+// One block = the 256 pairs of one fill workgroup.  The scan over read splits reads the row maxima
+// four rows at a time (dwordx4, three independent loads per step), so it is not one dependent L2
+// round trip per row.  The first tile pair of every pair is offered to the table-driven replay: per
+// fusion of the workgroup the first offer fixes the (M1 tile, M2 tile) the tables will be built for.
 __global__ __launch_bounds__(256) void k_combine(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
-    const uint32_t* __restrict__ rmax, const int32_t* __restrict__ min_score_tab, PairState* __restrict__ state,
-    KeptRow* __restrict__ kept, uint64_t kept_cap, ReplayTask* __restrict__ tasks, uint64_t task_cap,
-    uint64_t mask_cap, Counters* __restrict__ ctr, Geom g)
+    const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
+    const WgInfo* __restrict__ wginfo,
+    const uint32_t* __restrict__ wg_generic, PairState* __restrict__ state, KeptRow* __restrict__ kept,
+    uint64_t kept_cap, ReplayTask* __restrict__ tasks, uint64_t task_cap, uint64_t mask_cap,
+    uint32_t* __restrict__ gtasks, uint64_t gtask_cap, int32_t* __restrict__ wgtile, Counters* __restrict__ ctr, Geom g)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_tile[GMAX];
+    const int tid = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
     const bool active = p < g.n_pairs;
-    int lq = 0, nc0 = 0, nc1 = 0, max_score = 0, n_kept = 0;
+    const int64_t w = p >> 6;
+    const int lane = (int)(p & 63);
+    if (tid < GMAX) s_tile[tid] = -1;
+    const uint32_t* rm = rmax + w * g.lq1 * WAVE;
+    const uint4* rm4 = reinterpret_cast<const uint4*>(rm) + lane;
+    // FindMaxRowEntry's acceptance rule (tools/SplitReadAligner.cpp:91-102): below minSplitScore counts as 0
+    auto accept = [](uint32_t word, int h, int n_chunks, int row) -> int {
+        if (row == 0 || n_chunks == 0) return 0;   // H(i,0)=0 < 8; empty reference: only column 0 (<=0)
+        const int v = half_of(word, h) - 2 * row;
+        return v >= DSA_MIN_SPLIT ? v : 0;
+    };
+    auto rowmax = [&](int h, int n_chunks, int row) -> int { return accept(rm[rowidx(row, lane)], h, n_chunks, row); };
+    int lq = 0, nc0 = 0, nc1 = 0, max_score = 0, n_kept = 0, fidx = -1;
     unsigned n_t0 = 0, n_t1 = 0;
     uint64_t tiles0 = 0, tiles1 = 0;     // tiles that attain the maximum at some kept row
     bool small = true;                   // references with more than 64 tiles replay every tile (exact, not minimal)
@@ -549,33 +581,52 @@ __global__ __launch_bounds__(256) void k_combine(
     if (active) {
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
+        fidx = pr.fusion_idx;
         lq = pr.read_len;
         nc0 = cdiv_dev(fu.ref0_len, W);
         nc1 = cdiv_dev(fu.ref1_len, W);
         small = nc0 <= 64 && nc1 <= 64;
         const int min_score = min_score_tab[lq];
-        for (int a = 0; a <= lq; ++a) {
-            const int s = row_max_h(rmax, g, p, 0, nc0, a) + row_max_h(rmax, g, p, 1, nc1, lq - a);
-            if (s >= min_score && s > max_score) max_score = s;
-        }
+        // visits every read split a with m1(a), m2(lq-a); four splits per step from three dwordx4 loads
+        auto for_each_split = [&](auto&& fn) {
+            for (int gq = 0; 4 * gq <= lq; ++gq) {
+                const int b_hi = lq - 4 * gq, b_lo = b_hi - 3;
+                const uint4 x1 = rm4[(int64_t)gq * WAVE];
+                const uint4 y_hi = rm4[(int64_t)(b_hi >> 2) * WAVE];
+                const uint4 y_lo = rm4[(int64_t)((b_lo > 0 ? b_lo : 0) >> 2) * WAVE];
+                const uint32_t xv[4] = {x1.x, x1.y, x1.z, x1.w};
+                const uint32_t yh[4] = {y_hi.x, y_hi.y, y_hi.z, y_hi.w}, yl[4] = {y_lo.x, y_lo.y, y_lo.z, y_lo.w};
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int a = 4 * gq + sidx, b = lq - a;
+                    if (b >= 0) {
+                        const uint32_t yw = (b >> 2) == (b_hi >> 2) ? yh[b & 3] : yl[b & 3];
+                        fn(a, b, accept(xv[sidx], 0, nc0, a), accept(yw, 1, nc1, b));
+                    }
+                }
+            }
+        };
+        for_each_split([&](int, int, int m1, int m2) {
+            const int sc = m1 + m2;
+            if (sc >= min_score && sc > max_score) max_score = sc;
+        });
         if (max_score != 0) {
-            const int64_t w = p >> 6;
-            const int lane = (int)(p & 63);
             first_a = lq;
-            for (int a = 0; a <= lq; ++a) {
-                const int b = lq - a;
-                const int m1 = row_max_h(rmax, g, p, 0, nc0, a), m2 = row_max_h(rmax, g, p, 1, nc1, b);
-                if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;   // an empty side emits nothing
+            for_each_split([&](int a, int b, int m1, int m2) {
+                if (m1 + m2 != max_score || m1 == 0 || m2 == 0) return;   // an empty side emits nothing
                 if (n_kept == 0) first_a = a;
                 last_a = a;
                 ++n_kept;
-                if (small) {
+                if (g.nch <= TMASK_TILES) {          // the fill kernel already tabulated the winning tiles
+                    tiles0 |= tmask[w * g.lq1 * WAVE + rowidx(a, lane)] & 0xFFFFu;
+                    tiles1 |= tmask[w * g.lq1 * WAVE + rowidx(b, lane)] >> 16;
+                } else if (small) {
                     for (int c = 0; c < nc0; ++c)
                         if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(a, lane)], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
                     for (int c = 0; c < nc1; ++c)
                         if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(b, lane)], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
                 }
-            }
+            });
             if (n_kept > 0) {
                 n_t0 = small ? (unsigned)__builtin_popcountll(tiles0) : (unsigned)nc0;
                 n_t1 = small ? (unsigned)__builtin_popcountll(tiles1) : (unsigned)nc1;
@@ -583,9 +634,29 @@ __global__ __launch_bounds__(256) void k_combine(
         }
     }
     const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
+    // offer the first tile pair to the table-driven replay
+    const WgInfo wgi = wginfo[blockIdx.x];
+    const bool fast_wg = wgi.n_groups > 0 && wg_generic[blockIdx.x] == 0;
+    int gsel = -1;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k)
+        if (k < wgi.n_groups && wgi.group_f[k] == fidx) gsel = k;
+    int key = -1;
+    if (n_tasks > 0 && small && fast_wg && gsel >= 0) {
+        const int c0 = nth_set_bit(tiles0, 0), c1 = nth_set_bit(tiles1, 0);
+        key = ((c0 >= 0 ? c0 : (int)NO_CHUNK) << 8) | (c1 >= 0 ? c1 : (int)NO_CHUNK);
+    }
+    __syncthreads();
+    if (key >= 0) atomicCAS(&s_tile[gsel], -1, key);
+    __syncthreads();
+    const bool fast = key >= 0 && s_tile[gsel] == key;
+    if (tid < GMAX) wgtile[(int64_t)blockIdx.x * GMAX + tid] = s_tile[tid];
+    const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
+
     const unsigned long long kb = wave_alloc(&ctr->n_kept, (unsigned)n_kept);
     const unsigned long long tb = wave_alloc(&ctr->n_tasks, n_tasks);
     const unsigned long long mb = wave_alloc(&ctr->n_masks, n_tasks * (unsigned)n_kept);
+    const unsigned long long gb = wave_alloc(&ctr->n_gtasks, n_gen);
     if (!active) return;
     PairState st;
     st.max_score = max_score;
@@ -594,8 +665,8 @@ __global__ __launch_bounds__(256) void k_combine(
     st.task_begin = (uint32_t)tb;
     st.n_tasks = n_tasks;
     st.pad_ = 0;
-    if (n_kept > 0 &&
-        (kb + n_kept > kept_cap || tb + n_tasks > task_cap || mb + (unsigned long long)n_tasks * n_kept > mask_cap)) {
+    if (n_kept > 0 && (kb + n_kept > kept_cap || tb + n_tasks > task_cap ||
+                       mb + (unsigned long long)n_tasks * n_kept > mask_cap || gb + n_gen > gtask_cap)) {
         st.n_kept = 0;     // overflow: the host sees the cursors, grows the buffers and reruns the finish stage
         state[p] = st;
         return;
@@ -604,7 +675,7 @@ __global__ __launch_bounds__(256) void k_combine(
     if (n_kept == 0) return;
     int k = 0;
     for (int a = first_a; a <= last_a; ++a) {
-        const int m1 = row_max_h(rmax, g, p, 0, nc0, a), m2 = row_max_h(rmax, g, p, 1, nc1, lq - a);
+        const int m1 = rowmax(0, nc0, a), m2 = rowmax(1, nc1, lq - a);
         if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;
         KeptRow kr;
         kr.a = (int16_t)a;
@@ -614,6 +685,7 @@ __global__ __launch_bounds__(256) void k_combine(
         kept[kb + k] = kr;
         ++k;
     }
+    unsigned gi = 0;
     for (unsigned t = 0; t < n_tasks; ++t) {
         const int c0 = small ? nth_set_bit(tiles0, (int)t) : (t < n_t0 ? (int)t : -1);
         const int c1 = small ? nth_set_bit(tiles1, (int)t) : (t < n_t1 ? (int)t : -1);
@@ -624,14 +696,47 @@ __global__ __launch_bounds__(256) void k_combine(
         rt.last_row = (uint16_t)(r0 > r1 ? r0 : r1);
         rt.chunk0 = c0 >= 0 ? (uint8_t)c0 : NO_CHUNK;
         rt.chunk1 = c1 >= 0 ? (uint8_t)c1 : NO_CHUNK;
+        if (t == 0 && fast)
+            rt.last_row |= TASK_FAST;
+        else
+            gtasks[gb + gi++] = (uint32_t)(tb + t);
         tasks[tb + t] = rt;
     }
 }
 
-// K3: replay one tile pair per lane from the stored boundaries; for every kept row of the pair report,
-// as 64-bit masks, the valid columns whose value equals the row maximum (lo half: M1 tile chunk0,
-// hi half: M2 tile chunk1).  Grid-stride over the device task counter (no host round trip).
+// Columns of the tile whose value at this row equals the kept row's maximum (either field).
+__device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int lq, const KeptRow* __restrict__ kr,
+                                            int n_kept, bool has0, bool has1, int nv0, int nv1, int& k0, int& k1,
+                                            uint64_t* __restrict__ masks, uint32_t mask_begin)
+{
+    const bool hit0 = has0 && k0 < n_kept && kr[k0].a == j;
+    const bool hit1 = has1 && k1 >= 0 && lq - kr[k1].a == j;
+    if (hit0) {
+        const uint32_t target = (uint32_t)(kr[k0].m1 + 2 * j) + BIAS16;
+        uint64_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (i < nv0 && (X[i] & 0xFFFFu) == target + 2u * i) mask |= (1ull << i);
+        masks[((uint64_t)mask_begin + k0) * 2] = mask;
+        ++k0;
+    }
+    if (hit1) {
+        const uint32_t target = (uint32_t)(kr[k1].m2 + 2 * j) + BIAS16;
+        uint64_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+            if (i < nv1 && (X[i] >> 16) == target + 2u * i) mask |= (1ull << i);
+        masks[((uint64_t)mask_begin + k1) * 2 + 1] = mask;
+        --k1;
+    }
+}
+
+// K3g: replay one tile pair per lane from the stored boundaries (generic scoring, any pair mix); for
+// every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
+// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Grid-stride over the device list
+// of tasks the table-driven kernel does not cover.
 __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+                                                   const uint32_t* __restrict__ gtasks, uint64_t gtask_cap,
                                                    const Counters* __restrict__ ctr,
                                                    const PairState* __restrict__ state,
                                                    const KeptRow* __restrict__ kept, uint64_t kept_cap,
@@ -642,11 +747,11 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                                                    const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
                                                    uint64_t mask_cap, Geom g)
 {
-    const unsigned long long n_tasks = ctr->n_tasks;
-    if (n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap) return;   // overflow run
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks;
+    const unsigned long long n_g = ctr->n_gtasks;
+    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_g;
          t += (unsigned long long)gridDim.x * blockDim.x) {
-        const ReplayTask rt = tasks[t];
+        const ReplayTask rt = tasks[gtasks[t]];
         const int64_t p = rt.pair;
         const int64_t w = p >> 6;
         const int lane = (int)(p & 63);
@@ -673,7 +778,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
 #pragma unroll
         for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
         uint32_t bprev = BIAS2;
-        const int R = rt.last_row;
+        const int R = rt.last_row & 0x7FFF;
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
@@ -690,33 +795,195 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                      (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
-            const bool hit0 = has0 && k0 < st.n_kept && kr[k0].a == j;
-            const bool hit1 = has1 && k1 >= 0 && lq - kr[k1].a == j;
-            if (hit0) {
-                const uint32_t target = (uint32_t)(kr[k0].m1 + 2 * j) + BIAS16;
-                uint64_t mask = 0;
-#pragma unroll
-                for (int i = 0; i < W; ++i)
-                    if (i < nv0 && (X[i] & 0xFFFFu) == target + 2u * i) mask |= (1ull << i);
-                masks[((uint64_t)rt.mask_begin + k0) * 2] = mask;
-                ++k0;
-            }
-            if (hit1) {
-                const uint32_t target = (uint32_t)(kr[k1].m2 + 2 * j) + BIAS16;
-                uint64_t mask = 0;
-#pragma unroll
-                for (int i = 0; i < W; ++i)
-                    if (i < nv1 && (X[i] >> 16) == target + 2u * i) mask |= (1ull << i);
-                masks[((uint64_t)rt.mask_begin + k1) * 2 + 1] = mask;
-                --k1;
-            }
+            record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
         }
-        // sides that were not replayed (or rows never reached) report no columns
+        // sides that were not replayed report no columns
         if (!has0)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
         if (!has1)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
     }
+}
+
+// K3f: table-driven replay.  One workgroup = the 256 pairs of one fill workgroup; the first task of
+// every pair whose tile pair matches its fusion's agreed (M1 tile, M2 tile) is replayed here with
+// the same LDS score tables as the fast fill kernel (no row maxima, no stores: add + max3 per column).
+__global__ __launch_bounds__(WG_LANES, 4) void k_replay_fast(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+                                                             const Counters* __restrict__ ctr,
+                                                             const PairState* __restrict__ state,
+                                                             const KeptRow* __restrict__ kept, uint64_t kept_cap,
+                                                             const dsa_pair* __restrict__ pairs,
+                                                             const dsa_fusion* __restrict__ fusions,
+                                                             const WgInfo* __restrict__ wginfo,
+                                                             const int32_t* __restrict__ wgtile,
+                                                             const uint32_t* __restrict__ refcodes,
+                                                             const uint32_t* __restrict__ rowcodes,
+                                                             const uint32_t* __restrict__ bnd,
+                                                             uint64_t* __restrict__ masks, uint64_t mask_cap,
+                                                             uint64_t gtask_cap, Geom g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
+    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || ctr->n_gtasks > gtask_cap) return;
+    const WgInfo wgi = wginfo[blockIdx.x];
+    int tile[GMAX];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k) {
+        tile[k] = wgtile[(int64_t)blockIdx.x * GMAX + k];
+        any |= tile[k] >= 0;
+    }
+    if (!any) return;                                   // uniform
+    // tables for the agreed tile pair of every fusion of the workgroup
+    for (int e = threadIdx.x; e < wgi.n_groups * NCOMBO * W; e += WG_LANES) {
+        const int i = e & (W - 1);
+        const int combo = (e >> 6) % NCOMBO;
+        const int gi = (e >> 6) / NCOMBO;
+        int key = -1;
+#pragma unroll
+        for (int k = 0; k < GMAX; ++k)
+            if (k == gi) key = tile[k];
+        uint32_t val = 0;
+        if (key >= 0) {
+            const int c0 = key >> 8, c1 = key & 0xFF;
+            const uint32_t* rc = refcodes + (int64_t)wgi.group_f[gi] * g.lrp;
+            const uint32_t q0 = c0 != NO_CHUNK ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
+            const uint32_t q1 = c1 != NO_CHUNK ? (rc[c1 * W + i] >> 16) : REF_PAD16;
+            const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};
+            int k1, k2;
+            table_row_classes(combo, k1, k2);
+            const uint32_t d0 = q0 == REF_PAD16 ? 0u : ((q0 >> 8) == cls_byte[k1] ? 4u : 1u);
+            const uint32_t d1 = q1 == REF_PAD16 ? 0u : ((q1 >> 8) == cls_byte[k2] ? 4u : 1u);
+            val = (d0 | (d1 << 16)) + (i > 0 ? TWO2 : 0u);
+        }
+        T[gi * TGROUP + combo * TROW + i] = val;
+    }
+    // Lanes take the workgroup's tasks in order of their first kept read split, so that the lanes of
+    // a wave reach their kept rows (where the column masks are extracted: ~400 instructions) together
+    // and sweep about the same number of rows.  Counting sort in LDS; any tie order gives the same output.
+    __shared__ int s_hist[258];
+    __shared__ unsigned short s_order[WG_LANES];
+    for (int e = threadIdx.x; e < 258; e += WG_LANES) s_hist[e] = 0;
+    __syncthreads();
+    int my_key = 256, my_rank = 0;
+    {
+        const int64_t q = (int64_t)blockIdx.x * WG_LANES + threadIdx.x;
+        if (q < g.n_pairs) {
+            const PairState sq = state[q];
+            if (sq.n_kept > 0 && sq.n_tasks > 0 && (tasks[sq.task_begin].last_row & TASK_FAST))
+                my_key = min((int)kept[sq.kept_begin].a, 255);
+        }
+        my_rank = atomicAdd(&s_hist[my_key], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int e = 0; e < 257; ++e) {
+            const int n = s_hist[e];
+            s_hist[e] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
+    __syncthreads();
+
+    const int64_t p = (int64_t)blockIdx.x * WG_LANES + s_order[threadIdx.x];
+    const int lane = (int)(p & 63);
+    const int64_t w = p >> 6;
+    bool has = false;
+    PairState st{};
+    ReplayTask rt{};
+    dsa_pair pr{};
+    dsa_fusion fu{};
+    if (p < g.n_pairs) {
+        st = state[p];
+        if (st.n_kept > 0 && st.n_tasks > 0) {
+            rt = tasks[st.task_begin];
+            has = (rt.last_row & TASK_FAST) != 0;
+        }
+        pr = pairs[p];
+        fu = fusions[pr.fusion_idx];
+    }
+    const int R = has ? (rt.last_row & 0x7FFF) : 0;
+    int Rw = R;                                          // wave maximum
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) Rw = max(Rw, __shfl_xor(Rw, d, 64));
+    if (Rw == 0) return;                                  // wave-uniform; no barriers below
+    const bool has0 = has && rt.chunk0 != NO_CHUNK, has1 = has && rt.chunk1 != NO_CHUNK;
+    const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
+    int gsel = 0;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k)
+        if (k < wgi.n_groups && wgi.group_f[k] == pr.fusion_idx) gsel = k;
+    const uint32_t* tb = T + gsel * TGROUP;
+    const int64_t wr = w < g.n_waves ? w : (int64_t)blockIdx.x * WG_WAVES;   // idle lanes read a valid plane
+    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + wr * g.lq1 * WAVE) + lane;
+    const uint4* bi0 = reinterpret_cast<const uint4*>(bnd + (wr * g.nch + (c0 - 1)) * g.lq1 * WAVE) + lane;
+    const uint4* bi1 = reinterpret_cast<const uint4*>(bnd + (wr * g.nch + (c1 - 1)) * g.lq1 * WAVE) + lane;
+    const KeptRow* kr = kept + st.kept_begin;
+    const int lq = pr.read_len;
+    const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
+    const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
+    int k0 = 0, k1 = st.n_kept - 1;
+
+    uint32_t X[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+    const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+    uint32_t bprev = BIAS2;
+    const int ngq = (Rw >> 2) + 1;
+    auto boundary = [&](int gq) -> uint4 {
+        const uint4 x0 = c0 > 0 ? bi0[(int64_t)gq * WAVE] : bias4;
+        const uint4 x1 = c1 > 0 ? bi1[(int64_t)gq * WAVE] : bias4;
+        return make_uint4((x0.x & 0xFFFFu) | (x1.x & 0xFFFF0000u), (x0.y & 0xFFFFu) | (x1.y & 0xFFFF0000u),
+                          (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
+    };
+    uint4 rc_n = rows4[0];
+    uint4 b_n = boundary(0);
+    for (int gq = 0; gq < ngq; ++gq) {
+        const uint4 rc = rc_n, b = b_n;
+        const int gn = gq + 1 < ngq ? gq + 1 : gq;
+        rc_n = rows4[(int64_t)gn * WAVE];
+        b_n = boundary(gn);
+        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * gq + sidx;
+            const uint32_t bcur = bv[sidx];
+            if (j >= 1 && j <= Rw) {                     // wave-uniform
+                const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
+                uint4 v = trow[0];
+                uint32_t a = bprev + v.x;
+                uint32_t up = bcur - TWO2;
+#pragma unroll
+                for (int q = 0; q < W / 4; ++q) {
+                    uint4 vn = v;
+                    if (q + 1 < W / 4) vn = trow[q + 1];
+                    uint32_t an;
+                    an = X[4 * q + 0] + v.y;
+                    X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                    a = an;
+                    an = X[4 * q + 1] + v.z;
+                    X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                    a = an;
+                    an = X[4 * q + 2] + v.w;
+                    X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                    a = an;
+                    an = X[4 * q + 3] + vn.x;
+                    X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                    a = an;
+                    up = X[4 * q + 3];
+                    v = vn;
+                }
+                if (has && j <= R) record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
+            }
+            bprev = bcur;
+        }
+    }
+    if (has && !has0)
+        for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
+    if (has && !has1)
+        for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
 }
 
 // K4: emit.  For every kept split a (ascending) the cross product columns1 x columns2 in ascending
