@@ -37,6 +37,26 @@ def build_lib(force=False):
     return LIB
 
 
+TOOLS = ["dosplitalign"]
+
+
+def build_tools(force=False):
+    """The drop-in tool binaries (C++17 host code on the C ABI) -> bin/."""
+    bindir = os.path.join(ROOT, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    lib = build_lib(force)
+    outs = []
+    for t in TOOLS:
+        src = os.path.join(ROOT, "tools_src", t + ".cpp")
+        out = os.path.join(bindir, t)
+        deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"), lib]
+        if force or _newer(out, deps):
+            _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out, src, lib,
+                  "-Wl,-rpath,$ORIGIN/../defuse_amd"])
+        outs.append(out)
+    return outs
+
+
 def build_oracle(force=False):
     out = os.path.join(ROOT, "oracle", "libdsa_oracle.so")
     srcs = [os.path.join(ROOT, "oracle", "dsa_oracle.c"), os.path.join(ROOT, "include", "defuse_dsa.h")]
@@ -49,6 +69,7 @@ def main(argv):
     force = "--force" in argv
     build_lib(force)
     if "--lib" not in argv:
+        build_tools(force)
         build_oracle(force)
 
 

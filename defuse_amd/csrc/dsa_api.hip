@@ -298,14 +298,14 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
                                ctx->d_bnd.p, ctx->d_masks.p, (uint64_t)(ctx->d_masks.cap / 2), g);
             hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
                                ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p, (const int64_t*)nullptr,
-                               (dsa_record*)nullptr, (uint64_t)0, g);
+                               (dsa_record*)nullptr, (uint64_t)0, (int64_t)s.pair_begin, g);
             HIPC(hipMemsetAsync(ctx->d_rec_count.p + np, 0, sizeof(int64_t), st));
             if (int rc = exclusive_scan(ctx, ctx->d_rec_count.p, ctx->d_rec_offset.p, np + 1)) return rc;
         }
         hipLaunchKernelGGL(k_emit<true>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
                            ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p,
                            (const int64_t*)ctx->d_rec_offset.p, ctx->d_records.p + ctx->n_records,
-                           (uint64_t)(ctx->d_records.cap - ctx->n_records), g);
+                           (uint64_t)(ctx->d_records.cap - ctx->n_records), (int64_t)s.pair_begin, g);
         HIPC(hipEventRecord(ctx->ev[3], st));
         HIPC(hipMemcpyAsync(&ctr, ctx->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -419,6 +419,7 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     if (!ctx) return DSA_E_ARG;
     if (n_fusions < 0 || n_pairs < 0 || ref_bytes_len < 0 || read_bytes_len < 0)
         return fail(ctx, DSA_E_ARG, "negative size");
+    if (n_pairs >= ((int64_t)1 << 31)) return fail(ctx, DSA_E_LIMIT, "more than 2^31-1 pairs in one batch");
     if ((n_fusions && !fusions) || (n_pairs && !pairs) || (ref_bytes_len && !ref_bytes) || (read_bytes_len && !read_bytes))
         return fail(ctx, DSA_E_ARG, "null pointer with non-zero size");
     dsa_limits lim;

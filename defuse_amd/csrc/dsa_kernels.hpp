@@ -1004,7 +1004,7 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
                        const PairState* __restrict__ state, const KeptRow* __restrict__ kept,
                        const ReplayTask* __restrict__ tasks, const uint64_t* __restrict__ masks,
                        int64_t* __restrict__ rec_count, const int64_t* __restrict__ rec_offset,
-                       dsa_record* __restrict__ out, uint64_t out_cap, Geom g)
+                       dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base, Geom g)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.n_pairs) return;
@@ -1045,6 +1045,7 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
                                 rec.read_first = kr.a;
                                 rec.read_second = pr.read_len - kr.a;
                                 rec.score = kr.m1 < kr.m2 ? kr.m1 : kr.m2;
+                                rec.pair_idx = (int32_t)(pair_base + p);
                                 out[wr] = rec;
                             }
                             ++wr;

@@ -16,8 +16,8 @@ FUSION_DTYPE = np.dtype([("fusion_id", "<i4"), ("ref0_off", "<i4"), ("ref0_len",
 PAIR_DTYPE = np.dtype([("fusion_idx", "<i4"), ("read_off", "<i4"), ("read_len", "<i4"), ("frag", "<i4"),
                        ("read_end", "u1"), ("revcomp", "u1"), ("pad_", "u1", (2,))])
 RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "revcomp", "ref_first",
-                                             "ref_second", "read_first", "read_second", "score")])
-assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 36
+                                             "ref_second", "read_first", "read_second", "score", "pair_idx")])
+assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
 EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_align_batch",
            "dsa_upload", "dsa_run", "dsa_download", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]

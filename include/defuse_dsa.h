@@ -65,12 +65,15 @@ typedef struct dsa_pair {
     uint8_t pad_[2];
 } dsa_pair;
 
-/* One output line of dosplitalign (tools/SplitAlignment.cpp:305-317). */
+/* One output line of dosplitalign (tools/SplitAlignment.cpp:305-317), plus the index of the
+ * candidate it belongs to, so that a caller that reordered its candidates (e.g. grouped them by
+ * fusion) can restore its own output order. */
 typedef struct dsa_record {
     int32_t fusion_id, frag, read_end, revcomp;
     int32_t ref_first, ref_second;      /* refSplit  */
     int32_t read_first, read_second;    /* readSplit */
     int32_t score;                      /* min(score1, score2) */
+    int32_t pair_idx;                   /* index into pairs[] of the batch (n_pairs < 2^31) */
 } dsa_record;
 
 typedef struct dsa_limits {

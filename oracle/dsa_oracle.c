@@ -220,6 +220,7 @@ int ora_align_batch(const uint8_t* ref_bytes, int64_t ref_bytes_len,
                 r->read_first = tmp[q].read_first;
                 r->read_second = tmp[q].read_second;
                 r->score = tmp[q].score;
+                r->pair_idx = (int32_t)p;
             }
             n++;
         }

@@ -91,7 +91,7 @@ def test_smoke_vector_through_gpu(gpu_ctx, ora):
         bb.add_read(fidx[t.fusion_id], seq, frag=frag, read_end=rend, revcomp=revcomp)
     got = gpu_ctx.align_batch(*bb.arrays())
     exp = [tuple(int(x) for x in l.split()) for l in open(d + "expected.split.align.txt")]
-    assert as_tuples(got) == exp
+    assert [t[:9] for t in as_tuples(got)] == exp
 
 
 def test_slicing_gives_same_records(built, ora):
@@ -139,8 +139,11 @@ def test_full_size_properties(gpu_ctx, ora):
     sel = np.isin(pairs["fusion_idx"], sample)
     exp = ora.align_batch(ref, fus, reads, pairs[sel])
     sub = got[np.isin(got["fusion_id"], sample)]
-    assert sub.tobytes() == exp.tobytes()
+    for name in got.dtype.names:
+        if name != "pair_idx":                                     # the sample renumbers the pairs
+            assert (sub[name] == exp[name]).all(), name
+    assert len(sub) == len(exp)
     # order independence: the same fusions presented in reverse order give the same records per pair
     order = np.argsort(-pairs["fusion_idx"][sel], kind="stable")
     rev = gpu_ctx.align_batch(ref, fus, reads, pairs[sel][order])
-    assert sorted(as_tuples(rev)) == sorted(as_tuples(exp))
+    assert sorted(t[:9] for t in as_tuples(rev)) == sorted(t[:9] for t in as_tuples(exp))

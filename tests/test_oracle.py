@@ -104,7 +104,7 @@ def test_no_cpu_fallback_without_gpu(built):
 
 def test_struct_layouts_match_header(built):
     from defuse_amd import dsa
-    assert dsa.FUSION_DTYPE.itemsize == 20 and dsa.PAIR_DTYPE.itemsize == 20 and dsa.RECORD_DTYPE.itemsize == 36
+    assert dsa.FUSION_DTYPE.itemsize == 20 and dsa.PAIR_DTYPE.itemsize == 20 and dsa.RECORD_DTYPE.itemsize == 40
     assert ctypes.sizeof(dsa.Timing) == 48 and ctypes.sizeof(dsa.Limits) == 12
 
 
@@ -119,7 +119,8 @@ def test_oracle_batch_matches_python_loop(ora):
         rd = reads[p["read_off"]:p["read_off"] + p["read_len"]].tobytes()
         for (a, b, c, d, s) in ora.task_align(rd, r0, r1):
             exp.append((f["fusion_id"], p["frag"], p["read_end"], p["revcomp"], a, b, c, d, s))
-    assert [tuple(int(x) for x in r) for r in recs] == [tuple(int(x) for x in e) for e in exp]
+    assert [tuple(int(x) for x in r)[:9] for r in recs] == [tuple(int(x) for x in e) for e in exp]
+    assert (np.diff(recs["pair_idx"]) >= 0).all()
     assert len(exp) > 0
 
 

@@ -1,0 +1,93 @@
+"""The drop-in tool binaries: command line behaviour (CPU) and byte-exact outputs (GPU)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from tests import pipeline_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMOKE = os.path.join(ROOT, "tests", "golden", "smoke")
+TOOL = os.path.join(ROOT, "bin", "dosplitalign")
+
+
+@pytest.fixture(scope="module")
+def tools(built):
+    from defuse_amd import build
+    build.build_tools()
+    return True
+
+
+def smoke_args(tmp, out, regions="regions.txt"):
+    for n in ("ref.fa", "exons.txt", "regions.txt", "improper.sam", "reads.1.fastq", "reads.2.fastq"):
+        shutil.copy(os.path.join(SMOKE, n), tmp)          # the tool writes ref.fa.fai next to the FASTA
+    d = str(tmp) + "/"
+    return ["-f", d + "ref.fa", "-e", d + "exons.txt", "-u", "300", "-s", "30", "-n", "50", "-x", "50", "-r", d + regions,
+            "-i", d + "improper.sam", "-1", d + "reads.1.fastq", "-2", d + "reads.2.fastq", "-a", out]
+
+
+def test_cli_errors(tools, tmp_path):
+    r = subprocess.run([TOOL, "-f", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stderr.startswith("PARSE ERROR:") and "Required arguments missing" in r.stderr
+    r = subprocess.run([TOOL, "--bogus", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Couldn't find match for argument" in r.stderr
+    args = smoke_args(tmp_path, str(tmp_path / "o"))
+    args[args.index("-n") + 1] = "fifty"
+    r = subprocess.run([TOOL] + args, capture_output=True, text=True)
+    assert r.returncode == 1 and "Couldn't read argument value" in r.stderr
+    r = subprocess.run([TOOL, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Fusion sequence prediction by split reads" in r.stdout
+    for flag in ("--fasta", "--exons", "--ufrag", "--sfrag", "--minread", "--maxread", "--regions", "--improper",
+                 "--seq1", "--seq2", "--align"):
+        assert flag in r.stdout                                 # tools/dosplitalign.cpp:43-56
+
+
+def test_missing_inputs_fail(tools, tmp_path):
+    args = smoke_args(tmp_path, str(tmp_path / "o"))
+    args[args.index("-r") + 1] = str(tmp_path / "nope.txt")
+    r = subprocess.run([TOOL] + args, capture_output=True, text=True)
+    assert r.returncode != 0 and "Unable to open align region pairs file" in r.stderr
+    args = smoke_args(tmp_path, str(tmp_path / "o"))
+    args[args.index("-1") + 1] = str(tmp_path / "reads.1.txt")
+    r = subprocess.run([TOOL] + args, capture_output=True, text=True)
+    assert r.returncode != 0 and "unrecognized extension" in r.stderr
+
+
+def test_no_candidates_needs_no_gpu(tools, tmp_path):
+    """Regions that no mate alignment touches: empty output file, exit 0, .fai index built."""
+    args = smoke_args(tmp_path, str(tmp_path / "out.align"))
+    with open(tmp_path / "far.txt", "w") as f:
+        f.write("7\t0\tchrA\t+\t2500\t2600\n7\t1\tchrA\t-\t200\t300\n")
+    args[args.index("-r") + 1] = str(tmp_path / "far.txt")
+    r = subprocess.run([TOOL] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "[fai_load] build FASTA index." in r.stderr
+    assert os.path.getsize(tmp_path / "out.align") == 0
+    fai = open(tmp_path / "ref.fa.fai").read().split("\n")
+    assert fai[0] == "chrA\t3000\t6\t60\t61" and fai[1] == "chrB\t3000\t3062\t60\t61"
+
+
+@pytest.mark.gpu
+def test_dosplitalign_smoke_vector(tools, tmp_path):
+    """The reference's own known-answer vector through the drop-in binary, byte for byte."""
+    out = tmp_path / "split.align"
+    r = subprocess.run([TOOL] + smoke_args(tmp_path, str(out)), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp = "".join("\t".join(l.split()) + "\t\n" for l in open(os.path.join(SMOKE, "expected.split.align.txt")))
+    assert out.read_text() == exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5, 6])
+def test_dosplitalign_matches_oracle(tools, tmp_path, seed):
+    from oracle import dosplitalign_oracle as ora
+    case = pipeline_case.build(str(tmp_path / "case"), seed=seed)
+    exp = ora.dosplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                           case["regions"], case["improper"], case["seq1"], case["seq2"])
+    os.remove(case["fasta"] + ".fai") if os.path.exists(case["fasta"] + ".fai") else None
+    out = tmp_path / "split.align"
+    r = subprocess.run([TOOL] + pipeline_case.tool_args(case, str(out)), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert len(exp.splitlines()) > 20
+    assert out.read_text() == exp

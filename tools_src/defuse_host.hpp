@@ -1,0 +1,656 @@
+// defuse_host.hpp — host-side logic of the drop-in `dosplitalign` / `evalsplitalign` binaries.
+//
+// Written from scratch (C++17, no Boost, no samtools) to behave like the reference's C++98 tools
+// for the split-alignment path; every block cites the reference code it mirrors (paths relative
+// to the reference tree).  The DP itself is NOT here: candidates are batched and handed to the HIP
+// library through include/defuse_dsa.h.
+#pragma once
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace defuse {
+
+enum Strand { PlusStrand = 0, MinusStrand = 1 };   // tools/Common.h:20-24
+
+struct Region { int start = 0, end = 0; };
+struct Location { std::string refName; int strand = 0, start = 0, end = 0; };
+
+[[noreturn]] inline void die(const std::string& msg)
+{
+    std::cerr << msg << std::endl;
+    std::exit(1);
+}
+
+// C++ `int / int` truncates toward zero — the bin arithmetic of the reference relies on it.
+inline std::vector<std::string> split_tabs(const std::string& line, char sep = '\t')
+{
+    std::vector<std::string> out;   // boost::split(is_any_of("\t")): empty fields are kept
+    size_t b = 0;
+    for (;;) {
+        size_t e = line.find(sep, b);
+        if (e == std::string::npos) { out.emplace_back(line.substr(b)); break; }
+        out.emplace_back(line.substr(b, e - b));
+        b = e + 1;
+    }
+    return out;
+}
+
+// boost::lexical_cast<int>: optional sign, digits only, no whitespace, no trailing junk, range checked.
+inline bool lexical_int(const std::string& s, int& out)
+{
+    if (s.empty()) return false;
+    size_t k = (s[0] == '+' || s[0] == '-') ? 1 : 0;
+    if (k == s.size()) return false;
+    long long v = 0;
+    for (size_t i = k; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        v = v * 10 + (s[i] - '0');
+        if (v > 2147483648LL) return false;
+    }
+    if (s[0] == '-') v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
+    out = (int)v;
+    return true;
+}
+inline int lexical_int_or_die(const std::string& s, const std::string& context)
+{
+    int v;
+    if (!lexical_int(s, v)) die("Error: bad integer '" + s + "' " + context);   // reference: uncaught bad_lexical_cast
+    return v;
+}
+
+// tools/Common.cpp:32-54
+inline void ReverseComplement(std::string& seq)
+{
+    std::reverse(seq.begin(), seq.end());
+    for (char& c : seq) {
+        switch (c) {
+            case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'T': c = 'A'; break; case 'G': c = 'C'; break;
+            case 'a': c = 't'; break; case 'c': c = 'g'; break; case 't': c = 'a'; break; case 'g': c = 'c'; break;
+        }
+    }
+}
+
+inline int InterpretStrand(const std::string& s)   // tools/Common.cpp:91-106
+{
+    if (s == "+") return PlusStrand;
+    if (s == "-") return MinusStrand;
+    die("Error: Unable to intepret strand " + s);
+}
+
+// ReadID / ClusterID bit-field unions (tools/Common.h:192-218): low 31 bits index, top bit end.
+inline int pack_id(int index, int end) { return (int)(((uint32_t)index & 0x7FFFFFFFu) | ((uint32_t)end << 31)); }
+
+// ---------------------------------------------------------------------------------------------
+// Command line in the style of the reference's TCLAP usage (all arguments required, short or long
+// name, "--" ends parsing, -h/--help, --version; parse error -> "PARSE ERROR:" on stderr, exit 1;
+// include/tclap/CmdLine.h:306-326,370-416, StdOutput.h:130-152).
+// ---------------------------------------------------------------------------------------------
+class CmdLine {
+public:
+    struct Arg { std::string flag, name, desc, type; std::string value; bool set = false; };
+    CmdLine(std::string message, std::string version = "none") : message_(std::move(message)), version_(std::move(version)) {}
+    void add(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type)
+    {
+        args_.push_back({flag, name, desc, type, "", false});
+    }
+    void parse(int argc, char** argv)
+    {
+        prog_ = argc > 0 ? argv[0] : "prog";
+        size_t slash = prog_.find_last_of('/');
+        if (slash != std::string::npos) prog_ = prog_.substr(slash + 1);
+        for (int i = 1; i < argc; ++i) {
+            std::string tok = argv[i];
+            if (tok == "--") break;
+            if (tok == "-h" || tok == "--help") { usage(std::cout); std::exit(0); }
+            if (tok == "--version") { std::cout << std::endl << prog_ << "  version: " << version_ << std::endl << std::endl; std::exit(0); }
+            Arg* a = find(tok);
+            if (!a) fail("Argument: " + tok, "Couldn't find match for argument");
+            if (a->set) fail("Argument: " + id(*a), "Argument already set!");
+            if (i + 1 >= argc) fail("Argument: " + id(*a), "Missing a value for this argument!");
+            a->value = argv[++i];
+            a->set = true;
+            if (a->type == "integer") { int v; if (!strict_int(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
+            if (a->type == "float") { double v; if (!strict_double(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
+        }
+        std::string missing;
+        for (const Arg& a : args_)
+            if (!a.set) missing += (missing.empty() ? "" : ", ") + a.name;
+        if (!missing.empty()) fail("", "Required arguments missing: " + missing);
+    }
+    std::string str(const std::string& name) const { return get(name).value; }
+    int integer(const std::string& name) const { int v = 0; strict_int(get(name).value, v); return v; }
+    double real(const std::string& name) const { double v = 0; strict_double(get(name).value, v); return v; }
+
+private:
+    static bool strict_int(const std::string& s, int& v)
+    {
+        std::istringstream is(s);
+        is >> v;
+        return !is.fail() && is.peek() == EOF;
+    }
+    static bool strict_double(const std::string& s, double& v)
+    {
+        std::istringstream is(s);
+        is >> v;
+        return !is.fail() && is.peek() == EOF;
+    }
+    static std::string id(const Arg& a) { return "-" + a.flag + " (--" + a.name + ")"; }
+    Arg* find(const std::string& tok)
+    {
+        for (Arg& a : args_)
+            if (tok == "-" + a.flag || tok == "--" + a.name) return &a;
+        return nullptr;
+    }
+    const Arg& get(const std::string& name) const
+    {
+        for (const Arg& a : args_)
+            if (a.name == name) return a;
+        die("internal error: unknown argument " + name);
+    }
+    void short_usage(std::ostream& os) const
+    {
+        os << "   " << prog_;
+        for (const Arg& a : args_) os << " -" << a.flag << " <" << a.type << ">";
+        os << " [--] [--version] [-h]" << std::endl;
+    }
+    void usage(std::ostream& os) const
+    {
+        os << std::endl << "USAGE: " << std::endl << std::endl;
+        short_usage(os);
+        os << std::endl << std::endl << "Where: " << std::endl << std::endl;
+        for (const Arg& a : args_)
+            os << "   -" << a.flag << " <" << a.type << ">,  --" << a.name << " <" << a.type << ">" << std::endl
+               << "     (required)  " << a.desc << std::endl << std::endl;
+        os << "   --,  --ignore_rest" << std::endl << "     Ignores the rest of the labeled arguments following this flag." << std::endl << std::endl
+           << "   --version" << std::endl << "     Displays version information and exits." << std::endl << std::endl
+           << "   -h,  --help" << std::endl << "     Displays usage information and exits." << std::endl << std::endl << std::endl
+           << "   " << message_ << std::endl << std::endl;
+    }
+    [[noreturn]] void fail(const std::string& arg_id, const std::string& error) const
+    {
+        std::cerr << "PARSE ERROR: " << arg_id << std::endl << "             " << error << std::endl << std::endl;
+        std::cerr << "Brief USAGE: " << std::endl;
+        short_usage(std::cerr);
+        std::cerr << std::endl << "For complete USAGE and HELP type: " << std::endl << "   " << prog_ << " --help" << std::endl << std::endl;
+        std::exit(1);
+    }
+    std::string message_, version_, prog_;
+    std::vector<Arg> args_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// FASTA random access: tools/FastaIndex.cpp:18-61 on top of a .fai index with the semantics of
+// external/samtools-0.1.8/faidx.c (fai_load builds "<fasta>.fai" when missing, :260-300; fai_fetch
+// :305-357: 1-based inclusive region clipped to the sequence, non-graph characters skipped).
+// ---------------------------------------------------------------------------------------------
+class FastaIndex {
+public:
+    void Open(const std::string& fasta)
+    {
+        const std::string fai = fasta + ".fai";
+        std::ifstream in(fai.c_str(), std::ios::binary);
+        if (!in.good()) {
+            std::cerr << "[fai_load] build FASTA index." << std::endl;
+            build(fasta, fai);
+            in.open(fai.c_str(), std::ios::binary);
+            if (!in.good()) die("[fai_load] fail to open FASTA index.");
+        }
+        std::string line;
+        while (std::getline(in, line)) {
+            size_t e = 0;
+            while (e < line.size() && std::isgraph((unsigned char)line[e])) ++e;
+            Entry en;
+            std::istringstream rest(e < line.size() ? line.substr(e + 1) : "");
+            rest >> en.len >> en.offset >> en.line_blen >> en.line_len;
+            index_[line.substr(0, e)] = en;
+        }
+        file_.open(fasta.c_str(), std::ios::binary);
+        if (!file_.good()) die("[fai_load] fail to open FASTA file.");
+    }
+
+    // FastaIndex::Get: start/length are in-out (tools/FastaIndex.h:24): clipped values flow back.
+    void Get(const std::string& reference, int strand, int& start, int& length, std::string& sequence) const
+    {
+        if (length < 0) { sequence.clear(); return; }
+        if (start < 1) { length -= 1 - start; start = 1; }
+        const int end = start + length - 1;
+        auto it = index_.find(reference);
+        if (it == index_.end()) die("Error: Unable to find sequence for " + reference);
+        const Entry& en = it->second;
+        long long beg = start, e = end;       // the reference formats "name:start-end" and parses it back with atoi
+        if (beg > 0) --beg;
+        if (beg >= en.len) beg = en.len;
+        if (e >= en.len) e = en.len;
+        if (beg > e) beg = e;
+        sequence.clear();
+        if (e > beg && en.line_blen > 0) {
+            file_.clear();
+            file_.seekg(en.offset + beg / en.line_blen * en.line_len + beg % en.line_blen, std::ios::beg);
+            sequence.reserve((size_t)(e - beg));
+            char c;
+            while ((long long)sequence.size() < e - beg && file_.get(c))
+                if (std::isgraph((unsigned char)c)) sequence.push_back(c);
+        }
+        length = (int)sequence.size();
+        if (strand == MinusStrand) ReverseComplement(sequence);
+    }
+
+private:
+    struct Entry { long long len = 0, offset = 0; int line_blen = 0, line_len = 0; };
+    static void build(const std::string& fasta, const std::string& fai)
+    {
+        std::ifstream in(fasta.c_str(), std::ios::binary);
+        if (!in.good()) die("[fai_build] fail to open the FASTA file " + fasta);
+        std::ofstream out(fai.c_str(), std::ios::binary);
+        if (!out.good()) die("[fai_build] fail to write FASTA index " + fai);
+        std::string line, name;
+        long long pos = 0, len = 0, offset = 0;
+        int line_blen = 0, line_len = 0;
+        bool have = false, first_line = true;
+        auto flush = [&]() { if (have) out << name << "\t" << len << "\t" << offset << "\t" << line_blen << "\t" << line_len << "\n"; };
+        while (std::getline(in, line)) {
+            const long long raw = (long long)line.size() + 1;
+            if (!line.empty() && line[0] == '>') {
+                flush();
+                size_t e = 1;
+                while (e < line.size() && !std::isspace((unsigned char)line[e])) ++e;
+                name = line.substr(1, e - 1);
+                have = true;
+                len = 0;
+                offset = pos + raw;
+                first_line = true;
+                line_blen = line_len = 0;
+            } else if (have) {
+                int graph = 0;
+                for (char c : line) graph += std::isgraph((unsigned char)c) ? 1 : 0;
+                if (first_line) { line_blen = graph; line_len = (int)raw; first_line = false; }
+                len += graph;
+            }
+            pos += raw;
+        }
+        flush();
+    }
+    std::unordered_map<std::string, Entry> index_;
+    mutable std::ifstream file_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// tools/ExonRegions.cpp (the parts the split-alignment path reaches).
+// ---------------------------------------------------------------------------------------------
+class ExonRegions {
+public:
+    bool Read(std::istream& in)   // :21-112
+    {
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty()) continue;
+            std::vector<std::string> f = split_tabs(line);
+            if (f.size() < 6) continue;
+            const std::string &gene = f[0], &transcript = f[1], &chromosome = f[2], &strand = f[3];
+            std::vector<Region> exons;
+            for (size_t k = 5; k < f.size(); k += 2) {
+                Region ex;
+                if (!lexical_int(f[k - 1], ex.start) || !lexical_int(f[k], ex.end)) {
+                    std::cout << "Failed to interpret exon:" << std::endl << line << std::endl;
+                    std::exit(1);
+                }
+                exons.push_back(ex);
+            }
+            const int s = InterpretStrand(strand);
+            int total = 0;
+            for (const Region& r : exons) total += r.end - r.start + 1;
+            chromosome_[transcript] = chromosome;
+            strand_[transcript] = s;
+            exons_[transcript] = exons;
+            length_[transcript] = total;
+            gene_[transcript] = gene;
+            exons_str_[PlusStrand][transcript] = exons;
+            std::vector<Region> minus;   // TransformExons :114-124
+            for (auto it = exons.rbegin(); it != exons.rend(); ++it) minus.push_back(Region{-it->end, -it->start});
+            exons_str_[MinusStrand][transcript] = minus;
+            region_[transcript] = Region{exons.front().start, exons.back().end};
+            for (int b = region_[transcript].start / kBin; b <= region_[transcript].end / kBin; ++b)
+                lookup_[chromosome][b].push_back(transcript);
+        }
+        return true;
+    }
+    bool IsTranscript(const std::string& t) const { return gene_.count(t) != 0; }
+    const std::string& GetTranscriptGene(const std::string& t) const
+    {
+        auto it = gene_.find(t);
+        if (it == gene_.end()) die("Error: Data mismatch, unable to find gene for transcript " + t);
+        return it->second;
+    }
+    void GetRegionTranscripts(const std::string& chromosome, const Region& region, std::vector<std::string>& out) const   // :131-161
+    {
+        auto ci = lookup_.find(chromosome);
+        if (ci == lookup_.end()) die("Error: Data mismatch, invalid chromosome " + chromosome);
+        std::set<std::string> uniq;   // canonical order: ascending
+        for (int b = region.start / kBin; b <= region.end / kBin; ++b) {
+            auto bi = ci->second.find(b);
+            if (bi == ci->second.end()) continue;
+            for (const std::string& t : bi->second) {
+                const Region& r = region_.at(t);
+                if (!(r.end < region.start || r.start > region.end)) uniq.insert(t);
+            }
+        }
+        out.insert(out.end(), uniq.begin(), uniq.end());
+    }
+    bool RemapTranscriptToGenome(const std::string& t, int strand, int position, std::string& chrom, int& rstrand, int& rpos) const   // :258-302
+    {
+        auto ei = exons_.find(t);
+        if (ei == exons_.end() || ei->second.empty()) die("Error: Data mismatch, unable to find transcript " + t);
+        const std::vector<Region>& ex = ei->second;
+        const int tlen = length_.at(t), tstrand = strand_.at(t);
+        chrom = chromosome_.at(t);
+        rstrand = (tstrand == strand) ? PlusStrand : MinusStrand;
+        if (tstrand == MinusStrand) position = tlen - position + 1;
+        int off = 0;
+        for (const Region& r : ex) {
+            const int n = r.end - r.start + 1;
+            if (position <= off + n) { rpos = position - (off + 1) + r.start; return true; }
+            off += n;
+        }
+        rpos = position - tlen + ex.back().end;
+        return true;
+    }
+    bool RemapThroughTranscript(const std::string& t, int position, int strand, int ext_min, int ext_max, int& rstrand, int& start, int& end) const   // :421-482
+    {
+        auto ei = exons_.find(t);
+        if (ei == exons_.end() || ei->second.empty()) die("Error: Data mismatch, unable to find transcript " + t);
+        const std::vector<Region>& ex = exons_str_[strand].at(t);
+        const int tlen = length_.at(t), tstrand = strand_.at(t);
+        rstrand = (strand == tstrand) ? PlusStrand : MinusStrand;
+        const int sp = (strand == PlusStrand) ? position : -position;
+        if (sp > ex.back().end) return false;
+        int off = 0;
+        for (const Region& r : ex) {
+            const int n = r.end - r.start + 1;
+            if (sp <= r.end) {
+                const int rs = sp - r.start + ext_min + 1, re = sp - r.start + ext_max + 1;
+                if (re < 1) return false;
+                start = std::max(1, rs) + off;
+                end = std::max(1, re) + off;
+                break;
+            }
+            off += n;
+        }
+        if (end < 1 || start > tlen) return false;
+        if (strand != tstrand) {
+            start = tlen - start + 1;
+            end = tlen - end + 1;
+            std::swap(start, end);
+        }
+        return true;
+    }
+
+private:
+    static constexpr int kBin = 100000;   // :19
+    std::unordered_map<std::string, std::string> chromosome_, gene_;
+    std::unordered_map<std::string, int> strand_, length_;
+    std::unordered_map<std::string, std::vector<Region>> exons_;
+    mutable std::unordered_map<std::string, std::vector<Region>> exons_str_[2];
+    std::unordered_map<std::string, Region> region_;
+    std::unordered_map<std::string, std::unordered_map<int, std::vector<std::string>>> lookup_;
+};
+
+// tools/Common.cpp:117-131
+inline bool ParseTranscriptID(const std::string& id, std::string& gene, std::string& transcript)
+{
+    std::vector<std::string> f = split_tabs(id, '|');
+    if (f.size() < 2) return false;
+    gene = f[0];
+    transcript = f[1];
+    return true;
+}
+
+// tools/Parsers.cpp:211-264
+inline std::map<int, std::vector<Location>> ReadAlignRegionPairs(const std::string& filename)
+{
+    std::ifstream in(filename.c_str());
+    if (!in.good()) die("Error: Unable to open align region pairs file " + filename);
+    std::map<int, std::vector<Location>> pairs;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::vector<std::string> f = split_tabs(line);
+        if (f.size() < 5) continue;
+        int id, end;
+        Location loc;
+        bool ok = lexical_int(f[0], id) && lexical_int(f[1], end);
+        if (ok && !(end == 0 || end == 1)) die("Error: DebugCheck pairEnd == 0 || pairEnd == 1 failed");
+        if (ok) {
+            loc.refName = f[2];
+            loc.strand = InterpretStrand(f[3]);
+            ok = f.size() > 5 && lexical_int(f[4], loc.start) && lexical_int(f[5], loc.end);
+        }
+        if (!ok) {
+            std::cout << "Failed to interpret region:" << std::endl << line << std::endl;
+            std::exit(1);
+        }
+        pairs[id].resize(2);
+        pairs[id][end] = loc;
+    }
+    return pairs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SplitAlignmentTask geometry: tools/SplitAlignment.cpp:31-175, :637-655, :657-686.
+// ---------------------------------------------------------------------------------------------
+struct SplitAlignmentTask {
+    int mFusionID = 0;
+    std::string mAlignRefName[2];
+    int mAlignStrand[2] = {0, 0};
+    int mSplitAlignSeqStart[2] = {0, 0}, mSplitAlignSeqLength[2] = {0, 0}, mSplitSeqStrand[2] = {0, 0};
+    std::string mSplitAlignSeq[2], mSplitRemainderSeq[2];
+    std::vector<Location> mMateRegions[2];
+
+    static void CalculateBreakRegion(int minRead, int maxRead, int maxFrag, int alignStart, int alignEnd, int strand, int& breakStart, int& breakLength)
+    {
+        const int regionLength = alignEnd - alignStart + 1;
+        const int push = std::min(maxRead, (int)(0.5 * regionLength));
+        breakLength = maxFrag - regionLength - minRead + 2 * push;
+        breakStart = (strand == PlusStrand) ? alignEnd - push + 1 : alignStart + push - 1;
+    }
+
+    bool Initialize(int id, const std::vector<Location>& alignPair, const FastaIndex& reference, const ExonRegions& exons,
+                    double fragMean, double fragStdDev, int minReadLength, int maxReadLength)
+    {
+        mFusionID = id;
+        const int minFrag = (int)(fragMean - 3 * fragStdDev), maxFrag = (int)(fragMean + 3 * fragStdDev);
+        if (alignPair.size() != 2) {
+            std::cerr << "Error: Incorrect input for SplitAlignment::Calculate()" << std::endl;
+            return false;
+        }
+        for (int ce = 0; ce <= 1; ++ce) {
+            const std::string& refName = alignPair[ce].refName;
+            const int strand = alignPair[ce].strand, alignStart = alignPair[ce].start, alignEnd = alignPair[ce].end;
+            mAlignRefName[ce] = refName;
+            mAlignStrand[ce] = strand;
+            const int refSeqStrand = (ce == 0) ? strand : 1 - strand;
+            int breakStart, breakLength;
+            CalculateBreakRegion(minReadLength, maxReadLength, maxFrag, alignStart, alignEnd, strand, breakStart, breakLength);
+            mSplitSeqStrand[ce] = refSeqStrand;
+            if (strand == PlusStrand) {
+                mSplitAlignSeqStart[ce] = breakStart - maxReadLength;
+                mSplitAlignSeqLength[ce] = breakLength + maxReadLength;
+            } else {
+                mSplitAlignSeqStart[ce] = breakStart - breakLength + 1;
+                mSplitAlignSeqLength[ce] = breakLength + maxReadLength;
+            }
+            reference.Get(refName, refSeqStrand, mSplitAlignSeqStart[ce], mSplitAlignSeqLength[ce], mSplitAlignSeq[ce]);
+            mSplitRemainderSeq[ce].clear();
+            if (strand == PlusStrand) {
+                if (alignStart < mSplitAlignSeqStart[ce]) {
+                    int rs = alignStart, rl = mSplitAlignSeqStart[ce] - 1 - alignStart + 1;
+                    reference.Get(refName, refSeqStrand, rs, rl, mSplitRemainderSeq[ce]);
+                }
+            } else if (alignEnd > mSplitAlignSeqStart[ce] + mSplitAlignSeqLength[ce] - 1) {
+                int rs = mSplitAlignSeqStart[ce] + mSplitAlignSeqLength[ce], rl = alignEnd - rs + 1;
+                reference.Get(refName, refSeqStrand, rs, rl, mSplitRemainderSeq[ce]);
+            }
+            std::string chromosome, gene, transcript;
+            int genomeStrand, genomeBreakStart;
+            if (ParseTranscriptID(refName, gene, transcript) && exons.IsTranscript(transcript)) {
+                exons.RemapTranscriptToGenome(transcript, strand, breakStart, chromosome, genomeStrand, genomeBreakStart);
+            } else {
+                chromosome = refName;
+                genomeStrand = strand;
+                genomeBreakStart = breakStart;
+            }
+            const int mateMin = minFrag - breakLength - maxReadLength + 1, mateMax = maxFrag - minReadLength;
+            Region mate;
+            if (genomeStrand == PlusStrand) { mate.start = genomeBreakStart - mateMax; mate.end = genomeBreakStart - mateMin; }
+            else { mate.start = genomeBreakStart + mateMin; mate.end = genomeBreakStart + mateMax; }
+            mMateRegions[ce].push_back(Location{chromosome, genomeStrand, mate.start, mate.end});
+            std::vector<std::string> transcripts;
+            exons.GetRegionTranscripts(chromosome, mate, transcripts);
+            for (const std::string& t : transcripts) {
+                int rstrand, ms = 0, me = 0;
+                if (exons.RemapThroughTranscript(t, genomeBreakStart, 1 - genomeStrand, mateMin, mateMax, rstrand, ms, me))
+                    mMateRegions[ce].push_back(Location{exons.GetTranscriptGene(t) + "|" + t, 1 - rstrand, ms, me});
+            }
+        }
+        return true;
+    }
+};
+
+inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, const std::string& exonsFile, double fragMean,
+                                                     double fragStdDev, int minRead, int maxRead,
+                                                     const std::map<int, std::vector<Location>>& regions)
+{
+    FastaIndex reference;
+    ExonRegions exons;
+    reference.Open(fasta);
+    std::ifstream ef(exonsFile.c_str());
+    if (!ef.good() || !exons.Read(ef)) die("Error: Unable to read exon regions file " + exonsFile);
+    std::map<int, SplitAlignmentTask> tasks;   // canonical iteration order: ascending fusion id
+    for (const auto& kv : regions) tasks[kv.first].Initialize(kv.first, kv.second, reference, exons, fragMean, fragStdDev, minRead, maxRead);
+    return tasks;
+}
+
+// tools/SplitAlignment.cpp:177-229
+class BinnedLocations {
+public:
+    explicit BinnedLocations(int spacing) : spacing_(spacing) {}
+    void Add(int id, const Location& loc)
+    {
+        const int idx = (int)ids_.size();
+        ids_.push_back(id);
+        regions_.push_back(Region{loc.start, loc.end});
+        for (int b = loc.start / spacing_; b <= loc.end / spacing_; ++b) binned_[loc.strand][loc.refName][b].push_back(idx);
+    }
+    void Overlapping(const std::string& ref, int strand, const Region& region, std::set<int>& ids) const
+    {
+        auto ri = binned_[strand].find(ref);
+        if (ri == binned_[strand].end()) return;
+        for (int b = region.start / spacing_; b <= region.end / spacing_; ++b) {
+            auto bi = ri->second.find(b);
+            if (bi == ri->second.end()) continue;
+            for (int idx : bi->second)
+                if (regions_[idx].start <= region.end && regions_[idx].end >= region.start) ids.insert(ids_[idx]);
+        }
+    }
+
+private:
+    int spacing_;
+    std::unordered_map<std::string, std::unordered_map<int, std::vector<int>>> binned_[2];
+    std::vector<int> ids_;
+    std::vector<Region> regions_;
+};
+
+// FASTQ: tools/ReadStream.cpp:18-32 (extension check), :57-104 (record parsing), AddReads SplitAlignment.cpp:253-264
+inline bool AddReads(const std::string& filename, std::unordered_map<int, std::string>& reads)
+{
+    const size_t dot = filename.find_last_of('.');
+    const std::string ext = filename.substr(dot + 1);
+    if (ext != "fastq" && ext != "fq") {
+        std::cerr << "Error: unrecognized extension " << ext << std::endl;
+        return false;
+    }
+    std::ifstream in(filename.c_str());
+    if (!in.good()) {
+        std::cerr << "Error: unable to open file " << filename << std::endl;
+        return false;
+    }
+    std::string l[4];
+    for (;;) {
+        int n = 0;
+        while (n < 4 && std::getline(in, l[n])) ++n;
+        if (n < 4) break;
+        if (l[0].empty() || l[0][0] != '@') { std::cerr << "Error: Unable to interpret read name " << l[0] << std::endl; break; }
+        const size_t slash = l[0].find_first_of('/');
+        const char endc = (slash != std::string::npos && slash + 1 < l[0].size()) ? l[0][slash + 1] : '\0';
+        if (endc != '1' && endc != '2') { std::cerr << "Error: Unable to interpret read end " << l[0] << std::endl; break; }
+        const int frag = lexical_int_or_die(l[0].substr(1, slash - 1), "in read name " + l[0]);
+        reads[pack_id(frag, endc == '1' ? 0 : 1)] = l[1];
+    }
+    return true;
+}
+
+// One record of the improper SAM: tools/AlignmentStream.cpp:39-130
+struct RawAlignment { std::string fragment, reference; int readEnd = 0, strand = 0; Region region; };
+class SamAlignmentStream {
+public:
+    explicit SamAlignmentStream(const std::string& filename)
+    {
+        if (filename == "-") in_ = &std::cin;
+        else {
+            file_.open(filename.c_str());
+            if (!file_.good()) die("Error: Unable to open sam file " + filename);
+            in_ = &file_;
+        }
+    }
+    bool GetNextAlignment(RawAlignment& a)
+    {
+        std::string line;
+        while (std::getline(*in_, line)) {
+            ++line_no_;
+            if (line.empty()) die("Error: Empty alignment line " + std::to_string(line_no_));
+            if (line[0] == '@') continue;
+            std::vector<std::string> f = split_tabs(line);
+            if (f.size() < 10) die("Error: Format error for alignment line " + std::to_string(line_no_));
+            const int flag = lexical_int_or_die(f[1], "in sam line " + std::to_string(line_no_));
+            const int pos = lexical_int_or_die(f[3], "in sam line " + std::to_string(line_no_));
+            if (f[2] == "*") continue;
+            a.strand = (flag & 0x10) ? MinusStrand : PlusStrand;
+            std::vector<std::string> q = split_tabs(f[0], '/');
+            if (q.size() == 2) {
+                if (q[1] != "1" && q[1] != "2") die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no_));
+                a.fragment = q[0];
+                a.readEnd = (q[1] == "1") ? 0 : 1;
+            } else {
+                a.fragment = f[0];
+                if (flag & 0x40) a.readEnd = 0;
+                else if (flag & 0x80) a.readEnd = 1;
+            }
+            a.reference = f[2];
+            a.region.start = pos;
+            a.region.end = pos + (int)f[9].size() - 1;
+            return true;
+        }
+        return false;
+    }
+
+private:
+    std::ifstream file_;
+    std::istream* in_ = nullptr;
+    int line_no_ = 0;
+};
+
+}  // namespace defuse

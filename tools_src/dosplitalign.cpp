@@ -1,0 +1,151 @@
+// dosplitalign — drop-in replacement of the reference tool (tools/dosplitalign.cpp:25-111): same
+// command line, same input formats, same output lines; the per-candidate
+// SplitAlignmentTask::Align of tools/SplitAlignment.cpp:294 is replaced by one batched call into the
+// MI355X library (include/defuse_dsa.h).  There is no CPU fallback: without a GPU the tool exits 1.
+//
+// Output order: one SAM record at a time, its overlapping cluster ends in ascending (signed) id order
+// — the canonical order of SURVEY.md 8(c) for the reference's unordered_set iteration (the pipeline
+// sorts the file by fusion id afterwards, scripts/defuse_run.pl:528).
+//
+// Environment: DEFUSE_GPU=<ordinal> selects the device (default 0; with HIP_VISIBLE_DEVICES the
+// ordinal is relative to the visible set).
+#include <numeric>
+
+#include "../include/defuse_dsa.h"
+#include "defuse_host.hpp"
+
+using namespace defuse;
+
+int main(int argc, char* argv[])
+{
+    CmdLine cmd("Fusion sequence prediction by split reads");
+    cmd.add("f", "fasta", "Reference Fasta", "string");
+    cmd.add("e", "exons", "Exon Regions Filename", "string");
+    cmd.add("u", "ufrag", "Fragment Length Mean", "float");
+    cmd.add("s", "sfrag", "Fragment Length Standard Deviation", "float");
+    cmd.add("n", "minread", "Minimum Read Length", "integer");
+    cmd.add("x", "maxread", "Maximum Read Length", "integer");
+    cmd.add("r", "regions", "Fusion Regions Filename", "string");
+    cmd.add("i", "improper", "Improper Alignments Sam Filename", "string");
+    cmd.add("1", "seq1", "End 1 Sequences", "string");
+    cmd.add("2", "seq2", "End 2 Sequences", "string");
+    cmd.add("a", "align", "Split Alignments Filename", "string");
+    cmd.parse(argc, argv);
+
+    const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
+    std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
+                                                         cmd.integer("minread"), cmd.integer("maxread"), regions);
+
+    // SplitReadRealigner::AddTask (tools/SplitAlignment.cpp:236-251): 2000 bp bins over the mate regions
+    BinnedLocations binned(2000);
+    for (const auto& kv : tasks)
+        for (int ce = 0; ce <= 1; ++ce)
+            for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id(kv.first, ce), loc);
+
+    std::unordered_map<int, std::string> reads;
+    if (!AddReads(cmd.str("seq1"), reads) || !AddReads(cmd.str("seq2"), reads)) {
+        std::cout << "Error: unable to read sequences" << std::endl;
+        return 1;
+    }
+
+    // the GPU batch: one dsa_fusion per task that gets at least one candidate
+    std::vector<uint8_t> ref_bytes, read_bytes;
+    std::vector<dsa_fusion> fusions;
+    std::vector<dsa_pair> cand;                    // candidates in the reference's visiting order
+    std::unordered_map<int, int> fusion_index;     // fusion id -> index into fusions
+    std::unordered_map<int, std::set<std::pair<int, int>>> candidate_unique;   // :268, :292
+
+    SamAlignmentStream sam(cmd.str("improper"));
+    RawAlignment mate;
+    while (sam.GetNextAlignment(mate)) {
+        std::set<int> overlapping;                 // ascending signed order: end-1 ids (negative) first
+        binned.Overlapping(mate.reference, mate.strand, mate.region, overlapping);
+        for (int cid : overlapping) {
+            const int cluster_end = cid < 0 ? 1 : 0;
+            const int fusion_id = cid & 0x7FFFFFFF;
+            const int frag = lexical_int_or_die(mate.fragment, "as fragment name");
+            const int read_end = (mate.readEnd == 0) ? 1 : 0;
+            const int revcomp = (cluster_end == 0) ? 1 : 0;
+            const int rid = pack_id(frag, read_end);
+            if (!candidate_unique[fusion_id].insert(std::make_pair(rid, revcomp)).second) continue;
+            std::string seq = reads[rid];          // operator[]: a missing read aligns as the empty string (:286)
+            if (revcomp) ReverseComplement(seq);
+            auto fi = fusion_index.find(fusion_id);
+            if (fi == fusion_index.end()) {
+                const SplitAlignmentTask& t = tasks[fusion_id];
+                dsa_fusion f;
+                f.fusion_id = fusion_id;
+                f.ref0_off = (int32_t)ref_bytes.size();
+                f.ref0_len = (int32_t)t.mSplitAlignSeq[0].size();
+                ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
+                f.ref1_off = (int32_t)ref_bytes.size();
+                f.ref1_len = (int32_t)t.mSplitAlignSeq[1].size();
+                ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
+                fi = fusion_index.emplace(fusion_id, (int)fusions.size()).first;
+                fusions.push_back(f);
+            }
+            dsa_pair p{};
+            p.fusion_idx = fi->second;
+            p.read_off = (int32_t)read_bytes.size();
+            p.read_len = (int32_t)seq.size();
+            p.frag = frag;
+            p.read_end = (uint8_t)read_end;
+            p.revcomp = (uint8_t)revcomp;
+            read_bytes.insert(read_bytes.end(), seq.begin(), seq.end());
+            if (read_bytes.size() > 0x7FFFFFF0u) die("Error: more than 2 GiB of candidate read sequence in one run");
+            cand.push_back(p);
+        }
+    }
+
+    std::ofstream out(cmd.str("align").c_str());
+    if (!out.good()) die("Error: Unable to open " + cmd.str("align"));
+
+    if (!cand.empty()) {
+        // group by fusion for the kernels (stable: keeps the visiting order inside a fusion)
+        std::vector<int64_t> order(cand.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return cand[a].fusion_idx < cand[b].fusion_idx; });
+        std::vector<dsa_pair> pairs(cand.size());
+        for (size_t k = 0; k < order.size(); ++k) pairs[k] = cand[order[k]];
+
+        dsa_ctx* ctx = nullptr;
+        const char* dev = std::getenv("DEFUSE_GPU");
+        if (dsa_create(&ctx, dev ? std::atoi(dev) : 0) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
+        std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
+        int64_t n = 0;
+        int rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
+                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
+                                 (int64_t)recs.size(), &n);
+        if (rc == DSA_E_CAPACITY) {
+            recs.resize((size_t)n);
+            rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
+                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
+                                 recs.data(), (int64_t)recs.size(), &n);
+        }
+        if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
+        dsa_destroy(ctx);
+
+        // back to the visiting order: records arrive grouped by batch pair index
+        std::vector<int64_t> first(pairs.size() + 1, 0);
+        for (int64_t k = 0; k < n; ++k) ++first[recs[k].pair_idx + 1];
+        for (size_t k = 0; k < pairs.size(); ++k) first[k + 1] += first[k];
+        std::vector<int64_t> slot_of(cand.size());
+        for (size_t k = 0; k < order.size(); ++k) slot_of[order[k]] = (int64_t)k;
+        std::string buf;
+        for (size_t c = 0; c < cand.size(); ++c) {
+            const int64_t k = slot_of[c];
+            for (int64_t r = first[k]; r < first[k + 1]; ++r) {
+                const dsa_record& a = recs[r];
+                // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
+                buf += std::to_string(a.fusion_id) + "\t" + std::to_string(a.frag) + "\t" + std::to_string(a.read_end) + "\t" +
+                       std::to_string(a.revcomp) + "\t" + std::to_string(a.ref_first) + "\t" + std::to_string(a.ref_second) + "\t" +
+                       std::to_string(a.read_first) + "\t" + std::to_string(a.read_second) + "\t" + std::to_string(a.score) + "\t\n";
+            }
+            if (buf.size() > (1u << 20)) { out << buf; buf.clear(); }
+        }
+        out << buf;
+    }
+    out.close();
+    if (!out.good()) die("Error: failed writing " + cmd.str("align"));
+    return 0;
+}
