@@ -56,6 +56,9 @@ constexpr int NCOMBO = NCLS * NCLS;
 constexpr int TROW = W + 4;           // table row stride in dwords: table row t starts at bank quad t mod 16, so
                                       // the 16 rows of the A/C/G/T x A/C/G/T combinations never collide under
                                       // ds_read_b128 (rows 16..24, the combinations with an N, are rare)
+#ifndef FILL_PF
+#define FILL_PF 2               // LDS table reads kept in flight ahead of the column being updated
+#endif
 constexpr int GMAX = 4;               // max distinct fusions per workgroup on the fast path
 constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
 // Stored values are V + 1024 per int16 field: always a positive normal fp16 bit pattern.
@@ -328,10 +331,43 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
     const int ngq = (lq >> 2) + 1;
     uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
     uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
+    const uint4* src = reinterpret_cast<const uint4*>(cmax + (int64_t)w * g.nch * g.lq1 * WAVE) + lane;
+    const int64_t cstride = (int64_t)(g.lq1 >> 2) * WAVE;       // uint4 elements between two tiles
+    constexpr int NC = 8;
+    if (nch_wave <= NC) {
+        // all tiles of a row group in registers: one round of independent loads, then max and masks
+        for (int gq = 0; gq < ngq; ++gq) {
+            uint4 v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                v[c] = c < nch_wave ? src[c * cstride + (int64_t)gq * WAVE] : make_uint4(0, 0, 0, 0);
+            uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < nch_wave) {
+                    m.x = max2(m.x, v[c].x);
+                    m.y = max2(m.y, v[c].y);
+                    m.z = max2(m.z, v[c].z);
+                    m.w = max2(m.w, v[c].w);
+                }
+            uint4 t = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < nch_wave) {
+                    t.x |= eq_bits(v[c].x, m.x, c);
+                    t.y |= eq_bits(v[c].y, m.y, c);
+                    t.z |= eq_bits(v[c].z, m.z, c);
+                    t.w |= eq_bits(v[c].w, m.w, c);
+                }
+            out[(int64_t)gq * WAVE] = m;
+            tout[(int64_t)gq * WAVE] = t;
+        }
+        return;
+    }
     for (int gq = 0; gq < ngq; ++gq) {
         uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         for (int c = 0; c < nch_wave; ++c) {
-            const uint4 v = (reinterpret_cast<const uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane)[(int64_t)gq * WAVE];
+            const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
             m.x = max2(m.x, v.x);
             m.y = max2(m.y, v.y);
             m.z = max2(m.z, v.z);
@@ -341,7 +377,7 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
         if (nch_wave <= TMASK_TILES) {
             uint4 t = make_uint4(0, 0, 0, 0);
             for (int c = 0; c < nch_wave; ++c) {
-                const uint4 v = (reinterpret_cast<const uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane)[(int64_t)gq * WAVE];
+                const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
                 t.x |= eq_bits(v.x, m.x, c);
                 t.y |= eq_bits(v.y, m.y, c);
                 t.z |= eq_bits(v.z, m.z, c);
@@ -479,13 +515,23 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                     // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
                     // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
                     const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
-                    uint4 v = trow[0];
-                    uint32_t a = bprev + v.x;
+                    uint4 vq[FILL_PF + 1];                  // table reads in flight
+#ifdef DSA_ABLATE_LDS
+#define TROW_LD(k) make_uint4(rcv[sidx] + (k), 0x00060006u, 0x00030003u, 0x00060006u)
+#else
+#define TROW_LD(k) trow[k]
+#endif
+#pragma unroll
+                    for (int k = 0; k <= FILL_PF; ++k) vq[k] = TROW_LD(k);
+                    uint32_t a = bprev + vq[0].x;
                     uint32_t up = bcur - TWO2;
 #pragma unroll
                     for (int q = 0; q < W / 4; ++q) {
-                        uint4 vn = v;
-                        if (q + 1 < W / 4) vn = trow[q + 1];
+                        const uint4 v = vq[0];
+#pragma unroll
+                        for (int k = 0; k < FILL_PF; ++k) vq[k] = vq[k + 1];
+                        if (q + 1 + FILL_PF < W / 4) vq[FILL_PF] = TROW_LD(q + 1 + FILL_PF);
+                        const uint4 vn = vq[0];
                         uint32_t an;
                         an = X[4 * q + 0] + v.y;
                         X[4 * q + 0] = max3(a, X[4 * q + 0], up);
@@ -500,21 +546,28 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                         X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
                         a = an;
                         up = X[4 * q + 3];
-                        v = vn;
                     }
                     cmv[sidx] = tile_row_max<false>(X, W, W);
                     bov[sidx] = X[W - 1] - drift2(W - 1);
                 }
                 bprev = bcur;
             }
+#ifdef DSA_ABLATE_STORES
+            if (gq == ngq - 1) {
+#endif
             cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
             bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+#ifdef DSA_ABLATE_STORES
+            }
+#endif
         }
     }
+#ifndef DSA_ABLATE_TAIL
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
         reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
