@@ -37,7 +37,7 @@ def build_lib(force=False):
     return LIB
 
 
-TOOLS = ["dosplitalign"]
+TOOLS = ["dosplitalign", "evalsplitalign"]
 
 
 def build_tools(force=False):

@@ -91,3 +91,48 @@ def test_dosplitalign_matches_oracle(tools, tmp_path, seed):
     assert r.returncode == 0, r.stderr
     assert len(exp.splitlines()) > 20
     assert out.read_text() == exp
+
+
+EVAL = os.path.join(ROOT, "bin", "evalsplitalign")
+
+
+def eval_args(case, align, out):
+    return ["-f", case["fasta"], "-e", case["exons"], "-u", str(case["ufrag"]), "-s", str(case["sfrag"]),
+            "-n", str(case["minread"]), "-x", str(case["maxread"]), "-r", case["regions"], "-a", align,
+            "-q", out + ".seq", "-b", out + ".break", "-p", out + ".predalign"]
+
+
+def test_evalsplitalign_smoke_vector(tools, tmp_path):
+    """evalsplitalign on the reference's known-answer vector."""
+    args = smoke_args(tmp_path, "unused")
+    case = dict(fasta=args[1], exons=args[3], ufrag=300, sfrag=30, minread=50, maxread=50, regions=args[13])
+    align = tmp_path / "split.align"
+    align.write_text("".join("\t".join(l.split()) + "\t\n" for l in open(os.path.join(SMOKE, "expected.split.align.txt"))))
+    out = str(tmp_path / "pred")
+    r = subprocess.run([EVAL] + eval_args(case, str(align), out), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + ".break").read() == open(os.path.join(SMOKE, "expected.break.txt")).read()
+    assert len(open(out + ".predalign").read().splitlines()) == 14
+    f = open(out + ".seq").read().rstrip("\n").split("\t")
+    assert f[0] == "0" and f[2:] == ["0", "14", "0.511905", "0.5"]
+
+
+@pytest.mark.parametrize("seed", [5, 8])
+def test_evalsplitalign_matches_oracle(tools, tmp_path, seed):
+    from oracle import dosplitalign_oracle as ora
+    case = pipeline_case.build(str(tmp_path / "case"), seed=seed)
+    txt = ora.dosplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                           case["regions"], case["improper"], case["seq1"], case["seq2"])
+    # the pipeline sorts by fusion id between the two tools (scripts/defuse_run.pl:528)
+    lines = sorted(txt.splitlines(True), key=lambda l: int(l.split("\t")[0]))
+    align = tmp_path / "sorted.align"
+    align.write_text("".join(lines))
+    exp = ora.evalsplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                             case["regions"], str(align))
+    out = str(tmp_path / "pred")
+    r = subprocess.run([EVAL] + eval_args(case, str(align), out), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out + ".seq").read() == exp[0]
+    assert open(out + ".break").read() == exp[1]
+    assert open(out + ".predalign").read() == exp[2]
+    assert len(exp[1].splitlines()) >= 6
