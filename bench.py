@@ -25,6 +25,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(args):
+    """HBM bytes per fill launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 correction applied) — only if they were taken on this very workload."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None, None
+    w = d.get("workload", {})
+    if (w.get("fusions"), w.get("reads"), w.get("lq"), w.get("lr")) != (args.fusions, args.reads, args.lq, args.lr):
+        return None, None
+    return d["hbm_bytes_per_launch"], "profiles/r01/pmc_traffic.json"
+
+
 def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
     """Times the CPU oracle (a literal port of the reference's algorithm, oracle/dsa_oracle.c) on a
     bounded sample of the same workload, single thread."""
@@ -112,6 +126,7 @@ def main():
         aligns_per_launch = len(pairs) / max(1, t.fill_launches)
         achieved = bytes_per_align * aligns_per_launch / (launch_ms * 1e-3) / 1e9
         cells = synth.cells_per_align(args.lq, args.lr)
+        traffic, traffic_src = measured_traffic(args)
         out = {
             "metric": "split-read DP aligns/sec", "value": total_aligns / elapsed, "unit": "aligns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -122,10 +137,13 @@ def main():
                        "aligns_per_step_per_gpu": len(pairs), "cells_per_align": cells,
                        "records_per_align": round(rec_per_align, 4), "parallelism": "fusion-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_fill", "kernel_ms": launch_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_fill_fast", "kernel_ms": launch_ms,
                          "algorithmic_bytes_per_align": round(bytes_per_align, 2),
-                         "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9},
+                         "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
+                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)); "
+                                 "traffic >> algorithmic bytes because tile checkpoints and tile maxima "
+                                 "(needed for exact tie enumeration) stream through HBM, see DESIGN.md 5"},
             "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)) * max(1, t.fill_launches),
                          "finish": float(np.mean(finish_ms))},
             "replay_tiles_per_align": round(t.n_replay_tasks / len(pairs), 4),
