@@ -31,14 +31,14 @@ def _run(cmd):
 
 def build_lib(force=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h")]
+           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h")]
     if force or _newer(LIB, srcs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip")])
+              "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip")])
     return LIB
 
 
-TOOLS = ["dosplitalign", "evalsplitalign", "setcover"]
+TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs"]
 
 
 def build_tools(force=False):
@@ -51,7 +51,7 @@ def build_tools(force=False):
         src = os.path.join(ROOT, "tools_src", t + ".cpp")
         out = os.path.join(bindir, t)
         deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
-                os.path.join(ROOT, "include", "defuse_sc.h"), lib]
+                os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"), lib]
         if force or _newer(out, deps):
             _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out, src, lib,
                   "-Wl,-rpath,$ORIGIN/../defuse_amd"])

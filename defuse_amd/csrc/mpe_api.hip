@@ -1,0 +1,571 @@
+// mpe_api.hip — mate-pair EM clustering on gfx950 (include/defuse_mpe.h), replacing
+// MatePairEM::DoClustering (tools/MatePairEM.cpp:540-636) and everything it calls:
+//   MaxLikelihood :192-325, LogLikelihood :96-137, UpdateResponsibilities :139-181,
+//   UpdateMixWeights :183-190, SelectKKZ :327-386, ExpectationMaximization :388-494,
+//   kmns / optra / qtran (AS 136, tools/asa136.C).
+//
+// FP64 throughout, no contraction into FMA, and every sum is taken in the reference's serial order
+// (MaxLikelihood compares two prefix sums for exact equality, so a tree reduction would change
+// results).  One problem (bin pair) per lane: the problems are independent and there are thousands
+// of them per chromosome pair; a problem's working set lives in a per-problem slice of one global
+// workspace.  Round-1 mapping: correctness first — moving the O(N*K) loops of big problems onto the
+// lanes of a wave is the next step.
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/defuse_mpe.h"
+
+namespace {
+
+std::string g_mpe_err;
+
+#define MPE_HIP(call)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char b_[256];                                                                         \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g_mpe_err = b_;                                                                       \
+            return -2;                                                                            \
+        }                                                                                         \
+    } while (0)
+
+constexpr double R8_HUGE = 1.0e30;          // tools/asa136.C r8_huge
+constexpr double DBL_MAX_ = 1.7976931348623157e308;
+constexpr double LAMBDA = 0.1, TOLERANCE = 0.001;   // tools/MatePairEM.cpp:55-56
+constexpr int KMEANS_ITER = 1000;
+
+// per-problem workspace, carved out of one global allocation: doubles then ints
+struct Work {
+    int N;
+    const double *X, *Y, *U;
+    const int *ToXO, *ToYO;
+    double *XO, *YO;
+    double *R, *RXO, *RYO, *EX;     // [K][N]
+    double *SX, *SY;                // [N]
+    double *CX, *CY, *CS;           // [4N+4]
+    double *ka, *kd, *dist;         // kmns: a [2N], d [N]; KKZ: DistMin [N]
+    int *ic1, *ic2;                 // [N]
+    double W[MPE_KMAX], A[MPE_KMAX], B[MPE_KMAX];
+    double sd;
+    long long iters;
+    int fail;
+};
+
+__host__ __device__ inline size_t work_doubles(int n) { return (size_t)n * (2 + 4 * MPE_KMAX + 2 + 12 + 4) + 16; }
+__host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
+
+__device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
+{
+    double s = 0.0;
+    for (int j = 1; j <= 2; ++j) {
+        const double df = a[i - 1 + (j - 1) * m] - c[l - 1 + (j - 1) * k];
+        s = s + df * df;
+    }
+    return s;
+}
+
+__device__ void transfer(const double* a, int m, double* c, int k, int* nc, double* an1, double* an2, int* ic1, int* ic2, int i,
+                         int l1, int l2)
+{
+    const double al1 = (double)nc[l1 - 1], alw = al1 - 1.0, al2 = (double)nc[l2 - 1], alt = al2 + 1.0;
+    for (int j = 1; j <= 2; ++j) {
+        c[l1 - 1 + (j - 1) * k] = (c[l1 - 1 + (j - 1) * k] * al1 - a[i - 1 + (j - 1) * m]) / alw;
+        c[l2 - 1 + (j - 1) * k] = (c[l2 - 1 + (j - 1) * k] * al2 + a[i - 1 + (j - 1) * m]) / alt;
+    }
+    nc[l1 - 1] -= 1;
+    nc[l2 - 1] += 1;
+    an2[l1 - 1] = alw / al1;
+    an1[l1 - 1] = 1.0 < alw ? alw / (alw - 1.0) : R8_HUGE;
+    an1[l2 - 1] = alt / al2;
+    an2[l2 - 1] = alt / (alt + 1.0);
+    ic1[i - 1] = l2;
+    ic2[i - 1] = l1;
+}
+
+// AS 136 with n = 2 (tools/asa136.C:13-336 kmns, :339-566 optra, :569-758 qtran); returns ifault
+__device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2, double* d, int iter)
+{
+    if (k <= 1 || m <= k) return 3;
+    int nc[MPE_KMAX], ncp[MPE_KMAX], itran[MPE_KMAX], live[MPE_KMAX];
+    double an1[MPE_KMAX], an2[MPE_KMAX];
+    for (int i = 1; i <= m; ++i) {
+        ic1[i - 1] = 1;
+        ic2[i - 1] = 2;
+        double dt[2];
+        for (int il = 1; il <= 2; ++il) dt[il - 1] = dist2(a, m, c, k, i, il);
+        if (dt[1] < dt[0]) {
+            ic1[i - 1] = 2;
+            ic2[i - 1] = 1;
+            const double t = dt[0];
+            dt[0] = dt[1];
+            dt[1] = t;
+        }
+        for (int l = 3; l <= k; ++l) {
+            const double db = dist2(a, m, c, k, i, l);
+            if (db < dt[1]) {
+                if (dt[0] <= db) {
+                    dt[1] = db;
+                    ic2[i - 1] = l;
+                } else {
+                    dt[1] = dt[0];
+                    ic2[i - 1] = ic1[i - 1];
+                    dt[0] = db;
+                    ic1[i - 1] = l;
+                }
+            }
+        }
+    }
+    for (int l = 1; l <= k; ++l) {
+        nc[l - 1] = 0;
+        for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = 0.0;
+    }
+    for (int i = 1; i <= m; ++i) {
+        const int l = ic1[i - 1];
+        nc[l - 1] += 1;
+        for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = c[l - 1 + (j - 1) * k] + a[i - 1 + (j - 1) * m];
+    }
+    for (int l = 1; l <= k; ++l)
+        if (nc[l - 1] == 0) return 1;
+    for (int l = 1; l <= k; ++l) {
+        const double aa = (double)nc[l - 1];
+        for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = c[l - 1 + (j - 1) * k] / aa;
+        an2[l - 1] = aa / (aa + 1.0);
+        an1[l - 1] = 1.0 < aa ? aa / (aa - 1.0) : R8_HUGE;
+        itran[l - 1] = 1;
+        ncp[l - 1] = -1;
+    }
+    int indx = 0, ifault = 2;
+    for (int ij = 1; ij <= iter; ++ij) {
+        // ---- optra
+        {
+            for (int l = 1; l <= k; ++l)
+                if (itran[l - 1] == 1) live[l - 1] = m + 1;
+            bool early = false;
+            for (int i = 1; i <= m; ++i) {
+                indx += 1;
+                const int l1 = ic1[i - 1];
+                int l2 = ic2[i - 1];
+                const int ll = l2;
+                if (1 < nc[l1 - 1]) {
+                    if (ncp[l1 - 1] != 0) d[i - 1] = dist2(a, m, c, k, i, l1) * an1[l1 - 1];
+                    double r2 = dist2(a, m, c, k, i, l2) * an2[l2 - 1];
+                    for (int l = 1; l <= k; ++l) {
+                        if ((i < live[l1 - 1] || i < live[l2 - 1]) && l != l1 && l != ll) {
+                            const double rr = r2 / an2[l - 1];
+                            const double dc = dist2(a, m, c, k, i, l);
+                            if (dc < rr) {
+                                r2 = dc * an2[l - 1];
+                                l2 = l;
+                            }
+                        }
+                    }
+                    if (d[i - 1] <= r2) {
+                        ic2[i - 1] = l2;
+                    } else {
+                        indx = 0;
+                        live[l1 - 1] = m + i;
+                        live[l2 - 1] = m + i;
+                        ncp[l1 - 1] = i;
+                        ncp[l2 - 1] = i;
+                        transfer(a, m, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                    }
+                }
+                if (indx == m) { early = true; break; }
+            }
+            if (!early)
+                for (int l = 1; l <= k; ++l) {
+                    itran[l - 1] = 0;
+                    live[l - 1] = live[l - 1] - m;
+                }
+        }
+        if (indx == m) { ifault = 0; break; }
+        // ---- qtran
+        {
+            int icoun = 0, istep = 0;
+            bool done = false;
+            while (!done) {
+                for (int i = 1; i <= m; ++i) {
+                    icoun += 1;
+                    istep += 1;
+                    const int l1 = ic1[i - 1], l2 = ic2[i - 1];
+                    if (1 < nc[l1 - 1]) {
+                        if (istep <= ncp[l1 - 1]) d[i - 1] = dist2(a, m, c, k, i, l1) * an1[l1 - 1];
+                        if (istep < ncp[l1 - 1] || istep < ncp[l2 - 1]) {
+                            const double r2 = d[i - 1] / an2[l2 - 1];
+                            const double dd = dist2(a, m, c, k, i, l2);
+                            if (dd < r2) {
+                                icoun = 0;
+                                indx = 0;
+                                itran[l1 - 1] = 1;
+                                itran[l2 - 1] = 1;
+                                ncp[l1 - 1] = istep + m;
+                                ncp[l2 - 1] = istep + m;
+                                transfer(a, m, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                            }
+                        }
+                    }
+                    if (icoun == m) { done = true; break; }
+                }
+            }
+        }
+        if (k == 2) { ifault = 0; break; }
+        for (int l = 1; l <= k; ++l) ncp[l - 1] = 0;
+    }
+    // the final recomputation of centres and wss (asa136.C:262-300) does not change ic1: omitted
+    return ifault;
+}
+
+__device__ void exponents(Work& w, int K)
+{
+    for (int i = 0; i < w.N; ++i)
+        for (int j = 0; j < K; ++j) {
+            const double t = (w.A[j] + w.B[j] - w.X[i] - w.Y[i] - w.U[i]) / w.sd;
+            w.EX[(size_t)j * w.N + i] = -0.5 * (t * t) - LAMBDA * fmax(0.0, w.X[i] - w.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - w.B[j]);
+        }
+}
+
+__device__ double log_likelihood(Work& w, int K)   // tools/MatePairEM.cpp:96-137
+{
+    exponents(w, K);
+    double LL = 0.0;
+    for (int i = 0; i < w.N; ++i) {
+        double maxexp = w.EX[i];
+        for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, w.EX[(size_t)j * w.N + i]);
+        double sum = 0.0;
+        for (int j = 0; j < K; ++j) sum += w.W[j] * exp(w.EX[(size_t)j * w.N + i] - maxexp);
+        if (sum == 0.0) return -DBL_MAX_;
+        LL = LL + log(sum) + maxexp;
+    }
+    return LL;
+}
+
+__device__ bool update_responsibilities(Work& w, int K)   // :139-181
+{
+    exponents(w, K);
+    for (int i = 0; i < w.N; ++i) {
+        const int ixo = w.ToXO[i], iyo = w.ToYO[i];
+        double maxexp = w.EX[i];
+        for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, w.EX[(size_t)j * w.N + i]);
+        double norm = 0.0;
+        for (int j = 0; j < K; ++j) norm += w.W[j] * exp(w.EX[(size_t)j * w.N + i] - maxexp);
+        if (norm == 0.0) return false;                     // DebugCheck(norm != 0.0)
+        for (int j = 0; j < K; ++j) {
+            const double r = w.W[j] * exp(w.EX[(size_t)j * w.N + i] - maxexp) / norm;
+            w.R[(size_t)j * w.N + i] = r;
+            w.RXO[(size_t)j * w.N + ixo] = r;
+            w.RYO[(size_t)j * w.N + iyo] = r;
+        }
+    }
+    return true;
+}
+
+// :192-325; returns 0 = no update (NK == 0), 1 = ok, -1 = the reference would read past the end
+__device__ int max_likelihood(Work& w, const double* R, const double* RXO, const double* RYO, double& a, double& b)
+{
+    const int N = w.N;
+    double acc = 0.0;
+    for (int i = 0; i < N; ++i) { acc = i == 0 ? RXO[0] : acc + RXO[i]; w.SX[i] = acc; }
+    for (int i = 0; i < N; ++i) { acc = i == 0 ? RYO[0] : acc + RYO[i]; w.SY[i] = acc; }
+    int i = 0, j = 0, n = 0;
+    auto push = [&](double cx, double cy, double cs) { w.CX[n] = cx; w.CY[n] = cy; w.CS[n] = cs; ++n; };
+    push(w.XO[0], w.YO[0], 0.0);
+    while (i < N && j < N) {
+        if (i + 1 < N && w.XO[i] == w.XO[i + 1]) { ++i; continue; }
+        if (j + 1 < N && w.YO[j] == w.YO[j + 1]) { ++j; continue; }
+        if (w.SX[i] == w.SY[j]) {
+            push(w.XO[i], w.YO[j], w.SX[i]);
+            if (i + 1 < N && j + 1 < N) push(w.XO[i + 1], w.YO[j + 1], w.SX[i]);
+            ++i;
+            ++j;
+        } else if (w.SX[i] < w.SY[j]) {
+            push(w.XO[i], w.YO[j], w.SX[i]);
+            if (i + 1 < N) push(w.XO[i + 1], w.YO[j], w.SX[i]);
+            ++i;
+        } else {
+            push(w.XO[i], w.YO[j], w.SY[j]);
+            if (j + 1 < N) push(w.XO[i], w.YO[j + 1], w.SY[j]);
+            ++j;
+        }
+    }
+    double NK = 0.0;
+    for (int t = 0; t < N; ++t) NK += R[t];
+    if (NK == 0.0) return 0;
+    double RXYU = 0.0;
+    for (int t = 0; t < N; ++t) RXYU += R[t] * (w.X[t] + w.Y[t] + w.U[t]);
+    const double var = w.sd * w.sd;
+    int mi = 0;
+    while (mi < n) {
+        if ((RXYU - NK * (w.CX[mi] + w.CY[mi])) / var + LAMBDA * w.CS[mi] > 0) break;
+        ++mi;
+    }
+    if (mi >= n) return -1;
+    const double aplusb = (RXYU + var * LAMBDA * w.CS[mi]) / NK;
+    if (mi == 0) {
+        const double min_a = w.CX[0], max_a = aplusb - w.CY[0];
+        a = 0.5 * (min_a + max_a);
+        b = aplusb - a;
+    } else if (w.CS[mi] != w.CS[mi - 1]) {
+        a = w.CX[mi];
+        b = w.CY[mi];
+    } else {
+        const double min_a = fmax(w.CX[mi], aplusb - w.CY[mi - 1]);
+        const double max_a = fmin(w.CX[mi - 1], aplusb - w.CY[mi]);
+        a = 0.5 * (min_a + max_a);
+        b = aplusb - a;
+    }
+    return 1;
+}
+
+__device__ bool select_kkz(Work& w, int k, double* A, double* B)   // :327-386
+{
+    const int N = w.N;
+    double l2max = w.X[0] * w.Y[0];
+    int imax = 0;
+    for (int i = 1; i < N; ++i) {
+        const double l2 = w.X[i] * w.Y[i];
+        if (l2 > l2max) { imax = i; l2max = l2; }
+    }
+    int na = 1;
+    A[0] = w.X[imax];
+    B[0] = w.Y[imax];
+    while (na < k) {
+        for (int i = 0; i < N; ++i) {
+            double md = (w.X[i] - A[0]) * (w.X[i] - A[0]) + (w.Y[i] - B[0]) * (w.Y[i] - B[0]);
+            for (int j = 1; j < na; ++j) {
+                const double dj = (w.X[i] - A[j]) * (w.X[i] - A[j]) + (w.Y[i] - B[j]) * (w.Y[i] - B[j]);
+                md = fmin(md, dj);
+            }
+            w.dist[i] = md;
+        }
+        double dmax = w.dist[0];
+        int idx = 0;
+        for (int i = 0; i < N; ++i)
+            if (w.dist[i] > dmax) { dmax = w.dist[i]; idx = i; }
+        if (dmax == 0.0) return false;
+        A[na] = w.X[idx];
+        B[na] = w.Y[idx];
+        ++na;
+    }
+    return true;
+}
+
+// :388-494; returns true and sets ll on success
+__device__ bool expectation_maximization(Work& w, int K, double& ll)
+{
+    const int N = w.N;
+    if (K == 1 || K == N) {
+        const double v = 1.0 / K;
+        for (int j = 0; j < K; ++j)
+            for (int i = 0; i < N; ++i) {
+                w.R[(size_t)j * N + i] = v;
+                w.RXO[(size_t)j * N + i] = v;
+                w.RYO[(size_t)j * N + i] = v;
+            }
+    } else {
+        double px[MPE_KMAX], py[MPE_KMAX], c[2 * MPE_KMAX];
+        if (!select_kkz(w, K, px, py)) return false;
+        for (int i = 0; i < N; ++i) {          // both inserts are at begin(): a = [Y..., X...], c = [py..., px...]
+            w.ka[i] = w.Y[i];
+            w.ka[N + i] = w.X[i];
+        }
+        for (int j = 0; j < K; ++j) {
+            c[j] = py[j];
+            c[K + j] = px[j];
+        }
+        const int ifault = kmns(w.ka, N, c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER);
+        if (ifault == 1 || ifault == 3) { w.fail = 1; return false; }     // DebugCheck(ifault != 1 / != 3)
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < K; ++j) {
+                const double v = (j == w.ic1[i] - 1) ? 1.0 : 0.0;
+                w.R[(size_t)j * N + i] = v;
+                w.RXO[(size_t)j * N + w.ToXO[i]] = v;
+                w.RYO[(size_t)j * N + w.ToYO[i]] = v;
+            }
+    }
+    double last = 0.0;
+    bool valid = false;
+    for (;;) {
+        for (int j = 0; j < K; ++j) {
+            double a, b;
+            const int rc = max_likelihood(w, w.R + (size_t)j * N, w.RXO + (size_t)j * N, w.RYO + (size_t)j * N, a, b);
+            if (rc < 0) { w.fail = 1; return false; }
+            if (rc > 0) { w.A[j] = a; w.B[j] = b; }
+        }
+        for (int j = 0; j < K; ++j) {              // UpdateMixWeights :183-190
+            double nk = 0.0;
+            for (int i = 0; i < N; ++i) nk += w.R[(size_t)j * N + i];
+            w.W[j] = nk / N;
+        }
+        const double like = log_likelihood(w, K);
+        w.iters += 1;
+        if (valid && fabs(like - last) < TOLERANCE) break;
+        if (valid && like == -DBL_MAX_) return false;
+        if (valid && !(like / last < 1.0000001)) { w.fail = 1; return false; }   // DebugCheck
+        last = like;
+        valid = true;
+        if (!update_responsibilities(w, K)) { w.fail = 1; return false; }
+    }
+    ll = last;
+    return true;
+}
+
+__global__ void k_mpe(mpe_params prm, const int64_t* __restrict__ prob_off, int n_problems, const double* __restrict__ x,
+                      const double* __restrict__ y, const double* __restrict__ u, const int32_t* __restrict__ to_xo,
+                      const int32_t* __restrict__ to_yo, const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off,
+                      double* __restrict__ wdoubles, int* __restrict__ wints, int32_t* __restrict__ n_clusters,
+                      uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_problems) return;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    n_clusters[p] = 0;
+    status[p] = 0;
+    for (int i = 0; i < N; ++i) member[b + i] = 0;
+    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
+    Work w;
+    w.N = N;
+    w.X = x + b; w.Y = y + b; w.U = u + b;
+    w.ToXO = to_xo + b; w.ToYO = to_yo + b;
+    double* d = wdoubles + wd_off[p];
+    w.XO = d; d += N;
+    w.YO = d; d += N;
+    w.R = d; d += (size_t)MPE_KMAX * N;
+    w.RXO = d; d += (size_t)MPE_KMAX * N;
+    w.RYO = d; d += (size_t)MPE_KMAX * N;
+    w.EX = d; d += (size_t)MPE_KMAX * N;
+    w.SX = d; d += N;
+    w.SY = d; d += N;
+    w.CX = d; d += 4 * (size_t)N + 4;
+    w.CY = d; d += 4 * (size_t)N + 4;
+    w.CS = d; d += 4 * (size_t)N + 4;
+    w.ka = d; d += 2 * (size_t)N;
+    w.kd = d; d += N;
+    w.dist = d; d += N;
+    int* ip = wints + wi_off[p];
+    w.ic1 = ip;
+    w.ic2 = ip + N;
+    w.sd = prm.fragment_stddev;
+    w.iters = 0;
+    w.fail = 0;
+    for (int j = 0; j < MPE_KMAX; ++j) w.W[j] = w.A[j] = w.B[j] = 0.0;
+    for (int i = 0; i < N; ++i) {
+        w.XO[w.ToXO[i]] = w.X[i];
+        w.YO[w.ToYO[i]] = w.Y[i];
+    }
+    double min_bic = 0.0;
+    bool have = false;
+    int k_min = 1;
+    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
+    for (int K = 1; K <= kmax && !w.fail; ++K) {
+        double ll;
+        if (!expectation_maximization(w, K, ll)) continue;
+        const double bic = -2.0 * ll + K * 2.0 * log((double)N);
+        if (!have || bic < min_bic) { min_bic = bic; k_min = K; have = true; }
+    }
+    double ll;
+    if (!w.fail && expectation_maximization(w, k_min, ll)) {
+        const double coeff = 1.0 / (w.sd * sqrt(2 * M_PI));                // normalpdf, tools/Common.cpp:61-69
+        int emitted = 0;
+        for (int j = 0; j < k_min; ++j) {
+            int count = 0;
+            for (int i = 0; i < N; ++i) {
+                const double dist = ((w.A[j] + w.B[j] - w.X[i] - w.Y[i]) - w.U[i]) / w.sd;
+                const double prob = coeff * exp(-0.5 * dist * dist) *
+                                    exp(-LAMBDA * fmax(0.0, w.X[i] - w.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - w.B[j]));
+                const bool in = prob > prm.min_probability;
+                w.ic1[i] = in ? 1 : 0;
+                count += in ? 1 : 0;
+            }
+            if ((double)count >= (double)prm.min_cluster_size) {
+                for (int i = 0; i < N; ++i)
+                    if (w.ic1[i]) member[b + i] |= (uint16_t)(1u << emitted);
+                ++emitted;
+            }
+        }
+        n_clusters[p] = emitted;
+    }
+    status[p] = w.fail;
+    atomicAdd(iters, (unsigned long long)w.iters);
+}
+
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)); }
+};
+
+}  // namespace
+
+extern "C" const char* mpe_last_error(void) { return g_mpe_err.c_str(); }
+
+extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int64_t* prob_off, int32_t n_problems,
+                                 const double* x, const double* y, const double* u, const int32_t* to_xo,
+                                 const int32_t* to_yo, int32_t* n_clusters, uint16_t* member, int32_t* status,
+                                 mpe_timing* timing)
+{
+    mpe_timing t{};
+    if (!params || n_problems < 0 || (n_problems && !prob_off)) { g_mpe_err = "bad arguments"; return -3; }
+    const int64_t n_mp = n_problems ? prob_off[n_problems] : 0;
+    t.n_problems = n_problems;
+    t.n_mate_pairs = n_mp;
+    if (n_problems == 0) { if (timing) *timing = t; return 0; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_mpe_err = "no usable HIP device"; return -2; }
+    MPE_HIP(hipSetDevice(device));
+    std::vector<int64_t> wd(n_problems + 1, 0), wi(n_problems + 1, 0);
+    for (int p = 0; p < n_problems; ++p) {
+        const int64_t n = prob_off[p + 1] - prob_off[p];
+        if (n < 0 || n > 0x7FFFFFF) { g_mpe_err = "problem too large"; return -4; }
+        wd[p + 1] = wd[p] + (int64_t)work_doubles((int)n);
+        wi[p + 1] = wi[p] + (int64_t)work_ints((int)n);
+    }
+    DBuf<int64_t> d_off, d_wd, d_wi;
+    DBuf<double> d_x, d_y, d_u, d_work;
+    DBuf<int32_t> d_txo, d_tyo, d_nc, d_status;
+    DBuf<int> d_iwork;
+    DBuf<uint16_t> d_member;
+    DBuf<unsigned long long> d_iters;
+    MPE_HIP(d_off.alloc(n_problems + 1)); MPE_HIP(d_wd.alloc(n_problems + 1)); MPE_HIP(d_wi.alloc(n_problems + 1));
+    MPE_HIP(d_x.alloc(n_mp)); MPE_HIP(d_y.alloc(n_mp)); MPE_HIP(d_u.alloc(n_mp)); MPE_HIP(d_txo.alloc(n_mp)); MPE_HIP(d_tyo.alloc(n_mp));
+    MPE_HIP(d_work.alloc(wd[n_problems])); MPE_HIP(d_iwork.alloc(wi[n_problems]));
+    MPE_HIP(d_nc.alloc(n_problems)); MPE_HIP(d_status.alloc(n_problems)); MPE_HIP(d_member.alloc(n_mp)); MPE_HIP(d_iters.alloc(1));
+    MPE_HIP(hipMemcpy(d_off.p, prob_off, (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    MPE_HIP(hipMemcpy(d_wd.p, wd.data(), (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    MPE_HIP(hipMemcpy(d_wi.p, wi.data(), (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (n_mp) {
+        MPE_HIP(hipMemcpy(d_x.p, x, n_mp * sizeof(double), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_y.p, y, n_mp * sizeof(double), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_u.p, u, n_mp * sizeof(double), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_txo.p, to_xo, n_mp * sizeof(int32_t), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_tyo.p, to_yo, n_mp * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    MPE_HIP(hipMemset(d_iters.p, 0, sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    MPE_HIP(hipEventCreate(&e0));
+    MPE_HIP(hipEventCreate(&e1));
+    MPE_HIP(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_mpe, dim3((unsigned)((n_problems + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, n_problems, d_x.p, d_y.p,
+                       d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p, d_iters.p);
+    MPE_HIP(hipEventRecord(e1));
+    MPE_HIP(hipDeviceSynchronize());
+    MPE_HIP(hipGetLastError());
+    MPE_HIP(hipMemcpy(n_clusters, d_nc.p, n_problems * sizeof(int32_t), hipMemcpyDeviceToHost));
+    MPE_HIP(hipMemcpy(status, d_status.p, n_problems * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_mp) MPE_HIP(hipMemcpy(member, d_member.p, n_mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    unsigned long long it = 0;
+    MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
+    (void)hipEventElapsedTime(&t.kernel_ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    t.em_iterations = (int64_t)it;
+    for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;
+    if (timing) *timing = t;
+    return 0;
+}

@@ -1,0 +1,86 @@
+"""clustermatepairs: oracle behaviour (CPU) and the drop-in binary against the oracle (GPU)."""
+import os
+import subprocess
+
+import pytest
+
+from tests import cmp_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "bin", "clustermatepairs")
+
+
+def test_oracle_two_loci_shape():
+    """SURVEY.md Appendix A's mini check: two loci (12 + 8 fragments) give two clusters, and cluster 1's
+    end 0 is the chrB+ side because RefBinPacked ids order strand above the reference index."""
+    from oracle import clustermatepairs_oracle as o
+    txt, n = o.clustermatepairs(cmp_cases.two_loci(), 300, 30, 0.95, 5)
+    assert n == 2
+    lines = [l.split("\t") for l in txt.splitlines()]
+    assert {l[0] for l in lines} == {"0", "1"} and len(lines) % 2 == 0 and len(lines) >= 34
+    first_c1 = [l for l in lines if l[0] == "1" and l[1] == "0"][0]
+    assert first_c1[4:6] == ["chrB", "+"]
+    # the read-end column is inverted relative to the input (AlignmentStream.cpp:181), SURVEY a-8
+    assert [l for l in lines if l[0] == "0" and l[1] == "0"][0][3] == "1"
+
+
+def test_oracle_kmns_and_cdf_inverse():
+    from oracle import clustermatepairs_oracle as o
+    assert abs(o.normal_01_cdf_inverse(0.025) + 1.959963984540054) < 1e-12
+    a = [0.0, 0.1, 0.2, 10.0, 10.1, 10.2] + [5.0, 5.1, 4.9, 1.0, 1.1, 0.9]      # column-major, n = 2
+    ic1, nc, wss, ifault = o.kmns(a, 6, 2, [0.0, 10.0, 5.0, 1.0], 2, 100)
+    assert ifault == 0 and ic1 == [1, 1, 1, 2, 2, 2] and nc == [3, 3]
+
+
+def test_oracle_concordant_and_small_clusters_dropped():
+    from oracle import clustermatepairs_oracle as o
+    lines = ["0\t0\tchr1\t+\t1000\t1049\n", "0\t1\tchr1\t-\t1200\t1249\n"] * 1
+    assert o.clustermatepairs(lines, 300, 30, 0.95, 5) == ("", 0)
+    txt, n = o.clustermatepairs(cmp_cases.two_loci(), 300, 30, 0.95, 9)     # the 8-fragment locus is below -m 9
+    assert n == 1
+
+
+def test_cli(built):
+    from defuse_amd import build
+    build.build_tools()
+    r = subprocess.run([TOOL, "-a", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Required arguments missing: clusters, fragmentmean, fragmentstddev, precision, minclustersize" in r.stderr
+    r = subprocess.run([TOOL, "--help"], capture_output=True, text=True)
+    assert "Mate Pair Clustering Tool" in r.stdout
+
+
+def run_tool(lines, tmp_path, m=5, stdin=False):
+    p = tmp_path / "spanning.txt"
+    p.write_text("".join(lines))
+    out = tmp_path / "clusters.txt"
+    args = [TOOL, "-a", "-" if stdin else str(p), "-c", str(out), "-u", "300", "-s", "30", "-p", "0.95", "-m", str(m)]
+    r = subprocess.run(args, capture_output=True, text=True, input="".join(lines) if stdin else None)
+    return r, out.read_text() if out.exists() else None
+
+
+@pytest.mark.gpu
+def test_tool_two_loci(built, tmp_path):
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = cmp_cases.two_loci()
+    r, txt = run_tool(lines, tmp_path, stdin=True)                    # the pipeline pipes `cat files |` into -a -
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert txt == exp
+    assert r.stdout == ("Finding pairs of reference sequences connected by pairs of alignments\nInitializing clusterer\n"
+                        "Creating clusters\nCreated %d clusters\n" % n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_tool_matches_oracle(built, tmp_path, seed):
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = cmp_cases.many_loci(seed)
+    r, txt = run_tool(lines, tmp_path)
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert n >= 8
+    assert txt == exp
