@@ -84,3 +84,22 @@ def test_tool_matches_oracle(built, tmp_path, seed):
     exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
     assert n >= 8
     assert txt == exp
+
+
+@pytest.mark.gpu
+def test_tool_large_bin_pairs(built, tmp_path):
+    """Bigger problems (hundreds of mate pairs per bin pair, several mixtures) and -m 3."""
+    import numpy as np
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    rng = np.random.default_rng(11)
+    lines = []
+    frag = 0
+    for (n, ba, bb) in ((220, 40000, 90000), (150, 40120, 90060), (90, 41000, 90500), (60, 200000, 300000)):
+        lines += cmp_cases.locus_fragments(rng, frag, n, "chr1", "+", ba, "chr2", "-", bb)
+        frag += n
+    r, txt = run_tool(lines, tmp_path, m=3)
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 3)
+    assert n >= 4 and txt == exp
