@@ -225,7 +225,13 @@ int grow_records(dsa_ctx* ctx, size_t need)
 
 int run_slice(dsa_ctx* ctx, const Slice& s)
 {
-    const Geom g = s.g;
+    Geom g = s.g;
+#ifdef DSA_PRUNE_STATS
+    static unsigned long long* d_stats = nullptr;
+    if (!d_stats) (void)hipMalloc((void**)&d_stats, 4 * sizeof(unsigned long long));
+    (void)hipMemset(d_stats, 0, 4 * sizeof(unsigned long long));
+    g.stats = d_stats;
+#endif
     hipStream_t st = ctx->stream;
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
@@ -267,7 +273,8 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     HIPC(hipEventRecord(ctx->ev[1], st));
     // ---- fill: every workgroup is run by exactly one of the two kernels ---------------------------
     hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p, ctx->d_wgs.p,
-                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, g);
+                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_min_score.p, ctx->d_bnd.p, ctx->d_cmax.p,
+                       ctx->d_rmax.p, ctx->d_tmask.p, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p,
                        ctx->d_fusions.p, ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p,
                        ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, g);
@@ -328,6 +335,13 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     }
     if (redo_combine || (size_t)(ctx->n_records + n_rec) > ctx->d_records.cap)
         return fail(ctx, DSA_E_DEVICE, "finish stage did not converge");
+#ifdef DSA_PRUNE_STATS
+    {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(h, g.stats, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[prune] skipped row groups %llu of %llu, sum l_in %llu\n", h[0], h[1], h[2]);
+    }
+#endif
     ctx->n_records += n_rec;
     ctx->timing.pack_ms += elapsed(ctx->ev[0], ctx->ev[1]);
     ctx->timing.fill_ms += elapsed(ctx->ev[1], ctx->ev[2]);

@@ -110,6 +110,9 @@ struct Geom {
     int32_t lrp;           // refcodes stride = nch * W
     int32_t n_fusions;
     int64_t n_pairs;
+#ifdef DSA_PRUNE_STATS
+    unsigned long long* stats;   // diagnostic builds only
+#endif
 };
 
 struct KeptRow {           // one winning read split of a pair that has columns on both sides
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                                                            const uint32_t* __restrict__ wg_generic,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes,
+                                                           const int32_t* __restrict__ min_score_tab,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
                                                            uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask, Geom g)
 {
@@ -453,10 +457,28 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     const WgInfo wgi = wginfo[blockIdx.x];
     WaveInfo wi = {0, 0};
     int f = 0;
+    // Exact pruning: a cell with V(i,j) < 4j - slack, slack = 2*Lq - minScore, can never
+    // feed a row maximum that takes part in a split of score >= minScore (each further row adds at most
+    // 4), and no live cell's value comes from a dead cell.  Once a whole tile row and everything that
+    // can still enter from the left are dead, the rest of the tile is dead: the sweep stops there and
+    // stores "V = 0" for the remaining rows (a lower bound, which is all dead cells need to be).
+    int lq_lane = 0, slack = 0;
     if (live) {
         wi = winfo[w];
-        f = pairs[min((int64_t)w * WAVE + lane, g.n_pairs - 1)].fusion_idx;
+        const int64_t p = (int64_t)w * WAVE + lane;
+        f = pairs[min(p, g.n_pairs - 1)].fusion_idx;
+        if (p < g.n_pairs) {
+            lq_lane = pairs[p].read_len;
+            slack = 2 * lq_lane - min_score_tab[lq_lane];
+        }
     }
+    auto wave_max = [](int v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+        return v;
+    };
+    // rows up to which the boundary entering the next tile may still be alive (tile 0: column 0, V = 0)
+    int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
     if (threadIdx.x == 0) s_nch = 0;
     __syncthreads();
     if (lane == 0 && live) atomicMax(&s_nch, wi.nch_max);
@@ -500,13 +522,16 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
         const int ngq = (wi.lq_max >> 2) + 1;
         uint4 rc_n = rows4[0];
         uint4 b_n = (c == 0) ? bias4 : bi4[0];
-        for (int gq = 0; gq < ngq; ++gq) {
+        int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
+        int gq = 0;
+        for (; gq < ngq; ++gq) {
             const uint4 rc = rc_n, b = b_n;
             const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
             rc_n = rows4[(int64_t)gn * WAVE];
             b_n = (c == 0) ? bias4 : bi4[(int64_t)gn * WAVE];
             const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
             uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+            bool alive = false;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
                 const int j = 4 * gq + sidx;
@@ -549,6 +574,10 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                     }
                     cmv[sidx] = tile_row_max<false>(X, W, W);
                     bov[sidx] = X[W - 1] - drift2(W - 1);
+                    const int thr = 4 * j - slack + (int)BIAS16;
+                    const bool in_read = j <= lq_lane;
+                    alive |= in_read && ((int)(cmv[sidx] & 0xFFFFu) >= thr || (int)(cmv[sidx] >> 16) >= thr);
+                    if (in_read && ((int)(bov[sidx] & 0xFFFFu) >= thr || (int)(bov[sidx] >> 16) >= thr)) last_bnd = j;
                 }
                 bprev = bcur;
             }
@@ -560,7 +589,22 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 #ifdef DSA_ABLATE_STORES
             }
 #endif
+#ifndef DSA_NO_PRUNE
+            if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
+#endif
         }
+#ifdef DSA_PRUNE_STATS
+        if (lane == 0) {
+            atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
+            atomicAdd(&g.stats[1], (unsigned long long)ngq);
+            atomicAdd(&g.stats[2], (unsigned long long)l_in);
+        }
+#endif
+        for (; gq < ngq; ++gq) {                            // dead remainder of the tile
+            cm4[(int64_t)gq * WAVE] = bias4;
+            bo4[(int64_t)gq * WAVE] = bias4;
+        }
+        l_in = wave_max(last_bnd);
     }
 #ifndef DSA_ABLATE_TAIL
     if (live) {
