@@ -59,8 +59,8 @@ def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--fusions", type=int, default=10000)
     ap.add_argument("--reads", type=int, default=100)
     ap.add_argument("--lq", type=int, default=76)

@@ -289,7 +289,7 @@ int run_slice(dsa_ctx* ctx, const Slice& s)
     for (int attempt = 0; attempt < 4; ++attempt) {
         if (redo_combine) {
             HIPC(hipMemsetAsync(ctx->d_ctr.p, 0, sizeof(Counters), st));
-            hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(256), 0, st, pairs, ctx->d_fusions.p,
+            hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p,
                                ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, ctx->d_min_score.p, ctx->d_wgs.p, ctx->d_wg_generic.p,
                                ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p,
                                (uint64_t)ctx->d_tasks.cap, (uint64_t)(ctx->d_masks.cap / 2), ctx->d_gtasks.p,

@@ -95,7 +95,7 @@ struct WaveInfo {
     int32_t nch_max;       // most tiles among the wave's pairs (either matrix)
 };
 
-// Per workgroup (4 waves = 256 pairs): the distinct fusions of its pairs, for the fast path.
+// Per workgroup (WG_WAVES waves = WG_LANES pairs): the distinct fusions of its pairs, for the fast path.
 struct WgInfo {
     int32_t n_groups;              // 0 => not eligible for the fast path (more than GMAX fusions)
     int32_t group_f[GMAX];         // fusion_idx
@@ -642,11 +642,11 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int n)   // index of the 
 // K2: per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
 // have columns on both sides, and the tiles that hold a row maximum for them.  Single pass; space
 // comes from device cursors (capacities are checked by the host afterwards).
-// One block = the 256 pairs of one fill workgroup.  The scan over read splits reads the row maxima
+// One block = the WG_LANES pairs of one fill workgroup.  The scan over read splits reads the row maxima
 // four rows at a time (dwordx4, three independent loads per step), so it is not one dependent L2
 // round trip per row.  The first tile pair of every pair is offered to the table-driven replay: per
 // fusion of the workgroup the first offer fixes the (M1 tile, M2 tile) the tables will be built for.
-__global__ __launch_bounds__(256) void k_combine(
+__global__ __launch_bounds__(WG_LANES) void k_combine(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
     const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
     const WgInfo* __restrict__ wginfo,
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void k_combine(
 {
     __shared__ int s_tile[GMAX];
     const int tid = threadIdx.x;
-    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t p = (int64_t)blockIdx.x * WG_LANES + tid;
     const bool active = p < g.n_pairs;
     const int64_t w = p >> 6;
     const int lane = (int)(p & 63);
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
     }
 }
 
-// K3f: table-driven replay.  One workgroup = the 256 pairs of one fill workgroup; the first task of
+// K3f: table-driven replay.  One workgroup = the WG_LANES pairs of one fill workgroup; the first task of
 // every pair whose tile pair matches its fusion's agreed (M1 tile, M2 tile) is replayed here with
 // the same LDS score tables as the fast fill kernel (no row maxima, no stores: add + max3 per column).
 __global__ __launch_bounds__(WG_LANES, 4) void k_replay_fast(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
