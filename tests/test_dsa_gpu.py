@@ -42,6 +42,33 @@ def test_parity_long_reads_many_tiles(gpu_ctx, ora):
     assert len(got) > 20
 
 
+def test_parity_many_tiles_paths(gpu_ctx, ora):
+    """References of 17-20 tiles (beyond the 16-tile winning-tile masks: the combine kernel falls back to
+    the per-tile maxima) and of more than 64 tiles (every tile of a kept pair is replayed)."""
+    got = check_batch(gpu_ctx, ora, cases.mixed_batch(31, n_fusions=3, reads_per_fusion=24, lq=60, lr=(1050, 1250)))
+    assert len(got) > 10
+    got = check_batch(gpu_ctx, ora, cases.mixed_batch(32, n_fusions=2, reads_per_fusion=10, lq=40, lr=(4150, 4300)))
+    assert len(got) > 3
+
+
+def test_parity_single_fusion_fast_path(gpu_ctx, ora):
+    """One fusion, many reads over {A,C,G,T,N}: every workgroup takes the LDS-table kernels."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    bb = cases.BatchBuilder()
+    ref0, ref1 = cases.rnd(rng, 389), cases.rnd(rng, 389, b"ACGTN")
+    f = bb.add_fusion(ref0, ref1)
+    for r in range(700):
+        read = cases.mutate(rng, cases.split_read(rng, ref0, ref1, 76), 0.01)
+        if r % 50 == 0:
+            b = bytearray(read)
+            b[int(rng.integers(0, len(b)))] = ord("N")
+            read = bytes(b)
+        bb.add_read(f, read)
+    got = check_batch(gpu_ctx, ora, bb.arrays())
+    assert len(got) > 300
+
+
 def test_parity_ties(gpu_ctx, ora):
     got = check_batch(gpu_ctx, ora, cases.tie_batch(4))
     # the tie cases must really produce multi-record pairs
