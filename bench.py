@@ -79,9 +79,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # one process per GPU; DEFUSE_BENCH_BACKEND=gloo lets two ranks share one card for a rehearsal
+    backend = os.environ.get("DEFUSE_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     # every rank: its own shard of candidate fusions (different seed => different data, same shape)
     ref, fus, reads, pairs = synth.make_batch(args.fusions, args.reads, lq=args.lq, lr=args.lr, seed=2 + rank)
@@ -109,10 +116,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nn = torch.tensor([len(pairs) * args.steps, n_rec], dtype=torch.int64, device="cuda")
+        nn = torch.tensor([len(pairs) * args.steps, n_rec], dtype=torch.int64, device=red_dev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
         total_aligns = int(nn[0].item())
     else:

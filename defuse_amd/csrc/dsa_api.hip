@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "dsa_kernels.hpp"
@@ -43,6 +44,40 @@ struct DevBuf {
     }
 };
 
+struct HostResult {            // pinned: filled by async copies at the end of a slice's first phase
+    Counters ctr;
+    int64_t n_rec;
+};
+
+struct PipeLane {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[6] = {};      // 0 pack start, 1 fill start, 2 fill end, 3 phase-1 end, 4 emit start, 5 emit end
+    HostResult* host = nullptr;
+    int slice = -1;             // slice whose phase 1 is in flight
+    bool emit_pending = false;  // phase 2 launched, its time not yet accounted
+    DevBuf<WaveInfo> d_waves;
+    DevBuf<WgInfo> d_wgs;
+    DevBuf<uint32_t> d_wg_generic;
+    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
+    DevBuf<PairState> d_state;
+    DevBuf<KeptRow> d_kept;
+    DevBuf<int64_t> d_rec_count, d_rec_offset;
+    DevBuf<ReplayTask> d_tasks;
+    DevBuf<uint64_t> d_masks;
+    DevBuf<uint32_t> d_gtasks;
+    DevBuf<int32_t> d_wgtile;
+    DevBuf<Counters> d_ctr;
+    DevBuf<uint8_t> d_scan_tmp;
+    void release()
+    {
+        d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_refcodes.release(); d_rowcodes.release();
+        d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
+        d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
+        d_wgtile.release(); d_ctr.release(); d_scan_tmp.release();
+    }
+};
+
 struct Slice {
     int64_t pair_begin = 0, pair_end = 0;
     std::vector<WaveInfo> waves;     // one per 64 pairs
@@ -70,26 +105,13 @@ struct dsa_ctx {
     std::vector<Slice> slices;
     int64_t total_cells = 0;
 
-    // scratch
-    DevBuf<WaveInfo> d_waves;
-    DevBuf<WgInfo> d_wgs;
-    DevBuf<uint32_t> d_wg_generic;
-    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
-    DevBuf<PairState> d_state;
-    DevBuf<KeptRow> d_kept;
-    DevBuf<int64_t> d_rec_count, d_rec_offset;
-    DevBuf<ReplayTask> d_tasks;
-    DevBuf<uint64_t> d_masks;
-    DevBuf<uint32_t> d_gtasks;
-    DevBuf<int32_t> d_wgtile;
-    DevBuf<Counters> d_ctr;
-    DevBuf<int16_t> d_mscratch;
-    DevBuf<uint8_t> d_scan_tmp;
+    // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
+    // slice overlaps the fill of the next (separate HIP streams)
+    PipeLane lane[2];
     DevBuf<dsa_record> d_records;
     int64_t n_records = 0;
     bool have_results = false;
 
-    hipEvent_t ev[8] = {};
     dsa_timing timing{};
 };
 
@@ -136,6 +158,9 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
 {
     ctx->slices.clear();
     ctx->total_cells = 0;
+    // big batches are cut into at least four slices so that two of them can be in flight
+    int64_t slice_pair_cap = n_pairs >= 131072 ? (((n_pairs + 3) / 4 + WG_LANES - 1) / WG_LANES) * WG_LANES : n_pairs + 1;
+    if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) slice_pair_cap = std::max<int64_t>(WG_LANES, atoll(e));
     int64_t p = 0;
     while (p < n_pairs) {
         Slice cur;
@@ -152,6 +177,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
             }
             const int64_t waves_after = (int64_t)cur.waves.size() + cdiv((int)(e - p), WAVE);
             if (!cur.waves.empty() && slice_scratch_bytes(waves_after, (nlq1 + 3) & ~3, nnch) > ctx->scratch_budget) break;
+            if (!cur.waves.empty() && (int64_t)cur.waves.size() * WAVE >= slice_pair_cap) break;
             lq1 = nlq1;
             nch = nnch;
             WgInfo wg{};
@@ -194,12 +220,12 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
     return DSA_OK;
 }
 
-int exclusive_scan(dsa_ctx* ctx, const int64_t* in, int64_t* out, int64_t n)
+int exclusive_scan(dsa_ctx* ctx, PipeLane& L, const int64_t* in, int64_t* out, int64_t n)
 {
     size_t tmp = 0;
-    HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, ctx->stream));
-    HIPC(ctx->d_scan_tmp.reserve(tmp));
-    HIPC(hipcub::DeviceScan::ExclusiveSum(ctx->d_scan_tmp.p, tmp, in, out, (int)n, ctx->stream));
+    HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, in, out, (int)n, L.stream));
+    HIPC(L.d_scan_tmp.reserve(tmp));
+    HIPC(hipcub::DeviceScan::ExclusiveSum(L.d_scan_tmp.p, tmp, in, out, (int)n, L.stream));
     return DSA_OK;
 }
 
@@ -215,140 +241,144 @@ int grow_records(dsa_ctx* ctx, size_t need)
     if (need <= ctx->d_records.cap) return DSA_OK;
     DevBuf<dsa_record> bigger;
     HIPC(bigger.reserve(need + need / 2 + 1024));
+    HIPC(hipDeviceSynchronize());       // an emit of the other lane may still be writing the old buffer
     if (ctx->n_records)
-        HIPC(hipMemcpyAsync(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, ctx->stream));
-    HIPC(hipStreamSynchronize(ctx->stream));
+        HIPC(hipMemcpy(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice));
     ctx->d_records.release();
     ctx->d_records = bigger;
     return DSA_OK;
 }
 
-int run_slice(dsa_ctx* ctx, const Slice& s)
+// finish stage up to the record counts: combine -> replay -> count -> scan, then async copies of the
+// cursors and the record total into the lane's pinned result
+int launch_finish(dsa_ctx* ctx, PipeLane& L, const Slice& s)
 {
-    Geom g = s.g;
-#ifdef DSA_PRUNE_STATS
-    static unsigned long long* d_stats = nullptr;
-    if (!d_stats) (void)hipMalloc((void**)&d_stats, 4 * sizeof(unsigned long long));
-    (void)hipMemset(d_stats, 0, 4 * sizeof(unsigned long long));
-    g.stats = d_stats;
-#endif
-    hipStream_t st = ctx->stream;
+    const Geom g = s.g;
+    hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
+    const unsigned pair_grid = (unsigned)((np + 255) / 256);
+    HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
+    hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_tmask.p, ctx->d_min_score.p, L.d_wgs.p, L.d_wg_generic.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap,
+                       L.d_tasks.p, (uint64_t)L.d_tasks.cap, (uint64_t)(L.d_masks.cap / 2), L.d_gtasks.p, (uint64_t)L.d_gtasks.cap,
+                       L.d_wgtile.p, L.d_ctr.p, g);
+    hipLaunchKernelGGL(k_replay_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_ctr.p,
+                       L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p, L.d_wgs.p, L.d_wgtile.p,
+                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2),
+                       (uint64_t)L.d_gtasks.cap, g);
+    hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
+                       (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
+                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
+    hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p,
+                       L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr, (uint64_t)0,
+                       (int64_t)s.pair_begin, g);
+    HIPC(hipMemsetAsync(L.d_rec_count.p + np, 0, sizeof(int64_t), st));
+    if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
+    HIPC(hipEventRecord(L.ev[3], st));
+    HIPC(hipMemcpyAsync(&L.host->ctr, L.d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(&L.host->n_rec, L.d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    return DSA_OK;
+}
 
+// phase 1 of a slice: pack, fill, finish up to the record counts — everything asynchronous
+int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
+{
+    const Slice& s = ctx->slices[slice_idx];
+    Geom g = s.g;
+    hipStream_t st = L.stream;
+    const int64_t np = g.n_pairs;
+    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
+    if (g.lq1 > 7601) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");
     const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
-    HIPC(ctx->d_waves.reserve(s.waves.size()));
-    HIPC(ctx->d_wgs.reserve(s.wgs.size()));
-    HIPC(ctx->d_wg_generic.reserve(s.wg_flags.size()));
-    HIPC(ctx->d_refcodes.reserve((size_t)g.n_fusions * g.lrp));
-    HIPC(ctx->d_rowcodes.reserve(n_rows));
-    HIPC(ctx->d_bnd.reserve(n_rows * g.nch));
-    HIPC(ctx->d_cmax.reserve(n_rows * g.nch));
-    HIPC(ctx->d_rmax.reserve(n_rows));
-    HIPC(ctx->d_tmask.reserve(n_rows));
-    HIPC(ctx->d_state.reserve(np));
-    HIPC(ctx->d_rec_count.reserve(np + 1));
-    HIPC(ctx->d_rec_offset.reserve(np + 1));
-    HIPC(ctx->d_ctr.reserve(1));
-    HIPC(ctx->d_kept.reserve((size_t)np * 2 + 1024));
-    HIPC(ctx->d_tasks.reserve((size_t)np * 4 + 1024));
-    HIPC(ctx->d_masks.reserve((size_t)np * 8 + 1024));
-    HIPC(ctx->d_gtasks.reserve((size_t)np * 2 + 1024));
-    HIPC(ctx->d_wgtile.reserve((size_t)g.n_wgs * GMAX + 16));
-    if (int rc = grow_records(ctx, (size_t)ctx->n_records + (size_t)np * 2 + 1024)) return rc;
-    HIPC(hipMemcpyAsync(ctx->d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(ctx->d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(ctx->d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-
-    // ---- pack -------------------------------------------------------------------------------
-    HIPC(hipEventRecord(ctx->ev[0], st));
+    HIPC(L.d_waves.reserve(s.waves.size()));
+    HIPC(L.d_wgs.reserve(s.wgs.size()));
+    HIPC(L.d_wg_generic.reserve(s.wg_flags.size()));
+    HIPC(L.d_refcodes.reserve((size_t)g.n_fusions * g.lrp));
+    HIPC(L.d_rowcodes.reserve(n_rows));
+    HIPC(L.d_bnd.reserve(n_rows * g.nch));
+    HIPC(L.d_cmax.reserve(n_rows * g.nch));
+    HIPC(L.d_rmax.reserve(n_rows));
+    HIPC(L.d_tmask.reserve(n_rows));
+    HIPC(L.d_state.reserve(np));
+    HIPC(L.d_rec_count.reserve(np + 1));
+    HIPC(L.d_rec_offset.reserve(np + 1));
+    HIPC(L.d_ctr.reserve(1));
+    HIPC(L.d_kept.reserve((size_t)np * 2 + 1024));
+    HIPC(L.d_tasks.reserve((size_t)np * 4 + 1024));
+    HIPC(L.d_masks.reserve((size_t)np * 8 + 1024));
+    HIPC(L.d_gtasks.reserve((size_t)np * 2 + 1024));
+    HIPC(L.d_wgtile.reserve((size_t)g.n_wgs * GMAX + 16));
+    HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPC(hipEventRecord(L.ev[0], st));
     {
         int64_t total = (int64_t)g.n_fusions * g.lrp;
-        hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p,
-                           ctx->d_fusions.p, ctx->d_refcodes.p, g);
+        hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
+                           L.d_refcodes.p, g);
         total = (int64_t)n_rows / 4;
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
-                           ctx->d_rowcodes.p, ctx->d_wg_generic.p, g);
+                           L.d_rowcodes.p, L.d_wg_generic.p, g);
     }
-    HIPC(hipEventRecord(ctx->ev[1], st));
-    // ---- fill: every workgroup is run by exactly one of the two kernels ---------------------------
-    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p, ctx->d_wgs.p,
-                       ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_min_score.p, ctx->d_bnd.p, ctx->d_cmax.p,
-                       ctx->d_rmax.p, ctx->d_tmask.p, g);
-    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_waves.p,
-                       ctx->d_fusions.p, ctx->d_wg_generic.p, ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p,
-                       ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, g);
-    HIPC(hipEventRecord(ctx->ev[2], st));
+    HIPC(hipEventRecord(L.ev[1], st));
+    // every workgroup is run by exactly one of the two fill kernels
+    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                       L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, g);
+    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, ctx->d_fusions.p,
+                       L.d_wg_generic.p, L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, g);
+    HIPC(hipEventRecord(L.ev[2], st));
     HIPC(hipGetLastError());
-    // ---- finish: combine -> replay -> emit, no host round trip unless a buffer overflowed --------
-    if (g.lq1 > 7601) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");
-    const unsigned pair_grid = (unsigned)((np + 255) / 256);
-    Counters ctr{};
-    int64_t n_rec = 0;
-    bool redo_combine = true;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        if (redo_combine) {
-            HIPC(hipMemsetAsync(ctx->d_ctr.p, 0, sizeof(Counters), st));
-            hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p,
-                               ctx->d_cmax.p, ctx->d_rmax.p, ctx->d_tmask.p, ctx->d_min_score.p, ctx->d_wgs.p, ctx->d_wg_generic.p,
-                               ctx->d_state.p, ctx->d_kept.p, (uint64_t)ctx->d_kept.cap, ctx->d_tasks.p,
-                               (uint64_t)ctx->d_tasks.cap, (uint64_t)(ctx->d_masks.cap / 2), ctx->d_gtasks.p,
-                               (uint64_t)ctx->d_gtasks.cap, ctx->d_wgtile.p, ctx->d_ctr.p, g);
-            hipLaunchKernelGGL(k_replay_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, ctx->d_tasks.p,
-                               (uint64_t)ctx->d_tasks.cap, ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p,
-                               (uint64_t)ctx->d_kept.cap, pairs, ctx->d_fusions.p, ctx->d_wgs.p, ctx->d_wgtile.p,
-                               ctx->d_refcodes.p, ctx->d_rowcodes.p, ctx->d_bnd.p, ctx->d_masks.p,
-                               (uint64_t)(ctx->d_masks.cap / 2), (uint64_t)ctx->d_gtasks.cap, g);
-            hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, ctx->d_tasks.p, (uint64_t)ctx->d_tasks.cap,
-                               ctx->d_gtasks.p, (uint64_t)ctx->d_gtasks.cap, ctx->d_ctr.p, ctx->d_state.p, ctx->d_kept.p,
-                               (uint64_t)ctx->d_kept.cap, pairs, ctx->d_fusions.p, ctx->d_refcodes.p, ctx->d_rowcodes.p,
-                               ctx->d_bnd.p, ctx->d_masks.p, (uint64_t)(ctx->d_masks.cap / 2), g);
-            hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
-                               ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p, (const int64_t*)nullptr,
-                               (dsa_record*)nullptr, (uint64_t)0, (int64_t)s.pair_begin, g);
-            HIPC(hipMemsetAsync(ctx->d_rec_count.p + np, 0, sizeof(int64_t), st));
-            if (int rc = exclusive_scan(ctx, ctx->d_rec_count.p, ctx->d_rec_offset.p, np + 1)) return rc;
-        }
-        hipLaunchKernelGGL(k_emit<true>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, ctx->d_state.p,
-                           ctx->d_kept.p, ctx->d_tasks.p, ctx->d_masks.p, ctx->d_rec_count.p,
-                           (const int64_t*)ctx->d_rec_offset.p, ctx->d_records.p + ctx->n_records,
-                           (uint64_t)(ctx->d_records.cap - ctx->n_records), (int64_t)s.pair_begin, g);
-        HIPC(hipEventRecord(ctx->ev[3], st));
-        HIPC(hipMemcpyAsync(&ctr, ctx->d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-        HIPC(hipMemcpyAsync(&n_rec, ctx->d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
+    if (int rc = launch_finish(ctx, L, s)) return rc;
+    L.slice = slice_idx;
+    return DSA_OK;
+}
+
+void account_emit(dsa_ctx* ctx, PipeLane& L)
+{
+    if (!L.emit_pending) return;
+    (void)hipEventSynchronize(L.ev[5]);
+    ctx->timing.finish_ms += elapsed(L.ev[4], L.ev[5]);
+    L.emit_pending = false;
+}
+
+// phase 2: wait for the slice's counts, grow whatever overflowed (rare; then the finish stage is
+// re-run), and write its records behind those of the earlier slices
+int phase2(dsa_ctx* ctx, PipeLane& L)
+{
+    const Slice& s = ctx->slices[L.slice];
+    const Geom g = s.g;
+    const int64_t np = g.n_pairs;
+    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
+    account_emit(ctx, L);
+    for (int attempt = 0;; ++attempt) {
+        HIPC(hipStreamSynchronize(L.stream));
         HIPC(hipGetLastError());
-        redo_combine = ctr.n_kept > ctx->d_kept.cap || ctr.n_tasks > ctx->d_tasks.cap || ctr.n_masks > ctx->d_masks.cap / 2 ||
-                       ctr.n_gtasks > ctx->d_gtasks.cap;
-        if (redo_combine) {
-            HIPC(ctx->d_kept.reserve(ctr.n_kept + 1024));
-            HIPC(ctx->d_tasks.reserve(ctr.n_tasks + 1024));
-            HIPC(ctx->d_masks.reserve(2 * ctr.n_masks + 1024));
-            HIPC(ctx->d_gtasks.reserve(ctr.n_gtasks + 1024));
-            continue;
-        }
-        if ((size_t)(ctx->n_records + n_rec) > ctx->d_records.cap) {
-            if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
-            continue;
-        }
-        break;
+        const Counters c = L.host->ctr;
+        if (c.n_kept <= L.d_kept.cap && c.n_tasks <= L.d_tasks.cap && c.n_masks <= L.d_masks.cap / 2 && c.n_gtasks <= L.d_gtasks.cap) break;
+        if (attempt >= 3) return fail(ctx, DSA_E_DEVICE, "finish stage did not converge");
+        HIPC(L.d_kept.reserve(c.n_kept + 1024));
+        HIPC(L.d_tasks.reserve(c.n_tasks + 1024));
+        HIPC(L.d_masks.reserve(2 * c.n_masks + 1024));
+        HIPC(L.d_gtasks.reserve(c.n_gtasks + 1024));
+        if (int rc = launch_finish(ctx, L, s)) return rc;
     }
-    if (redo_combine || (size_t)(ctx->n_records + n_rec) > ctx->d_records.cap)
-        return fail(ctx, DSA_E_DEVICE, "finish stage did not converge");
-#ifdef DSA_PRUNE_STATS
-    {
-        unsigned long long h[4] = {0, 0, 0, 0};
-        (void)hipMemcpy(h, g.stats, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[prune] skipped row groups %llu of %llu, sum l_in %llu\n", h[0], h[1], h[2]);
-    }
-#endif
+    const int64_t n_rec = L.host->n_rec;
+    if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
+    HIPC(hipEventRecord(L.ev[4], L.stream));
+    hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, L.stream, pairs, ctx->d_fusions.p, L.d_state.p,
+                       L.d_kept.p, L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p,
+                       ctx->d_records.p + ctx->n_records, (uint64_t)(ctx->d_records.cap - ctx->n_records), (int64_t)s.pair_begin, g);
+    HIPC(hipEventRecord(L.ev[5], L.stream));
+    HIPC(hipGetLastError());
+    L.emit_pending = true;
     ctx->n_records += n_rec;
-    ctx->timing.pack_ms += elapsed(ctx->ev[0], ctx->ev[1]);
-    ctx->timing.fill_ms += elapsed(ctx->ev[1], ctx->ev[2]);
-    ctx->timing.finish_ms += elapsed(ctx->ev[2], ctx->ev[3]);
-    ctx->timing.total_ms += elapsed(ctx->ev[0], ctx->ev[3]);
+    ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[1]);
+    ctx->timing.fill_ms += elapsed(L.ev[1], L.ev[2]);
+    ctx->timing.finish_ms += elapsed(L.ev[2], L.ev[3]);
     ctx->timing.fill_launches += 1;
-    ctx->timing.n_replay_tasks += (int64_t)ctr.n_tasks;
+    ctx->timing.n_replay_tasks += (int64_t)L.host->ctr.n_tasks;
+    L.slice = -1;
     return DSA_OK;
 }
 
@@ -371,11 +401,18 @@ int dsa_create(dsa_ctx** out, int device)
         return DSA_E_DEVICE;
     }
     ctx->stream = ctx->own_stream;
-    for (auto& e : ctx->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
+    for (int l = 0; l < 2; ++l) {
+        PipeLane& L = ctx->lane[l];
+        bool ok = true;
+        if (l == 0) L.stream = ctx->stream;
+        else { ok = hipStreamCreate(&L.stream) == hipSuccess; L.own_stream = ok; }
+        for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
+        if (!ok) {
             delete ctx;
             return DSA_E_DEVICE;
         }
+    }
     if (const char* mb = getenv("DEFUSE_DSA_SCRATCH_MB")) {
         long v = atol(mb);
         if (v > 0) ctx->scratch_budget = (size_t)v << 20;
@@ -390,13 +427,15 @@ void dsa_destroy(dsa_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
-    ctx->d_min_score.release(); ctx->d_waves.release(); ctx->d_wgs.release(); ctx->d_wg_generic.release();
-    ctx->d_refcodes.release(); ctx->d_rowcodes.release(); ctx->d_bnd.release(); ctx->d_cmax.release(); ctx->d_rmax.release(); ctx->d_tmask.release();
-    ctx->d_state.release(); ctx->d_kept.release(); ctx->d_rec_count.release(); ctx->d_rec_offset.release();
-    ctx->d_tasks.release(); ctx->d_masks.release(); ctx->d_gtasks.release(); ctx->d_wgtile.release(); ctx->d_ctr.release(); ctx->d_mscratch.release();
-    ctx->d_scan_tmp.release(); ctx->d_records.release();
-    for (auto& e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
+    (void)hipDeviceSynchronize();
+    ctx->d_min_score.release(); ctx->d_records.release();
+    for (PipeLane& L : ctx->lane) {
+        L.release();
+        for (auto& e : L.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (L.host) (void)hipHostFree(L.host);
+        if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -416,6 +455,7 @@ int dsa_set_stream(dsa_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return DSA_E_ARG;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->lane[0].stream = ctx->stream;      // lane 1 keeps its private stream
     return DSA_OK;
 }
 
@@ -486,8 +526,26 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
     ctx->n_records = 0;
     ctx->timing = dsa_timing{};
     ctx->timing.cells = ctx->total_cells;
-    for (const Slice& s : ctx->slices)
-        if (int rc = run_slice(ctx, s)) return rc;
+    // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
+    const int ns = (int)ctx->slices.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < ns; ++k) {
+        PipeLane& L = ctx->lane[k & 1];
+        if (L.slice >= 0)
+            if (int rc = phase2(ctx, L)) return rc;
+        if (int rc = phase1(ctx, L, k)) return rc;
+    }
+    for (int k = ns; k < ns + 2; ++k) {
+        PipeLane& L = ctx->lane[k & 1];
+        if (L.slice >= 0)
+            if (int rc = phase2(ctx, L)) return rc;
+    }
+    for (PipeLane& L : ctx->lane) {
+        account_emit(ctx, L);
+        HIPC(hipStreamSynchronize(L.stream));
+    }
+    // stage times are per-stream sums and overlap between the lanes; total_ms is the elapsed time
+    ctx->timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.n_records = ctx->n_records;
     ctx->have_results = true;
     if (out_n) *out_n = ctx->n_records;

@@ -87,7 +87,7 @@ typedef struct dsa_timing {
     float   pack_ms;              /* byte -> code packing kernels                                */
     float   fill_ms;              /* the DP fill kernel(s) — the dominant kernel                 */
     float   finish_ms;            /* combine + tile replay + emit kernels                        */
-    float   total_ms;             /* first kernel start -> last kernel end                       */
+    float   total_ms;             /* elapsed host time of dsa_run (stage times overlap between slices) */
     int32_t fill_launches;        /* number of DP fill launches in fill_ms                       */
     int32_t pad_;
     int64_t cells;                /* DP cells filled: sum over pairs of 2*(Lref+1)*(Lread+1)     */
