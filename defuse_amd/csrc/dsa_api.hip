@@ -52,7 +52,7 @@ struct HostResult {            // pinned: filled by async copies at the end of a
 struct PipeLane {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[6] = {};      // 0 pack start, 1 fill start, 2 fill end, 3 phase-1 end, 4 emit start, 5 emit end
+    hipEvent_t ev[7] = {};      // 0 pack start, 4 pack end, 1 fill start, 2 fill end, 3 phase-1 end, 5 emit start, 6 emit end
     HostResult* host = nullptr;
     int slice = -1;             // slice whose phase 1 is in flight
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
@@ -66,7 +66,6 @@ struct PipeLane {
     DevBuf<ReplayTask> d_tasks;
     DevBuf<uint64_t> d_masks;
     DevBuf<uint32_t> d_gtasks;
-    DevBuf<int32_t> d_wgtile;
     DevBuf<Counters> d_ctr;
     DevBuf<uint8_t> d_scan_tmp;
     void release()
@@ -74,7 +73,7 @@ struct PipeLane {
         d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_refcodes.release(); d_rowcodes.release();
         d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
         d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
-        d_wgtile.release(); d_ctr.release(); d_scan_tmp.release();
+        d_ctr.release(); d_scan_tmp.release();
     }
 };
 
@@ -158,8 +157,10 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
 {
     ctx->slices.clear();
     ctx->total_cells = 0;
-    // big batches are cut into at least four slices so that two of them can be in flight
-    int64_t slice_pair_cap = n_pairs >= 131072 ? (((n_pairs + 3) / 4 + WG_LANES - 1) / WG_LANES) * WG_LANES : n_pairs + 1;
+    // Slices are cut by the scratch budget only: cutting finer to overlap two slices on the two lanes
+    // measured no faster than one big slice (the finish work already hides inside the fill kernel).
+    // DEFUSE_DSA_SLICE_PAIRS caps the pairs per slice (tests, experiments).
+    int64_t slice_pair_cap = n_pairs + 1;
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) slice_pair_cap = std::max<int64_t>(WG_LANES, atoll(e));
     int64_t p = 0;
     while (p < n_pairs) {
@@ -249,24 +250,42 @@ int grow_records(dsa_ctx* ctx, size_t need)
     return DSA_OK;
 }
 
-// finish stage up to the record counts: combine -> replay -> count -> scan, then async copies of the
-// cursors and the record total into the lane's pinned result
-int launch_finish(dsa_ctx* ctx, PipeLane& L, const Slice& s)
+FinishBufs finish_bufs(PipeLane& L)
+{
+    FinishBufs fb;
+    fb.state = L.d_state.p;
+    fb.kept = L.d_kept.p;
+    fb.tasks = L.d_tasks.p;
+    fb.masks = L.d_masks.p;
+    fb.gtasks = L.d_gtasks.p;
+    fb.ctr = L.d_ctr.p;
+    fb.kept_cap = L.d_kept.cap;
+    fb.task_cap = L.d_tasks.cap;
+    fb.mask_cap = L.d_masks.cap / 2;
+    fb.gtask_cap = L.d_gtasks.cap;
+    return fb;
+}
+
+// fill (with the per-workgroup combine and table-driven replay in its tail) -> generic replay ->
+// count -> scan, then async copies of the cursors and the record total into the lane's pinned result
+int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
 {
     const Geom g = s.g;
     hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     const unsigned pair_grid = (unsigned)((np + 255) / 256);
+    const FinishBufs fb = finish_bufs(L);
     HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
-    hipLaunchKernelGGL(k_combine, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p, L.d_cmax.p, L.d_rmax.p,
-                       L.d_tmask.p, ctx->d_min_score.p, L.d_wgs.p, L.d_wg_generic.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap,
-                       L.d_tasks.p, (uint64_t)L.d_tasks.cap, (uint64_t)(L.d_masks.cap / 2), L.d_gtasks.p, (uint64_t)L.d_gtasks.cap,
-                       L.d_wgtile.p, L.d_ctr.p, g);
-    hipLaunchKernelGGL(k_replay_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_ctr.p,
-                       L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p, L.d_wgs.p, L.d_wgtile.p,
-                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2),
-                       (uint64_t)L.d_gtasks.cap, g);
+    HIPC(hipEventRecord(L.ev[1], st));
+    // every workgroup is run by exactly one of the two fill kernels
+    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                       L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_tmask.p, fb, g);
+    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,
+                       L.d_wg_generic.p, L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_tmask.p, fb, g);
+    HIPC(hipEventRecord(L.ev[2], st));
     hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
                        L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
@@ -278,6 +297,7 @@ int launch_finish(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipEventRecord(L.ev[3], st));
     HIPC(hipMemcpyAsync(&L.host->ctr, L.d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(&L.host->n_rec, L.d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPC(hipGetLastError());
     return DSA_OK;
 }
 
@@ -308,7 +328,6 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_tasks.reserve((size_t)np * 4 + 1024));
     HIPC(L.d_masks.reserve((size_t)np * 8 + 1024));
     HIPC(L.d_gtasks.reserve((size_t)np * 2 + 1024));
-    HIPC(L.d_wgtile.reserve((size_t)g.n_wgs * GMAX + 16));
     HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -321,15 +340,8 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
         hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
                            L.d_rowcodes.p, L.d_wg_generic.p, g);
     }
-    HIPC(hipEventRecord(L.ev[1], st));
-    // every workgroup is run by exactly one of the two fill kernels
-    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, g);
-    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, ctx->d_fusions.p,
-                       L.d_wg_generic.p, L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, g);
-    HIPC(hipEventRecord(L.ev[2], st));
-    HIPC(hipGetLastError());
-    if (int rc = launch_finish(ctx, L, s)) return rc;
+    HIPC(hipEventRecord(L.ev[4], st));      // end of pack (ev[1] is re-recorded by every launch_compute)
+    if (int rc = launch_compute(ctx, L, s)) return rc;
     L.slice = slice_idx;
     return DSA_OK;
 }
@@ -337,8 +349,8 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
 void account_emit(dsa_ctx* ctx, PipeLane& L)
 {
     if (!L.emit_pending) return;
-    (void)hipEventSynchronize(L.ev[5]);
-    ctx->timing.finish_ms += elapsed(L.ev[4], L.ev[5]);
+    (void)hipEventSynchronize(L.ev[6]);
+    ctx->timing.finish_ms += elapsed(L.ev[5], L.ev[6]);
     L.emit_pending = false;
 }
 
@@ -361,19 +373,19 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
         HIPC(L.d_tasks.reserve(c.n_tasks + 1024));
         HIPC(L.d_masks.reserve(2 * c.n_masks + 1024));
         HIPC(L.d_gtasks.reserve(c.n_gtasks + 1024));
-        if (int rc = launch_finish(ctx, L, s)) return rc;
+        if (int rc = launch_compute(ctx, L, s)) return rc;
     }
     const int64_t n_rec = L.host->n_rec;
     if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
-    HIPC(hipEventRecord(L.ev[4], L.stream));
+    ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
+    HIPC(hipEventRecord(L.ev[5], L.stream));
     hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, L.stream, pairs, ctx->d_fusions.p, L.d_state.p,
                        L.d_kept.p, L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p,
                        ctx->d_records.p + ctx->n_records, (uint64_t)(ctx->d_records.cap - ctx->n_records), (int64_t)s.pair_begin, g);
-    HIPC(hipEventRecord(L.ev[5], L.stream));
+    HIPC(hipEventRecord(L.ev[6], L.stream));
     HIPC(hipGetLastError());
     L.emit_pending = true;
     ctx->n_records += n_rec;
-    ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[1]);
     ctx->timing.fill_ms += elapsed(L.ev[1], L.ev[2]);
     ctx->timing.finish_ms += elapsed(L.ev[2], L.ev[3]);
     ctx->timing.fill_launches += 1;

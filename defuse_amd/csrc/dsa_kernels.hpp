@@ -198,6 +198,36 @@ __device__ __forceinline__ void table_row_classes(int t, int& k1, int& k2)   // 
     else { k1 = t - 21; k2 = 4; }
 }
 
+// Score tables of one tile for the fusion groups of a workgroup (layout: k_fill_fast).  One thread per
+// (group, column): the five per-class terms of either field are formed once and combined into the 25
+// table rows, so a tile's tables cost ~100 instructions per thread.  code_of(gi, i, q0, q1) returns the
+// 16-bit reference codes of column i (REF_PAD16 = padding) for M1 / M2.
+template <class CodeFn>
+__device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_groups, CodeFn&& code_of)
+{
+    for (int e = threadIdx.x; e < n_groups * W; e += WG_LANES) {
+        const int i = e & (W - 1), gi = e >> 6;
+        uint32_t q0, q1;
+        code_of(gi, i, q0, q1);
+        const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};   // inverse of base_class
+        uint32_t lo[NCLS], hi[NCLS];
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) {
+            lo[k] = q0 == REF_PAD16 ? 0u : ((q0 >> 8) == cls_byte[k] ? 4u : 1u);
+            hi[k] = (q1 == REF_PAD16 ? 0u : ((q1 >> 8) == cls_byte[k] ? 4u : 1u)) << 16;
+        }
+        // +2 per field for i > 0: the diagonal move from column i-1 to i picks up the drift
+        const uint32_t drift = i > 0 ? TWO2 : 0u;
+        uint32_t* col = T + gi * TGROUP + i;
+#pragma unroll
+        for (int t = 0; t < NCOMBO; ++t) {
+            int k1, k2;
+            table_row_classes(t, k1, k2);
+            col[t * TROW] = (lo[k1] | hi[k2]) + drift;
+        }
+    }
+}
+
 // one thread = four consecutive rows of one pair (one dwordx4 of the rowcodes plane)
 __global__ void k_pack_rows(const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
                             uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ wg_generic, Geom g)
@@ -277,344 +307,6 @@ __device__ __forceinline__ uint32_t tile_row_max(const uint32_t (&X)[W], int nv0
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1g: generic DP fill.  One wave = 64 pairs; 4 waves per workgroup.  Runs only the workgroups
-// flagged generic (exotic read bytes or more than GMAX fusions in the workgroup).
-//   cmax[((w*nch + c)*lq1 + j)*64 + lane] = max over the tile's valid columns of V(.,j)   (2 x u16, biased)
-//   bnd [((w*nch + c)*lq1 + j)*64 + lane] = V(last column of tile c, j)
-// ---------------------------------------------------------------------------------------------
-template <bool MASKED>
-__device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const uint4* __restrict__ rows4,
-                                                   const uint4* __restrict__ bi4, uint4* __restrict__ cm4,
-                                                   uint4* __restrict__ bo4, int lq, bool first, int nv0, int nv1)
-{
-    uint32_t X[W];
-#pragma unroll
-    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-    const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-    uint32_t bprev = BIAS2;
-    const int ngq = (lq >> 2) + 1;
-    uint4 rc_n = rows4[0];
-    uint4 b_n = first ? bias4 : bi4[0];
-    for (int gq = 0; gq < ngq; ++gq) {
-        const uint4 rc = rc_n, b = b_n;
-        const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
-        rc_n = rows4[(int64_t)gn * WAVE];
-        b_n = first ? bias4 : bi4[(int64_t)gn * WAVE];
-        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
-        uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int j = 4 * gq + sidx;
-            if (j >= 1 && j <= lq) {                        // wave-uniform
-                row_step(X, r, rcv[sidx], bprev, bv[sidx]);
-                cmv[sidx] = tile_row_max<MASKED>(X, nv0, nv1);
-                bov[sidx] = X[W - 1] - drift2(W - 1);
-            }
-            bprev = bv[sidx];
-        }
-        cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
-        bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
-    }
-}
-
-// After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
-// dword per row instead of one per tile; tmask = which tiles attain it (bit c: M1 tile c, bit 16+c:
-// M2 tile c; only meaningful while a reference has at most 16 tiles, the combine kernel falls back to
-// cmax otherwise).  cmax of this wave is L2-hot.
-constexpr int TMASK_TILES = 16;
-__device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
-{
-    const uint32_t x = v ^ m;
-    return ((x & 0xFFFFu) == 0u ? (1u << c) : 0u) | ((x >> 16) == 0u ? (1u << (16 + c)) : 0u);
-}
-__device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
-                                               uint32_t* __restrict__ tmask, const Geom& g, int w, int lane,
-                                               int nch_wave, int lq)
-{
-    const int ngq = (lq >> 2) + 1;
-    uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
-    uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
-    const uint4* src = reinterpret_cast<const uint4*>(cmax + (int64_t)w * g.nch * g.lq1 * WAVE) + lane;
-    const int64_t cstride = (int64_t)(g.lq1 >> 2) * WAVE;       // uint4 elements between two tiles
-    constexpr int NC = 8;
-    if (nch_wave <= NC) {
-        // all tiles of a row group in registers: one round of independent loads, then max and masks
-        for (int gq = 0; gq < ngq; ++gq) {
-            uint4 v[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                v[c] = c < nch_wave ? src[c * cstride + (int64_t)gq * WAVE] : make_uint4(0, 0, 0, 0);
-            uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (c < nch_wave) {
-                    m.x = max2(m.x, v[c].x);
-                    m.y = max2(m.y, v[c].y);
-                    m.z = max2(m.z, v[c].z);
-                    m.w = max2(m.w, v[c].w);
-                }
-            uint4 t = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                if (c < nch_wave) {
-                    t.x |= eq_bits(v[c].x, m.x, c);
-                    t.y |= eq_bits(v[c].y, m.y, c);
-                    t.z |= eq_bits(v[c].z, m.z, c);
-                    t.w |= eq_bits(v[c].w, m.w, c);
-                }
-            out[(int64_t)gq * WAVE] = m;
-            tout[(int64_t)gq * WAVE] = t;
-        }
-        return;
-    }
-    for (int gq = 0; gq < ngq; ++gq) {
-        uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-        for (int c = 0; c < nch_wave; ++c) {
-            const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
-            m.x = max2(m.x, v.x);
-            m.y = max2(m.y, v.y);
-            m.z = max2(m.z, v.z);
-            m.w = max2(m.w, v.w);
-        }
-        out[(int64_t)gq * WAVE] = m;
-        if (nch_wave <= TMASK_TILES) {
-            uint4 t = make_uint4(0, 0, 0, 0);
-            for (int c = 0; c < nch_wave; ++c) {
-                const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
-                t.x |= eq_bits(v.x, m.x, c);
-                t.y |= eq_bits(v.y, m.y, c);
-                t.z |= eq_bits(v.z, m.z, c);
-                t.w |= eq_bits(v.w, m.w, c);
-            }
-            tout[(int64_t)gq * WAVE] = t;
-        }
-    }
-}
-
-__global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __restrict__ pairs,
-                                                           const WaveInfo* __restrict__ winfo,
-                                                           const dsa_fusion* __restrict__ fusions,
-                                                           const uint32_t* __restrict__ wg_generic,
-                                                           const uint32_t* __restrict__ refcodes,
-                                                           const uint32_t* __restrict__ rowcodes,
-                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
-                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask, Geom g)
-{
-    if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
-    if (w >= g.n_waves) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t p = min((int64_t)w * WAVE + lane, g.n_pairs - 1);   // tail lanes shadow the last pair
-    const WaveInfo wi = winfo[w];
-    const int f = pairs[p].fusion_idx;
-    const dsa_fusion fu = fusions[f];
-    const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
-    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
-
-    for (int c = 0; c < wi.nch_max; ++c) {
-        uint32_t r[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) r[i] = rc[c * W + i];
-        const int nv0 = fu.ref0_len - c * W, nv1 = fu.ref1_len - c * W;   // per lane; may be <= 0
-        uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
-        uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
-        const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
-        if (__builtin_amdgcn_ballot_w64(nv0 < W || nv1 < W) == 0)
-            sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
-        else
-            sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-    reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1f: fast DP fill (reads over {A,C,G,T,N}).  Per workgroup and tile, the substitution terms of
-// every fusion present are tabulated in LDS:
-//     T[g][k1*5+k2][i] = { d(ref0_g[i], base[k1]), d(rev(ref1_g)[i], base[k2]) },  d = eq ? 4 : 1
-// where k1/k2 are the classes of the M1 / M2 read base of the row.  Padded reference columns get
-// d = 0 (worse than a mismatch): their values can then reach but never exceed the row maximum of the
-// valid columns, so the tile row maximum needs no masking (the replay masks exclude them by index).
-// A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column; four rows share one
-// dwordx4 load of row codes / boundary and one dwordx4 store of tile maxima / boundary.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
-                                                           const WaveInfo* __restrict__ winfo,
-                                                           const WgInfo* __restrict__ wginfo,
-                                                           const uint32_t* __restrict__ wg_generic,
-                                                           const uint32_t* __restrict__ refcodes,
-                                                           const uint32_t* __restrict__ rowcodes,
-                                                           const int32_t* __restrict__ min_score_tab,
-                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
-                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask, Geom g)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
-    __shared__ int s_nch;
-    if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
-    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
-    const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
-    const int lane = threadIdx.x & 63;
-    const WgInfo wgi = wginfo[blockIdx.x];
-    WaveInfo wi = {0, 0};
-    int f = 0;
-    // Exact pruning (DESIGN.md 4): a cell with V(i,j) < 4j - slack, slack = 2*Lq - minScore, can never
-    // feed a row maximum that takes part in a split of score >= minScore (each further row adds at most
-    // 4), and no live cell's value comes from a dead cell.  Once a whole tile row and everything that
-    // can still enter from the left are dead, the rest of the tile is dead: the sweep stops there and
-    // stores "V = 0" for the remaining rows (a lower bound, which is all dead cells need to be).
-    int lq_lane = 0, slack = 0;
-    if (live) {
-        wi = winfo[w];
-        const int64_t p = (int64_t)w * WAVE + lane;
-        f = pairs[min(p, g.n_pairs - 1)].fusion_idx;
-        if (p < g.n_pairs) {
-            lq_lane = pairs[p].read_len;
-            slack = 2 * lq_lane - min_score_tab[lq_lane];
-        }
-    }
-    auto wave_max = [](int v) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-        return v;
-    };
-    // rows up to which the boundary entering the next tile may still be alive (tile 0: column 0, V = 0)
-    int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
-    if (threadIdx.x == 0) s_nch = 0;
-    __syncthreads();
-    if (lane == 0 && live) atomicMax(&s_nch, wi.nch_max);
-    __syncthreads();
-    const int nch_wg = s_nch;
-
-    int gsel = 0;
-#pragma unroll
-    for (int k = 0; k < GMAX; ++k)
-        if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
-    const uint32_t* tb = T + gsel * TGROUP;
-    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
-
-    for (int c = 0; c < nch_wg; ++c) {
-        __syncthreads();                          // previous tile's tables no longer in use
-        for (int e = threadIdx.x; e < wgi.n_groups * NCOMBO * W; e += WG_LANES) {
-            const int i = e & (W - 1);
-            const int combo = (e >> 6) % NCOMBO;
-            const int gi = (e >> 6) / NCOMBO;
-            const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
-            const uint32_t c0 = code & 0xFFFFu, c1 = code >> 16;
-            const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};   // inverse of base_class
-            int k1, k2;
-            table_row_classes(combo, k1, k2);
-            const uint32_t d0 = c0 == REF_PAD16 ? 0u : ((c0 >> 8) == cls_byte[k1] ? 4u : 1u);
-            const uint32_t d1 = c1 == REF_PAD16 ? 0u : ((c1 >> 8) == cls_byte[k2] ? 4u : 1u);
-            // +2 per field for i > 0: the diagonal move from column i-1 to i picks up the drift
-            T[gi * TGROUP + combo * TROW + i] = (d0 | (d1 << 16)) + (i > 0 ? TWO2 : 0u);
-        }
-        __syncthreads();
-        if (!live || c >= wi.nch_max) continue;   // wave-uniform
-
-        uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
-        uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
-        const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
-        uint32_t X[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-        uint32_t bprev = BIAS2;
-        const int ngq = (wi.lq_max >> 2) + 1;
-        uint4 rc_n = rows4[0];
-        uint4 b_n = (c == 0) ? bias4 : bi4[0];
-        int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
-        int gq = 0;
-        for (; gq < ngq; ++gq) {
-            const uint4 rc = rc_n, b = b_n;
-            const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
-            rc_n = rows4[(int64_t)gn * WAVE];
-            b_n = (c == 0) ? bias4 : bi4[(int64_t)gn * WAVE];
-            const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
-            uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
-            bool alive = false;
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int j = 4 * gq + sidx;
-                const uint32_t bcur = bv[sidx];
-                if (j >= 1 && j <= wi.lq_max) {             // wave-uniform
-                    // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
-                    // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
-                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
-                    uint4 vq[FILL_PF + 1];                  // table reads in flight
-#ifdef DSA_ABLATE_LDS
-#define TROW_LD(k) make_uint4(rcv[sidx] + (k), 0x00060006u, 0x00030003u, 0x00060006u)
-#else
-#define TROW_LD(k) trow[k]
-#endif
-#pragma unroll
-                    for (int k = 0; k <= FILL_PF; ++k) vq[k] = TROW_LD(k);
-                    uint32_t a = bprev + vq[0].x;
-                    uint32_t up = bcur - TWO2;
-#pragma unroll
-                    for (int q = 0; q < W / 4; ++q) {
-                        const uint4 v = vq[0];
-#pragma unroll
-                        for (int k = 0; k < FILL_PF; ++k) vq[k] = vq[k + 1];
-                        if (q + 1 + FILL_PF < W / 4) vq[FILL_PF] = TROW_LD(q + 1 + FILL_PF);
-                        const uint4 vn = vq[0];
-                        uint32_t an;
-                        an = X[4 * q + 0] + v.y;
-                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
-                        a = an;
-                        an = X[4 * q + 1] + v.z;
-                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
-                        a = an;
-                        an = X[4 * q + 2] + v.w;
-                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
-                        a = an;
-                        an = X[4 * q + 3] + vn.x;
-                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
-                        a = an;
-                        up = X[4 * q + 3];
-                    }
-                    cmv[sidx] = tile_row_max<false>(X, W, W);
-                    bov[sidx] = X[W - 1] - drift2(W - 1);
-                    const int thr = 4 * j - slack + (int)BIAS16;
-                    const bool in_read = j <= lq_lane;
-                    alive |= in_read && ((int)(cmv[sidx] & 0xFFFFu) >= thr || (int)(cmv[sidx] >> 16) >= thr);
-                    if (in_read && ((int)(bov[sidx] & 0xFFFFu) >= thr || (int)(bov[sidx] >> 16) >= thr)) last_bnd = j;
-                }
-                bprev = bcur;
-            }
-#ifdef DSA_ABLATE_STORES
-            if (gq == ngq - 1) {
-#endif
-            cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
-            bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
-#ifdef DSA_ABLATE_STORES
-            }
-#endif
-#ifndef DSA_NO_PRUNE
-            if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
-#endif
-        }
-#ifdef DSA_PRUNE_STATS
-        if (lane == 0) {
-            atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
-            atomicAdd(&g.stats[1], (unsigned long long)ngq);
-            atomicAdd(&g.stats[2], (unsigned long long)l_in);
-        }
-#endif
-        for (; gq < ngq; ++gq) {                            // dead remainder of the tile
-            cm4[(int64_t)gq * WAVE] = bias4;
-            bo4[(int64_t)gq * WAVE] = bias4;
-        }
-        l_in = wave_max(last_bnd);
-    }
-#ifndef DSA_ABLATE_TAIL
-    if (live) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
 // Finish stage
 // ---------------------------------------------------------------------------------------------
 // wave-aggregated allocation: every lane asks for n items, one atomic per wave
@@ -639,22 +331,40 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int n)   // index of the 
     return m ? __builtin_ctzll(m) : -1;
 }
 
-// K2: per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
+// Combine (tail of the fill kernels): per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
 // have columns on both sides, and the tiles that hold a row maximum for them.  Single pass; space
 // comes from device cursors (capacities are checked by the host afterwards).
 // One block = the WG_LANES pairs of one fill workgroup.  The scan over read splits reads the row maxima
 // four rows at a time (dwordx4, three independent loads per step), so it is not one dependent L2
 // round trip per row.  The first tile pair of every pair is offered to the table-driven replay: per
 // fusion of the workgroup the first offer fixes the (M1 tile, M2 tile) the tables will be built for.
-__global__ __launch_bounds__(WG_LANES) void k_combine(
+constexpr int TMASK_TILES = 16;   // tmask covers references of at most 16 tiles
+
+// device buffers of the finish stage, handed to the fill kernels as one argument
+struct FinishBufs {
+    PairState* state;
+    KeptRow* kept;
+    ReplayTask* tasks;
+    uint64_t* masks;
+    uint32_t* gtasks;
+    Counters* ctr;
+    uint64_t kept_cap, task_cap, mask_cap, gtask_cap;
+};
+
+// Runs in the workgroup that filled these pairs, right after its row maxima are written: every lane
+// re-reads only what it stored itself.  All threads of the workgroup must call it (barriers inside).
+// s_tile[k] returns the tile pair agreed for the table-driven replay of fusion group k (-1: none).
+__device__ __forceinline__ void combine_wg(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
     const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
-    const WgInfo* __restrict__ wginfo,
-    const uint32_t* __restrict__ wg_generic, PairState* __restrict__ state, KeptRow* __restrict__ kept,
-    uint64_t kept_cap, ReplayTask* __restrict__ tasks, uint64_t task_cap, uint64_t mask_cap,
-    uint32_t* __restrict__ gtasks, uint64_t gtask_cap, int32_t* __restrict__ wgtile, Counters* __restrict__ ctr, Geom g)
+    const WgInfo& wgi, bool fast_wg, int* s_tile, const FinishBufs& fb, const Geom& g)
 {
-    __shared__ int s_tile[GMAX];
+    PairState* __restrict__ state = fb.state;
+    KeptRow* __restrict__ kept = fb.kept;
+    ReplayTask* __restrict__ tasks = fb.tasks;
+    uint32_t* __restrict__ gtasks = fb.gtasks;
+    Counters* __restrict__ ctr = fb.ctr;
+    const uint64_t kept_cap = fb.kept_cap, task_cap = fb.task_cap, mask_cap = fb.mask_cap, gtask_cap = fb.gtask_cap;
     const int tid = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * WG_LANES + tid;
     const bool active = p < g.n_pairs;
@@ -732,8 +442,6 @@ __global__ __launch_bounds__(WG_LANES) void k_combine(
     }
     const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
     // offer the first tile pair to the table-driven replay
-    const WgInfo wgi = wginfo[blockIdx.x];
-    const bool fast_wg = wgi.n_groups > 0 && wg_generic[blockIdx.x] == 0;
     int gsel = -1;
 #pragma unroll
     for (int k = 0; k < GMAX; ++k)
@@ -747,7 +455,6 @@ __global__ __launch_bounds__(WG_LANES) void k_combine(
     if (key >= 0) atomicCAS(&s_tile[gsel], -1, key);
     __syncthreads();
     const bool fast = key >= 0 && s_tile[gsel] == key;
-    if (tid < GMAX) wgtile[(int64_t)blockIdx.x * GMAX + tid] = s_tile[tid];
     const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
 
     const unsigned long long kb = wave_alloc(&ctr->n_kept, (unsigned)n_kept);
@@ -764,7 +471,7 @@ __global__ __launch_bounds__(WG_LANES) void k_combine(
     st.pad_ = 0;
     if (n_kept > 0 && (kb + n_kept > kept_cap || tb + n_tasks > task_cap ||
                        mb + (unsigned long long)n_tasks * n_kept > mask_cap || gb + n_gen > gtask_cap)) {
-        st.n_kept = 0;     // overflow: the host sees the cursors, grows the buffers and reruns the finish stage
+        st.n_kept = 0;     // overflow: the host sees the cursors, grows the buffers and reruns the slice
         state[p] = st;
         return;
     }
@@ -828,137 +535,45 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
     }
 }
 
-// K3g: replay one tile pair per lane from the stored boundaries (generic scoring, any pair mix); for
-// every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
-// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Grid-stride over the device list
-// of tasks the table-driven kernel does not cover.
-__global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
-                                                   const uint32_t* __restrict__ gtasks, uint64_t gtask_cap,
-                                                   const Counters* __restrict__ ctr,
-                                                   const PairState* __restrict__ state,
-                                                   const KeptRow* __restrict__ kept, uint64_t kept_cap,
-                                                   const dsa_pair* __restrict__ pairs,
-                                                   const dsa_fusion* __restrict__ fusions,
-                                                   const uint32_t* __restrict__ refcodes,
-                                                   const uint32_t* __restrict__ rowcodes,
-                                                   const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
-                                                   uint64_t mask_cap, Geom g)
+// Table-driven replay (second tail of the fast fill kernel).  The first task of every pair of the
+// workgroup whose tile pair matches its fusion's agreed (M1 tile, M2 tile) is replayed with the same
+// LDS score tables as the fill (no row maxima, no stores: add + max3 per column).  Called by all
+// threads of the workgroup after combine_wg; T is free by then (barriers inside combine_wg).
+__device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, int* s_hist, unsigned short* s_order,
+                                               const WgInfo& wgi, const FinishBufs& fb,
+                                               const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
+                                               const uint32_t* __restrict__ refcodes, const uint32_t* __restrict__ rowcodes,
+                                               const uint32_t* __restrict__ bnd, const Geom& g)
 {
-    const unsigned long long n_g = ctr->n_gtasks;
-    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_g;
-         t += (unsigned long long)gridDim.x * blockDim.x) {
-        const ReplayTask rt = tasks[gtasks[t]];
-        const int64_t p = rt.pair;
-        const int64_t w = p >> 6;
-        const int lane = (int)(p & 63);
-        const bool has0 = rt.chunk0 != NO_CHUNK, has1 = rt.chunk1 != NO_CHUNK;
-        const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
-        const dsa_pair pr = pairs[p];
-        const dsa_fusion fu = fusions[pr.fusion_idx];
-        const PairState st = state[p];
-        const int lq = pr.read_len;
-        const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp;
-        const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
-        const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
-        const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
-        const KeptRow* kr = kept + st.kept_begin;
-
-        uint32_t r[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) {
-            const uint32_t lo = has0 ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
-            const uint32_t hi = has1 ? (rc[c1 * W + i] & 0xFFFF0000u) : (REF_PAD16 << 16);
-            r[i] = lo | hi;
-        }
-        uint32_t X[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-        uint32_t bprev = BIAS2;
-        const int R = rt.last_row & 0x7FFF;
-        const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
-        const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
-        // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
-        int k0 = 0, k1 = st.n_kept - 1;
-        uint32_t cj_next = rows[rowidx(1, lane)];
-        uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
-                          (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
-        for (int j = 1; j <= R; ++j) {
-            const uint32_t cj = cj_next;
-            const uint32_t bcur = b_next;
-            const int jn = j < R ? j + 1 : j;
-            cj_next = rows[rowidx(jn, lane)];
-            b_next = (c0 > 0 ? (bi0[rowidx(jn, lane)] & 0xFFFFu) : BIAS16) |
-                     (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
-            row_step(X, r, cj, bprev, bcur);
-            bprev = bcur;
-            record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
-        }
-        // sides that were not replayed report no columns
-        if (!has0)
-            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
-        if (!has1)
-            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
-    }
-}
-
-// K3f: table-driven replay.  One workgroup = the WG_LANES pairs of one fill workgroup; the first task of
-// every pair whose tile pair matches its fusion's agreed (M1 tile, M2 tile) is replayed here with
-// the same LDS score tables as the fast fill kernel (no row maxima, no stores: add + max3 per column).
-__global__ __launch_bounds__(WG_LANES, 4) void k_replay_fast(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
-                                                             const Counters* __restrict__ ctr,
-                                                             const PairState* __restrict__ state,
-                                                             const KeptRow* __restrict__ kept, uint64_t kept_cap,
-                                                             const dsa_pair* __restrict__ pairs,
-                                                             const dsa_fusion* __restrict__ fusions,
-                                                             const WgInfo* __restrict__ wginfo,
-                                                             const int32_t* __restrict__ wgtile,
-                                                             const uint32_t* __restrict__ refcodes,
-                                                             const uint32_t* __restrict__ rowcodes,
-                                                             const uint32_t* __restrict__ bnd,
-                                                             uint64_t* __restrict__ masks, uint64_t mask_cap,
-                                                             uint64_t gtask_cap, Geom g)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
-    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || ctr->n_gtasks > gtask_cap) return;
-    const WgInfo wgi = wginfo[blockIdx.x];
+    const PairState* __restrict__ state = fb.state;
+    const KeptRow* __restrict__ kept = fb.kept;
+    const ReplayTask* __restrict__ tasks = fb.tasks;
+    uint64_t* __restrict__ masks = fb.masks;
     int tile[GMAX];
     bool any = false;
 #pragma unroll
     for (int k = 0; k < GMAX; ++k) {
-        tile[k] = wgtile[(int64_t)blockIdx.x * GMAX + k];
+        tile[k] = s_tile[k];
         any |= tile[k] >= 0;
     }
     if (!any) return;                                   // uniform
     // tables for the agreed tile pair of every fusion of the workgroup
-    for (int e = threadIdx.x; e < wgi.n_groups * NCOMBO * W; e += WG_LANES) {
-        const int i = e & (W - 1);
-        const int combo = (e >> 6) % NCOMBO;
-        const int gi = (e >> 6) / NCOMBO;
+    build_tables(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
         int key = -1;
 #pragma unroll
         for (int k = 0; k < GMAX; ++k)
             if (k == gi) key = tile[k];
-        uint32_t val = 0;
+        q0 = q1 = REF_PAD16;                 // no tile agreed: nobody reads this group's table
         if (key >= 0) {
             const int c0 = key >> 8, c1 = key & 0xFF;
             const uint32_t* rc = refcodes + (int64_t)wgi.group_f[gi] * g.lrp;
-            const uint32_t q0 = c0 != NO_CHUNK ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
-            const uint32_t q1 = c1 != NO_CHUNK ? (rc[c1 * W + i] >> 16) : REF_PAD16;
-            const uint32_t cls_byte[NCLS] = {'A', 'C', 'T', 'G', 'N'};
-            int k1, k2;
-            table_row_classes(combo, k1, k2);
-            const uint32_t d0 = q0 == REF_PAD16 ? 0u : ((q0 >> 8) == cls_byte[k1] ? 4u : 1u);
-            const uint32_t d1 = q1 == REF_PAD16 ? 0u : ((q1 >> 8) == cls_byte[k2] ? 4u : 1u);
-            val = (d0 | (d1 << 16)) + (i > 0 ? TWO2 : 0u);
+            if (c0 != NO_CHUNK) q0 = rc[c0 * W + i] & 0xFFFFu;
+            if (c1 != NO_CHUNK) q1 = rc[c1 * W + i] >> 16;
         }
-        T[gi * TGROUP + combo * TROW + i] = val;
-    }
+    });
     // Lanes take the workgroup's tasks in order of their first kept read split, so that the lanes of
     // a wave reach their kept rows (where the column masks are extracted: ~400 instructions) together
     // and sweep about the same number of rows.  Counting sort in LDS; any tie order gives the same output.
-    __shared__ int s_hist[258];
-    __shared__ unsigned short s_order[WG_LANES];
     for (int e = threadIdx.x; e < 258; e += WG_LANES) s_hist[e] = 0;
     __syncthreads();
     int my_key = 256, my_rank = 0;
@@ -1081,6 +696,437 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_replay_fast(const ReplayTask* _
         for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
     if (has && !has1)
         for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1g: generic DP fill.  One wave = 64 pairs; 4 waves per workgroup.  Runs only the workgroups
+// flagged generic (exotic read bytes or more than GMAX fusions in the workgroup).
+//   cmax[((w*nch + c)*lq1 + j)*64 + lane] = max over the tile's valid columns of V(.,j)   (2 x u16, biased)
+//   bnd [((w*nch + c)*lq1 + j)*64 + lane] = V(last column of tile c, j)
+// ---------------------------------------------------------------------------------------------
+template <bool MASKED>
+__device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const uint4* __restrict__ rows4,
+                                                   const uint4* __restrict__ bi4, uint4* __restrict__ cm4,
+                                                   uint4* __restrict__ bo4, int lq, bool first, int nv0, int nv1)
+{
+    uint32_t X[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+    const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+    uint32_t bprev = BIAS2;
+    const int ngq = (lq >> 2) + 1;
+    uint4 rc_n = rows4[0];
+    uint4 b_n = first ? bias4 : bi4[0];
+    for (int gq = 0; gq < ngq; ++gq) {
+        const uint4 rc = rc_n, b = b_n;
+        const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
+        rc_n = rows4[(int64_t)gn * WAVE];
+        b_n = first ? bias4 : bi4[(int64_t)gn * WAVE];
+        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * gq + sidx;
+            if (j >= 1 && j <= lq) {                        // wave-uniform
+                row_step(X, r, rcv[sidx], bprev, bv[sidx]);
+                cmv[sidx] = tile_row_max<MASKED>(X, nv0, nv1);
+                bov[sidx] = X[W - 1] - drift2(W - 1);
+            }
+            bprev = bv[sidx];
+        }
+        cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
+        bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+    }
+}
+
+// After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
+// dword per row instead of one per tile; tmask = which tiles attain it (bit c: M1 tile c, bit 16+c:
+// M2 tile c; only meaningful while a reference has at most 16 tiles, the combine kernel falls back to
+// cmax otherwise).  cmax of this wave is L2-hot.
+__device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
+{
+    const uint32_t x = v ^ m;
+    return ((x & 0xFFFFu) == 0u ? (1u << c) : 0u) | ((x >> 16) == 0u ? (1u << (16 + c)) : 0u);
+}
+__device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
+                                               uint32_t* __restrict__ tmask, const Geom& g, int w, int lane,
+                                               int nch_wave, int lq)
+{
+    const int ngq = (lq >> 2) + 1;
+    uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
+    uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
+    const uint4* src = reinterpret_cast<const uint4*>(cmax + (int64_t)w * g.nch * g.lq1 * WAVE) + lane;
+    const int64_t cstride = (int64_t)(g.lq1 >> 2) * WAVE;       // uint4 elements between two tiles
+    constexpr int NC = 8;
+    if (nch_wave <= NC) {
+        // all tiles of a row group in registers: one round of independent loads, then max and masks
+        for (int gq = 0; gq < ngq; ++gq) {
+            uint4 v[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                v[c] = c < nch_wave ? src[c * cstride + (int64_t)gq * WAVE] : make_uint4(0, 0, 0, 0);
+            uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < nch_wave) {
+                    m.x = max2(m.x, v[c].x);
+                    m.y = max2(m.y, v[c].y);
+                    m.z = max2(m.z, v[c].z);
+                    m.w = max2(m.w, v[c].w);
+                }
+            uint4 t = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (c < nch_wave) {
+                    t.x |= eq_bits(v[c].x, m.x, c);
+                    t.y |= eq_bits(v[c].y, m.y, c);
+                    t.z |= eq_bits(v[c].z, m.z, c);
+                    t.w |= eq_bits(v[c].w, m.w, c);
+                }
+            out[(int64_t)gq * WAVE] = m;
+            tout[(int64_t)gq * WAVE] = t;
+        }
+        return;
+    }
+    for (int gq = 0; gq < ngq; ++gq) {
+        uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+        for (int c = 0; c < nch_wave; ++c) {
+            const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
+            m.x = max2(m.x, v.x);
+            m.y = max2(m.y, v.y);
+            m.z = max2(m.z, v.z);
+            m.w = max2(m.w, v.w);
+        }
+        out[(int64_t)gq * WAVE] = m;
+        if (nch_wave <= TMASK_TILES) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            for (int c = 0; c < nch_wave; ++c) {
+                const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
+                t.x |= eq_bits(v.x, m.x, c);
+                t.y |= eq_bits(v.y, m.y, c);
+                t.z |= eq_bits(v.z, m.z, c);
+                t.w |= eq_bits(v.w, m.w, c);
+            }
+            tout[(int64_t)gq * WAVE] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __restrict__ pairs,
+                                                           const WaveInfo* __restrict__ winfo,
+                                                           const WgInfo* __restrict__ wginfo,
+                                                           const dsa_fusion* __restrict__ fusions,
+                                                           const uint32_t* __restrict__ wg_generic,
+                                                           const uint32_t* __restrict__ refcodes,
+                                                           const uint32_t* __restrict__ rowcodes,
+                                                           const int32_t* __restrict__ min_score_tab,
+                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
+                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask,
+                                                           FinishBufs fb, Geom g)
+{
+    __shared__ int s_tile[GMAX];
+    if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup (uniform)
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
+    if (w < g.n_waves) {                         // whole waves past the end only join the combine barriers
+        const int lane = threadIdx.x & 63;
+        const int64_t p = min((int64_t)w * WAVE + lane, g.n_pairs - 1);   // tail lanes shadow the last pair
+        const WaveInfo wi = winfo[w];
+        const int f = pairs[p].fusion_idx;
+        const dsa_fusion fu = fusions[f];
+        const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
+        const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+
+        for (int c = 0; c < wi.nch_max; ++c) {
+            uint32_t r[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) r[i] = rc[c * W + i];
+            const int nv0 = fu.ref0_len - c * W, nv1 = fu.ref1_len - c * W;   // per lane; may be <= 0
+            uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+            uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+            const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
+            if (__builtin_amdgcn_ballot_w64(nv0 < W || nv1 < W) == 0)
+                sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
+            else
+                sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
+        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
+    }
+    const WgInfo wgi = wginfo[blockIdx.x];
+    combine_wg(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, s_tile, fb, g);   // every task goes to k_replay
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1f: fast DP fill (reads over {A,C,G,T,N}).  Per workgroup and tile, the substitution terms of
+// every fusion present are tabulated in LDS:
+//     T[g][k1*5+k2][i] = { d(ref0_g[i], base[k1]), d(rev(ref1_g)[i], base[k2]) },  d = eq ? 4 : 1
+// where k1/k2 are the classes of the M1 / M2 read base of the row.  Padded reference columns get
+// d = 0 (worse than a mismatch): their values can then reach but never exceed the row maximum of the
+// valid columns, so the tile row maximum needs no masking (the replay masks exclude them by index).
+// A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column; four rows share one
+// dwordx4 load of row codes / boundary and one dwordx4 store of tile maxima / boundary.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
+                                                           const WaveInfo* __restrict__ winfo,
+                                                           const WgInfo* __restrict__ wginfo,
+                                                           const uint32_t* __restrict__ wg_generic,
+                                                           const uint32_t* __restrict__ refcodes,
+                                                           const uint32_t* __restrict__ rowcodes,
+                                                           const int32_t* __restrict__ min_score_tab,
+                                                           const dsa_fusion* __restrict__ fusions,
+                                                           uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
+                                                           uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask,
+                                                           FinishBufs fb, Geom g)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
+    __shared__ int s_nch;
+    __shared__ int s_tile[GMAX];
+    __shared__ int s_hist[258];
+    __shared__ unsigned short s_order[WG_LANES];
+    if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
+    const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
+    const int lane = threadIdx.x & 63;
+    const WgInfo wgi = wginfo[blockIdx.x];
+    WaveInfo wi = {0, 0};
+    int f = 0;
+    // Exact pruning (DESIGN.md 4): a cell with V(i,j) < 4j - slack, slack = 2*Lq - minScore, can never
+    // feed a row maximum that takes part in a split of score >= minScore (each further row adds at most
+    // 4), and no live cell's value comes from a dead cell.  Once a whole tile row and everything that
+    // can still enter from the left are dead, the rest of the tile is dead: the sweep stops there and
+    // stores "V = 0" for the remaining rows (a lower bound, which is all dead cells need to be).
+    int lq_lane = 0, slack = 0;
+    if (live) {
+        wi = winfo[w];
+        const int64_t p = (int64_t)w * WAVE + lane;
+        f = pairs[min(p, g.n_pairs - 1)].fusion_idx;
+        if (p < g.n_pairs) {
+            lq_lane = pairs[p].read_len;
+            slack = 2 * lq_lane - min_score_tab[lq_lane];
+        }
+    }
+    auto wave_max = [](int v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+        return v;
+    };
+    // rows up to which the boundary entering the next tile may still be alive (tile 0: column 0, V = 0)
+    int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
+    if (threadIdx.x == 0) s_nch = 0;
+    __syncthreads();
+    if (lane == 0 && live) atomicMax(&s_nch, wi.nch_max);
+    __syncthreads();
+    const int nch_wg = s_nch;
+
+    int gsel = 0;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k)
+        if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
+    const uint32_t* tb = T + gsel * TGROUP;
+    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+
+    for (int c = 0; c < nch_wg; ++c) {
+#ifdef DSA_EXP_NOBARRIER
+        if (c == 0)
+#endif
+        __syncthreads();                          // previous tile's tables no longer in use
+#if defined(DSA_EXP_NOTABLE) || defined(DSA_EXP_NOBARRIER)
+        if (c == 0)
+#endif
+        build_tables(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
+            const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
+            q0 = code & 0xFFFFu;
+            q1 = code >> 16;
+        });
+#ifdef DSA_EXP_NOBARRIER
+        if (c == 0)
+#endif
+        __syncthreads();
+        if (!live || c >= wi.nch_max) continue;   // wave-uniform
+
+        uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
+        const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
+        uint32_t X[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+        uint32_t bprev = BIAS2;
+        const int ngq = (wi.lq_max >> 2) + 1;
+        uint4 rc_n = rows4[0];
+        uint4 b_n = (c == 0) ? bias4 : bi4[0];
+        int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
+        int gq = 0;
+        for (; gq < ngq; ++gq) {
+            const uint4 rc = rc_n, b = b_n;
+            const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
+            rc_n = rows4[(int64_t)gn * WAVE];
+            b_n = (c == 0) ? bias4 : bi4[(int64_t)gn * WAVE];
+            const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+            uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+            bool alive = false;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int j = 4 * gq + sidx;
+                const uint32_t bcur = bv[sidx];
+                if (j >= 1 && j <= wi.lq_max) {             // wave-uniform
+                    // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
+                    // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
+                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
+                    uint4 vq[FILL_PF + 1];                  // table reads in flight
+#ifdef DSA_ABLATE_LDS
+#define TROW_LD(k) make_uint4(rcv[sidx] + (k), 0x00060006u, 0x00030003u, 0x00060006u)
+#else
+#define TROW_LD(k) trow[k]
+#endif
+#pragma unroll
+                    for (int k = 0; k <= FILL_PF; ++k) vq[k] = TROW_LD(k);
+                    uint32_t a = bprev + vq[0].x;
+                    uint32_t up = bcur - TWO2;
+#pragma unroll
+                    for (int q = 0; q < W / 4; ++q) {
+                        const uint4 v = vq[0];
+#pragma unroll
+                        for (int k = 0; k < FILL_PF; ++k) vq[k] = vq[k + 1];
+                        if (q + 1 + FILL_PF < W / 4) vq[FILL_PF] = TROW_LD(q + 1 + FILL_PF);
+                        const uint4 vn = vq[0];
+                        uint32_t an;
+                        an = X[4 * q + 0] + v.y;
+                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                        a = an;
+                        an = X[4 * q + 1] + v.z;
+                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                        a = an;
+                        an = X[4 * q + 2] + v.w;
+                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                        a = an;
+                        an = X[4 * q + 3] + vn.x;
+                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                        a = an;
+                        up = X[4 * q + 3];
+                    }
+                    cmv[sidx] = tile_row_max<false>(X, W, W);
+                    bov[sidx] = X[W - 1] - drift2(W - 1);
+                    const int thr = 4 * j - slack + (int)BIAS16;
+                    const bool in_read = j <= lq_lane;
+                    alive |= in_read && ((int)(cmv[sidx] & 0xFFFFu) >= thr || (int)(cmv[sidx] >> 16) >= thr);
+                    if (in_read && ((int)(bov[sidx] & 0xFFFFu) >= thr || (int)(bov[sidx] >> 16) >= thr)) last_bnd = j;
+                }
+                bprev = bcur;
+            }
+#ifdef DSA_ABLATE_STORES
+            if (gq == ngq - 1) {
+#endif
+            cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
+            bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+#ifdef DSA_ABLATE_STORES
+            }
+#endif
+#ifndef DSA_NO_PRUNE
+            if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
+#endif
+        }
+#ifdef DSA_PRUNE_STATS
+        if (lane == 0) {
+            atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
+            atomicAdd(&g.stats[1], (unsigned long long)ngq);
+            atomicAdd(&g.stats[2], (unsigned long long)l_in);
+        }
+#endif
+#ifndef DSA_EXP_NODEADSTORE
+        for (; gq < ngq; ++gq) {                            // dead remainder of the tile
+            cm4[(int64_t)gq * WAVE] = bias4;
+            bo4[(int64_t)gq * WAVE] = bias4;
+        }
+#endif
+        l_in = wave_max(last_bnd);
+    }
+#ifndef DSA_ABLATE_TAIL
+    if (live) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
+        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
+    }
+    // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
+    // workgroups' sweeps, instead of in kernels of its own.
+    combine_wg(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, s_tile, fb, g);
+#ifndef DSA_ABLATE_REPLAY
+    replay_fast_wg(T, s_tile, s_hist, s_order, wgi, fb, pairs, fusions, refcodes, rowcodes, bnd, g);
+#endif
+#endif
+}
+
+// K3g: replay one tile pair per lane from the stored boundaries (generic scoring, any pair mix); for
+// every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
+// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Grid-stride over the device list
+// of tasks the table-driven kernel does not cover.
+__global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+                                                   const uint32_t* __restrict__ gtasks, uint64_t gtask_cap,
+                                                   const Counters* __restrict__ ctr,
+                                                   const PairState* __restrict__ state,
+                                                   const KeptRow* __restrict__ kept, uint64_t kept_cap,
+                                                   const dsa_pair* __restrict__ pairs,
+                                                   const dsa_fusion* __restrict__ fusions,
+                                                   const uint32_t* __restrict__ refcodes,
+                                                   const uint32_t* __restrict__ rowcodes,
+                                                   const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
+                                                   uint64_t mask_cap, Geom g)
+{
+    const unsigned long long n_g = ctr->n_gtasks;
+    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_g;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        const ReplayTask rt = tasks[gtasks[t]];
+        const int64_t p = rt.pair;
+        const int64_t w = p >> 6;
+        const int lane = (int)(p & 63);
+        const bool has0 = rt.chunk0 != NO_CHUNK, has1 = rt.chunk1 != NO_CHUNK;
+        const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
+        const dsa_pair pr = pairs[p];
+        const dsa_fusion fu = fusions[pr.fusion_idx];
+        const PairState st = state[p];
+        const int lq = pr.read_len;
+        const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp;
+        const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
+        const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
+        const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
+        const KeptRow* kr = kept + st.kept_begin;
+
+        uint32_t r[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t lo = has0 ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
+            const uint32_t hi = has1 ? (rc[c1 * W + i] & 0xFFFF0000u) : (REF_PAD16 << 16);
+            r[i] = lo | hi;
+        }
+        uint32_t X[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+        uint32_t bprev = BIAS2;
+        const int R = rt.last_row & 0x7FFF;
+        const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
+        const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
+        // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
+        int k0 = 0, k1 = st.n_kept - 1;
+        uint32_t cj_next = rows[rowidx(1, lane)];
+        uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
+                          (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+        for (int j = 1; j <= R; ++j) {
+            const uint32_t cj = cj_next;
+            const uint32_t bcur = b_next;
+            const int jn = j < R ? j + 1 : j;
+            cj_next = rows[rowidx(jn, lane)];
+            b_next = (c0 > 0 ? (bi0[rowidx(jn, lane)] & 0xFFFFu) : BIAS16) |
+                     (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+            row_step(X, r, cj, bprev, bcur);
+            bprev = bcur;
+            record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
+        }
+        // sides that were not replayed report no columns
+        if (!has0)
+            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
+        if (!has1)
+            for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
+    }
 }
 
 // K4: emit.  For every kept split a (ascending) the cross product columns1 x columns2 in ascending
