@@ -508,30 +508,89 @@ __device__ __forceinline__ void combine_wg(
     }
 }
 
-// Columns of the tile whose value at this row equals the kept row's maximum (either field).
+// Replay bookkeeping of one lane: the next kept row of either matrix, the row at which the sweep
+// meets it and the (biased) value its row maximum has there.  Kept rows ascend in a: M1 (row a) meets
+// them in order k = 0.., M2 (row lq-a) in reverse.
+struct HitCursor {
+    int k0, k1;
+    int row0, row1;        // -1: none left on that side
+    uint32_t t0, t1;
+    uint64_t valid0, valid1;   // columns of the tile that exist in the reference
+};
+__device__ __forceinline__ void cursor_next0(HitCursor& hc, const KeptRow* __restrict__ kr, int n_kept, bool has0)
+{
+    hc.row0 = -1;
+    if (has0 && hc.k0 < n_kept) {
+        const KeptRow r = kr[hc.k0];
+        hc.row0 = r.a;
+        hc.t0 = (uint32_t)(r.m1 + 2 * r.a) + BIAS16;
+    }
+}
+__device__ __forceinline__ void cursor_next1(HitCursor& hc, const KeptRow* __restrict__ kr, int lq, bool has1)
+{
+    hc.row1 = -1;
+    if (has1 && hc.k1 >= 0) {
+        const KeptRow r = kr[hc.k1];
+        hc.row1 = lq - r.a;
+        hc.t1 = (uint32_t)(r.m2 + 2 * (lq - r.a)) + BIAS16;
+    }
+}
+__device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr, int n_kept, int lq, bool has0, bool has1,
+                                                 int nv0, int nv1)
+{
+    HitCursor hc;
+    hc.k0 = 0;
+    hc.k1 = n_kept - 1;
+    hc.t0 = hc.t1 = 0;
+    hc.valid0 = nv0 >= W ? ~0ull : ((1ull << (nv0 > 0 ? nv0 : 0)) - 1ull);
+    hc.valid1 = nv1 >= W ? ~0ull : ((1ull << (nv1 > 0 ? nv1 : 0)) - 1ull);
+    cursor_next0(hc, kr, n_kept, has0);
+    cursor_next1(hc, kr, lq, has1);
+    return hc;
+}
+
+// Columns of the tile whose value at this row equals the given targets, both fields in one pass: per
+// column sub (drift) + xor (0 <=> equal) + pk_min(.,1) + shift-or into a miss-bit accumulator.
+__device__ __forceinline__ void equal_columns(const uint32_t (&X)[W], uint32_t target2, uint64_t& m0, uint64_t& m1)
+{
+    uint32_t miss[W / 16];
+#pragma unroll
+    for (int q = 0; q < W / 16; ++q) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = 16 * q + k;
+            const uint32_t e = (X[i] - drift2(i)) ^ target2;
+            const v2u one = {1, 1};
+            const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u, e), one));
+            acc |= y << k;         // bit k: lo field differs, bit 16+k: hi field differs
+        }
+        miss[q] = acc;
+    }
+    const uint32_t lo_a = (miss[0] & 0xFFFFu) | (miss[1] << 16), lo_b = (miss[2] & 0xFFFFu) | (miss[3] << 16);
+    const uint32_t hi_a = (miss[0] >> 16) | (miss[1] & 0xFFFF0000u), hi_b = (miss[2] >> 16) | (miss[3] & 0xFFFF0000u);
+    m0 = ~((uint64_t)lo_a | ((uint64_t)lo_b << 32));
+    m1 = ~((uint64_t)hi_a | ((uint64_t)hi_b << 32));
+}
+
+// At row j: report, for the kept rows met here, the valid columns that attain the row maximum.
 __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int lq, const KeptRow* __restrict__ kr,
-                                            int n_kept, bool has0, bool has1, int nv0, int nv1, int& k0, int& k1,
+                                            int n_kept, bool has0, bool has1, HitCursor& hc,
                                             uint64_t* __restrict__ masks, uint32_t mask_begin)
 {
-    const bool hit0 = has0 && k0 < n_kept && kr[k0].a == j;
-    const bool hit1 = has1 && k1 >= 0 && lq - kr[k1].a == j;
+    const bool hit0 = hc.row0 == j, hit1 = hc.row1 == j;
+    if (!(hit0 || hit1)) return;
+    uint64_t m0, m1;
+    equal_columns(X, (hit0 ? hc.t0 : 0xFFFFu) | ((hit1 ? hc.t1 : 0xFFFFu) << 16), m0, m1);
     if (hit0) {
-        const uint32_t target = (uint32_t)(kr[k0].m1 + 2 * j) + BIAS16;
-        uint64_t mask = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-            if (i < nv0 && (X[i] & 0xFFFFu) == target + 2u * i) mask |= (1ull << i);
-        masks[((uint64_t)mask_begin + k0) * 2] = mask;
-        ++k0;
+        masks[((uint64_t)mask_begin + hc.k0) * 2] = m0 & hc.valid0;
+        ++hc.k0;
+        cursor_next0(hc, kr, n_kept, has0);
     }
     if (hit1) {
-        const uint32_t target = (uint32_t)(kr[k1].m2 + 2 * j) + BIAS16;
-        uint64_t mask = 0;
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-            if (i < nv1 && (X[i] >> 16) == target + 2u * i) mask |= (1ull << i);
-        masks[((uint64_t)mask_begin + k1) * 2 + 1] = mask;
-        --k1;
+        masks[((uint64_t)mask_begin + hc.k1) * 2 + 1] = m1 & hc.valid1;
+        --hc.k1;
+        cursor_next1(hc, kr, lq, has1);
     }
 }
 
@@ -636,7 +695,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, i
     const int lq = pr.read_len;
     const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
     const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
-    int k0 = 0, k1 = st.n_kept - 1;
+    HitCursor hc = cursor_init(kr, has ? st.n_kept : 0, lq, has0, has1, nv0, nv1);
 
     uint32_t X[W];
 #pragma unroll
@@ -687,7 +746,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, i
                     up = X[4 * q + 3];
                     v = vn;
                 }
-                if (has && j <= R) record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
+                record_hits(X, j, lq, kr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
             }
             bprev = bcur;
         }
@@ -1106,7 +1165,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
-        int k0 = 0, k1 = st.n_kept - 1;
+        HitCursor hc = cursor_init(kr, st.n_kept, lq, has0, has1, nv0, nv1);
         uint32_t cj_next = rows[rowidx(1, lane)];
         uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
                           (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
@@ -1119,7 +1178,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                      (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
-            record_hits(X, j, lq, kr, st.n_kept, has0, has1, nv0, nv1, k0, k1, masks, rt.mask_begin);
+            record_hits(X, j, lq, kr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
         }
         // sides that were not replayed report no columns
         if (!has0)
