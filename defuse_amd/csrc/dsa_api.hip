@@ -68,6 +68,9 @@ struct PipeLane {
     DevBuf<uint32_t> d_gtasks;
     DevBuf<Counters> d_ctr;
     DevBuf<uint8_t> d_scan_tmp;
+#ifdef DSA_PRUNE_STATS
+    DevBuf<unsigned long long> d_stats;
+#endif
     void release()
     {
         d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_refcodes.release(); d_rowcodes.release();
@@ -270,7 +273,12 @@ FinishBufs finish_bufs(PipeLane& L)
 // count -> scan, then async copies of the cursors and the record total into the lane's pinned result
 int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
 {
-    const Geom g = s.g;
+    Geom g = s.g;
+#ifdef DSA_PRUNE_STATS
+    HIPC(L.d_stats.reserve(8));
+    HIPC(hipMemsetAsync(L.d_stats.p, 0, 8 * sizeof(unsigned long long), L.stream));
+    g.stats = L.d_stats.p;
+#endif
     hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
@@ -375,6 +383,14 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
         HIPC(L.d_gtasks.reserve(c.n_gtasks + 1024));
         if (int rc = launch_compute(ctx, L, s)) return rc;
     }
+#ifdef DSA_PRUNE_STATS
+    {
+        unsigned long long h[8];
+        HIPC(hipMemcpy(h, L.d_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu\n",
+                h[0], h[1], h[3], h[4], h[5], h[6]);
+    }
+#endif
     const int64_t n_rec = L.host->n_rec;
     if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
     ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);

@@ -331,13 +331,11 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int n)   // index of the 
     return m ? __builtin_ctzll(m) : -1;
 }
 
-// Combine (tail of the fill kernels): per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223), the kept rows that
-// have columns on both sides, and the tiles that hold a row maximum for them.  Single pass; space
-// comes from device cursors (capacities are checked by the host afterwards).
-// One block = the WG_LANES pairs of one fill workgroup.  The scan over read splits reads the row maxima
-// four rows at a time (dwordx4, three independent loads per step), so it is not one dependent L2
-// round trip per row.  The first tile pair of every pair is offered to the table-driven replay: per
-// fusion of the workgroup the first offer fixes the (M1 tile, M2 tile) the tables will be built for.
+// Combine (tail of the fill kernels): per pair, the winning read splits (tools/SplitReadAligner.cpp:194-223),
+// the kept rows that have columns on both sides, and the tiles that hold a row maximum for them.  Space
+// comes from device cursors (capacities are checked by the host afterwards).  The first tile pair of
+// every pair is offered to the table-driven replay: per fusion of the workgroup the first offer fixes
+// the (M1 tile, M2 tile) the tables will be built for.
 constexpr int TMASK_TILES = 16;   // tmask covers references of at most 16 tiles
 
 // device buffers of the finish stage, handed to the fill kernels as one argument
@@ -351,28 +349,73 @@ struct FinishBufs {
     uint64_t kept_cap, task_cap, mask_cap, gtask_cap;
 };
 
+// What combine hands to the table-driven replay of the same workgroup through LDS, so that the replay
+// starts without a chain of dependent global loads (state -> task -> kept row).
+struct LaneInfo {
+    uint32_t kept_begin, mask_begin;
+    uint16_t n_kept;
+    uint16_t last_row;        // bit 15 (TASK_FAST): the pair's first task is replayed by the workgroup
+    uint8_t  c0, c1;          // its tile pair (NO_CHUNK: side not replayed)
+    uint16_t first_a_group;   // first kept a (13 bits) | fusion group of the pair << 13
+    uint16_t lq;
+    uint8_t  nv0, nv1;        // valid columns of the two tiles
+};
+constexpr int KCACHE = 3;     // kept rows per pair that travel through LDS as well
+struct FinishLds {
+    int tile[GMAX];
+    int hist[258];
+    unsigned short order[WG_LANES];
+    LaneInfo info[WG_LANES];
+    uint64_t kc[KCACHE * WG_LANES];    // [k][thread], a KeptRow each
+};
+
+// four wave-aggregated allocations at once: the four atomics are in flight together
+__device__ __forceinline__ void wave_alloc4(Counters* ctr, const unsigned (&n)[4], unsigned long long (&base)[4])
+{
+    unsigned incl[4] = {n[0], n[1], n[2], n[3]};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned y = __shfl_up(incl[q], d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl[q] += y;
+        }
+    }
+    unsigned long long* const counter[4] = {&ctr->n_kept, &ctr->n_tasks, &ctr->n_masks, &ctr->n_gtasks};
+    unsigned long long b[4] = {0, 0, 0, 0};
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (incl[q]) b[q] = atomicAdd(counter[q], (unsigned long long)incl[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) base[q] = __shfl(b[q], 63, 64) + (incl[q] - n[q]);
+}
+
 // Runs in the workgroup that filled these pairs, right after its row maxima are written: every lane
 // re-reads only what it stored itself.  All threads of the workgroup must call it (barriers inside).
-// s_tile[k] returns the tile pair agreed for the table-driven replay of fusion group k (-1: none).
+// fl->tile[k] returns the tile pair agreed for the table-driven replay of fusion group k (-1: none);
+// HANDOFF also fills fl->info / fl->kc for replay_fast_wg.
+template <bool HANDOFF>
 __device__ __forceinline__ void combine_wg(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
     const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
-    const WgInfo& wgi, bool fast_wg, int* s_tile, const FinishBufs& fb, const Geom& g)
+    const WgInfo& wgi, bool fast_wg, FinishLds* fl, const FinishBufs& fb, const Geom& g)
 {
     PairState* __restrict__ state = fb.state;
     KeptRow* __restrict__ kept = fb.kept;
     ReplayTask* __restrict__ tasks = fb.tasks;
     uint32_t* __restrict__ gtasks = fb.gtasks;
-    Counters* __restrict__ ctr = fb.ctr;
     const uint64_t kept_cap = fb.kept_cap, task_cap = fb.task_cap, mask_cap = fb.mask_cap, gtask_cap = fb.gtask_cap;
     const int tid = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * WG_LANES + tid;
     const bool active = p < g.n_pairs;
     const int64_t w = p >> 6;
     const int lane = (int)(p & 63);
-    if (tid < GMAX) s_tile[tid] = -1;
+    if (tid < GMAX) fl->tile[tid] = -1;
     const uint32_t* rm = rmax + w * g.lq1 * WAVE;
     const uint4* rm4 = reinterpret_cast<const uint4*>(rm) + lane;
+    const uint4* tm4 = reinterpret_cast<const uint4*>(tmask + w * g.lq1 * WAVE) + lane;
     // FindMaxRowEntry's acceptance rule (tools/SplitReadAligner.cpp:91-102): below minSplitScore counts as 0
     auto accept = [](uint32_t word, int h, int n_chunks, int row) -> int {
         if (row == 0 || n_chunks == 0) return 0;   // H(i,0)=0 < 8; empty reference: only column 0 (<=0)
@@ -380,64 +423,121 @@ __device__ __forceinline__ void combine_wg(
         return v >= DSA_MIN_SPLIT ? v : 0;
     };
     auto rowmax = [&](int h, int n_chunks, int row) -> int { return accept(rm[rowidx(row, lane)], h, n_chunks, row); };
-    int lq = 0, nc0 = 0, nc1 = 0, max_score = 0, n_kept = 0, fidx = -1;
+    auto pick = [](const uint4& v, int k) -> uint32_t { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; };
+    int lq = 0, nc0 = 0, nc1 = 0, max_score = 0, n_kept = 0, fidx = -1, len0 = 0, len1 = 0;
     unsigned n_t0 = 0, n_t1 = 0;
     uint64_t tiles0 = 0, tiles1 = 0;     // tiles that attain the maximum at some kept row
     bool small = true;                   // references with more than 64 tiles replay every tile (exact, not minimal)
     int first_a = 0, last_a = 0;
+    uint64_t kcr[KCACHE] = {};           // the first kept rows (one-pass scan only)
+    int n_cached = 0;
     if (active) {
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
         fidx = pr.fusion_idx;
         lq = pr.read_len;
+        len0 = fu.ref0_len;
+        len1 = fu.ref1_len;
         nc0 = cdiv_dev(fu.ref0_len, W);
         nc1 = cdiv_dev(fu.ref1_len, W);
         small = nc0 <= 64 && nc1 <= 64;
         const int min_score = min_score_tab[lq];
-        // visits every read split a with m1(a), m2(lq-a); four splits per step from three dwordx4 loads
-        auto for_each_split = [&](auto&& fn) {
-            for (int gq = 0; 4 * gq <= lq; ++gq) {
+        if (g.nch <= TMASK_TILES) {
+            // One pass over the read splits a, four per step: row maxima and winning-tile masks of the rows
+            // a and lq-a come from six dwordx4 loads, issued two steps ahead (no dependent round trips).
+            struct Step { uint4 x, yh, yl, tx, th, tl; };
+            const int ng = lq >> 2;
+            auto load = [&](int gq) -> Step {
+                gq = gq < ng ? gq : ng;
                 const int b_hi = lq - 4 * gq, b_lo = b_hi - 3;
-                const uint4 x1 = rm4[(int64_t)gq * WAVE];
-                const uint4 y_hi = rm4[(int64_t)(b_hi >> 2) * WAVE];
-                const uint4 y_lo = rm4[(int64_t)((b_lo > 0 ? b_lo : 0) >> 2) * WAVE];
-                const uint32_t xv[4] = {x1.x, x1.y, x1.z, x1.w};
-                const uint32_t yh[4] = {y_hi.x, y_hi.y, y_hi.z, y_hi.w}, yl[4] = {y_lo.x, y_lo.y, y_lo.z, y_lo.w};
+                const int64_t ih = (int64_t)(b_hi >> 2) * WAVE, il = (int64_t)((b_lo > 0 ? b_lo : 0) >> 2) * WAVE;
+                Step s;
+                s.x = rm4[(int64_t)gq * WAVE];
+                s.yh = rm4[ih];
+                s.yl = rm4[il];
+                s.tx = tm4[(int64_t)gq * WAVE];
+                s.th = tm4[ih];
+                s.tl = tm4[il];
+                return s;
+            };
+            Step s0 = load(0), s1 = load(1);
+            for (int gq = 0; gq <= ng; ++gq) {
+                const Step cur = s0;
+                s0 = s1;
+                s1 = load(gq + 2);
+                const int b_hi = lq - 4 * gq;
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) {
                     const int a = 4 * gq + sidx, b = lq - a;
-                    if (b >= 0) {
-                        const uint32_t yw = (b >> 2) == (b_hi >> 2) ? yh[b & 3] : yl[b & 3];
-                        fn(a, b, accept(xv[sidx], 0, nc0, a), accept(yw, 1, nc1, b));
+                    if (b < 0) continue;
+                    const bool in_hi = (b >> 2) == (b_hi >> 2);
+                    const uint32_t yw = in_hi ? pick(cur.yh, b & 3) : pick(cur.yl, b & 3);
+                    const int m1 = accept(pick(cur.x, sidx), 0, nc0, a), m2 = accept(yw, 1, nc1, b);
+                    const int sc = m1 + m2;
+                    if (sc < min_score || sc < max_score) continue;
+                    if (sc > max_score) {        // a better split: forget the kept rows so far
+                        max_score = sc;
+                        n_kept = 0;
+                        tiles0 = tiles1 = 0;
+                    }
+                    if (m1 == 0 || m2 == 0) continue;   // an empty side emits nothing
+                    if (n_kept == 0) first_a = a;
+                    last_a = a;
+                    KeptRow kr;
+                    kr.a = (int16_t)a;
+                    kr.m1 = (int16_t)m1;
+                    kr.m2 = (int16_t)m2;
+                    kr.pad_ = 0;
+#pragma unroll
+                    for (int k = 0; k < KCACHE; ++k)
+                        if (n_kept == k) kcr[k] = __builtin_bit_cast(uint64_t, kr);
+                    ++n_kept;
+                    tiles0 |= pick(cur.tx, sidx) & 0xFFFFu;
+                    tiles1 |= (in_hi ? pick(cur.th, b & 3) : pick(cur.tl, b & 3)) >> 16;
+                }
+            }
+            n_cached = n_kept < KCACHE ? n_kept : KCACHE;
+        } else {
+            // long references: two passes, the winning tiles looked up in the per-tile maxima
+            auto for_each_split = [&](auto&& fn) {
+                for (int gq = 0; 4 * gq <= lq; ++gq) {
+                    const int b_hi = lq - 4 * gq, b_lo = b_hi - 3;
+                    const uint4 x1 = rm4[(int64_t)gq * WAVE];
+                    const uint4 y_hi = rm4[(int64_t)(b_hi >> 2) * WAVE];
+                    const uint4 y_lo = rm4[(int64_t)((b_lo > 0 ? b_lo : 0) >> 2) * WAVE];
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        const int a = 4 * gq + sidx, b = lq - a;
+                        if (b >= 0) {
+                            const uint32_t yw = (b >> 2) == (b_hi >> 2) ? pick(y_hi, b & 3) : pick(y_lo, b & 3);
+                            fn(a, b, accept(pick(x1, sidx), 0, nc0, a), accept(yw, 1, nc1, b));
+                        }
                     }
                 }
-            }
-        };
-        for_each_split([&](int, int, int m1, int m2) {
-            const int sc = m1 + m2;
-            if (sc >= min_score && sc > max_score) max_score = sc;
-        });
-        if (max_score != 0) {
-            first_a = lq;
-            for_each_split([&](int a, int b, int m1, int m2) {
-                if (m1 + m2 != max_score || m1 == 0 || m2 == 0) return;   // an empty side emits nothing
-                if (n_kept == 0) first_a = a;
-                last_a = a;
-                ++n_kept;
-                if (g.nch <= TMASK_TILES) {          // the fill kernel already tabulated the winning tiles
-                    tiles0 |= tmask[w * g.lq1 * WAVE + rowidx(a, lane)] & 0xFFFFu;
-                    tiles1 |= tmask[w * g.lq1 * WAVE + rowidx(b, lane)] >> 16;
-                } else if (small) {
-                    for (int c = 0; c < nc0; ++c)
-                        if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(a, lane)], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
-                    for (int c = 0; c < nc1; ++c)
-                        if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(b, lane)], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
-                }
+            };
+            for_each_split([&](int, int, int m1, int m2) {
+                const int sc = m1 + m2;
+                if (sc >= min_score && sc > max_score) max_score = sc;
             });
-            if (n_kept > 0) {
-                n_t0 = small ? (unsigned)__builtin_popcountll(tiles0) : (unsigned)nc0;
-                n_t1 = small ? (unsigned)__builtin_popcountll(tiles1) : (unsigned)nc1;
+            if (max_score != 0) {
+                first_a = lq;
+                for_each_split([&](int a, int b, int m1, int m2) {
+                    if (m1 + m2 != max_score || m1 == 0 || m2 == 0) return;   // an empty side emits nothing
+                    if (n_kept == 0) first_a = a;
+                    last_a = a;
+                    ++n_kept;
+                    if (small) {
+                        for (int c = 0; c < nc0; ++c)
+                            if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(a, lane)], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
+                        for (int c = 0; c < nc1; ++c)
+                            if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(b, lane)], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
+                    }
+                });
             }
+        }
+        if (n_kept > 0) {
+            n_t0 = small ? (unsigned)__builtin_popcountll(tiles0) : (unsigned)nc0;
+            n_t1 = small ? (unsigned)__builtin_popcountll(tiles1) : (unsigned)nc1;
         }
     }
     const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
@@ -452,33 +552,56 @@ __device__ __forceinline__ void combine_wg(
         key = ((c0 >= 0 ? c0 : (int)NO_CHUNK) << 8) | (c1 >= 0 ? c1 : (int)NO_CHUNK);
     }
     __syncthreads();
-    if (key >= 0) atomicCAS(&s_tile[gsel], -1, key);
+    if (key >= 0) atomicCAS(&fl->tile[gsel], -1, key);
     __syncthreads();
-    const bool fast = key >= 0 && s_tile[gsel] == key;
+    bool fast = key >= 0 && fl->tile[gsel] == key;
     const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
 
-    const unsigned long long kb = wave_alloc(&ctr->n_kept, (unsigned)n_kept);
-    const unsigned long long tb = wave_alloc(&ctr->n_tasks, n_tasks);
-    const unsigned long long mb = wave_alloc(&ctr->n_masks, n_tasks * (unsigned)n_kept);
-    const unsigned long long gb = wave_alloc(&ctr->n_gtasks, n_gen);
+    const unsigned want[4] = {(unsigned)n_kept, n_tasks, n_tasks * (unsigned)n_kept, n_gen};
+    unsigned long long base[4];
+    wave_alloc4(fb.ctr, want, base);
+    const unsigned long long kb = base[0], tb = base[1], mb = base[2], gb = base[3];
+    bool ok = active && n_kept > 0;
+    if (ok && (kb + n_kept > kept_cap || tb + n_tasks > task_cap || mb + (unsigned long long)n_tasks * n_kept > mask_cap ||
+               gb + n_gen > gtask_cap))
+        ok = false;        // overflow: the host sees the cursors, grows the buffers and reruns the slice
+    if (HANDOFF) {
+        LaneInfo li;
+        li.kept_begin = (uint32_t)kb;
+        li.mask_begin = (uint32_t)mb;
+        li.n_kept = (uint16_t)(ok ? n_kept : 0);
+        const int c0 = (key >> 8) & 0xFF, c1 = key & 0xFF;
+        const bool here = ok && fast;
+        const int r0 = c0 != NO_CHUNK ? last_a : 0, r1 = c1 != NO_CHUNK ? lq - first_a : 0;
+        li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST) : (uint16_t)0;
+        li.c0 = here ? (uint8_t)c0 : NO_CHUNK;
+        li.c1 = here ? (uint8_t)c1 : NO_CHUNK;
+        li.first_a_group = (uint16_t)((first_a & 0x1FFF) | ((gsel >= 0 ? gsel : 0) << 13));
+        li.lq = (uint16_t)lq;
+        const int v0 = len0 - c0 * W, v1 = len1 - c1 * W;
+        li.nv0 = (uint8_t)(here && c0 != NO_CHUNK ? (v0 < W ? (v0 > 0 ? v0 : 0) : W) : 0);
+        li.nv1 = (uint8_t)(here && c1 != NO_CHUNK ? (v1 < W ? (v1 > 0 ? v1 : 0) : W) : 0);
+        fl->info[tid] = li;
+    }
     if (!active) return;
     PairState st;
     st.max_score = max_score;
-    st.n_kept = n_kept;
+    st.n_kept = ok ? n_kept : 0;
     st.kept_begin = (uint32_t)kb;
     st.task_begin = (uint32_t)tb;
     st.n_tasks = n_tasks;
     st.pad_ = 0;
-    if (n_kept > 0 && (kb + n_kept > kept_cap || tb + n_tasks > task_cap ||
-                       mb + (unsigned long long)n_tasks * n_kept > mask_cap || gb + n_gen > gtask_cap)) {
-        st.n_kept = 0;     // overflow: the host sees the cursors, grows the buffers and reruns the slice
-        state[p] = st;
-        return;
-    }
     state[p] = st;
-    if (n_kept == 0) return;
-    int k = 0;
-    for (int a = first_a; a <= last_a; ++a) {
+    if (!ok) return;
+    // kept rows: the first ones are still in registers, the rest is re-read
+    int k = 0, a_next = first_a;
+    for (; k < n_cached; ++k) {
+        const KeptRow kr = __builtin_bit_cast(KeptRow, k == 0 ? kcr[0] : k == 1 ? kcr[1] : kcr[KCACHE - 1]);
+        kept[kb + k] = kr;
+        if (HANDOFF) fl->kc[k * WG_LANES + tid] = __builtin_bit_cast(uint64_t, kr);
+        a_next = kr.a + 1;
+    }
+    for (int a = a_next; k < n_kept && a <= last_a; ++a) {
         const int m1 = rowmax(0, nc0, a), m2 = rowmax(1, nc1, lq - a);
         if (m1 + m2 != max_score || m1 == 0 || m2 == 0) continue;
         KeptRow kr;
@@ -487,6 +610,7 @@ __device__ __forceinline__ void combine_wg(
         kr.m2 = (int16_t)m2;
         kr.pad_ = 0;
         kept[kb + k] = kr;
+        if (HANDOFF && k < KCACHE) fl->kc[k * WG_LANES + tid] = __builtin_bit_cast(uint64_t, kr);
         ++k;
     }
     unsigned gi = 0;
@@ -510,33 +634,39 @@ __device__ __forceinline__ void combine_wg(
 
 // Replay bookkeeping of one lane: the next kept row of either matrix, the row at which the sweep
 // meets it and the (biased) value its row maximum has there.  Kept rows ascend in a: M1 (row a) meets
-// them in order k = 0.., M2 (row lq-a) in reverse.
+// them in order k = 0.., M2 (row lq-a) in reverse.  The first KCACHE kept rows may come from LDS
+// (kc != nullptr: kc[k * WG_LANES] is kept row k of the pair).
 struct HitCursor {
     int k0, k1;
     int row0, row1;        // -1: none left on that side
     uint32_t t0, t1;
     uint64_t valid0, valid1;   // columns of the tile that exist in the reference
 };
-__device__ __forceinline__ void cursor_next0(HitCursor& hc, const KeptRow* __restrict__ kr, int n_kept, bool has0)
+__device__ __forceinline__ KeptRow kept_row(const KeptRow* __restrict__ kr, const uint64_t* kc, int k)
+{
+    if (kc != nullptr && k < KCACHE) return __builtin_bit_cast(KeptRow, kc[k * WG_LANES]);
+    return kr[k];
+}
+__device__ __forceinline__ void cursor_next0(HitCursor& hc, const KeptRow* __restrict__ kr, const uint64_t* kc, int n_kept, bool has0)
 {
     hc.row0 = -1;
     if (has0 && hc.k0 < n_kept) {
-        const KeptRow r = kr[hc.k0];
+        const KeptRow r = kept_row(kr, kc, hc.k0);
         hc.row0 = r.a;
         hc.t0 = (uint32_t)(r.m1 + 2 * r.a) + BIAS16;
     }
 }
-__device__ __forceinline__ void cursor_next1(HitCursor& hc, const KeptRow* __restrict__ kr, int lq, bool has1)
+__device__ __forceinline__ void cursor_next1(HitCursor& hc, const KeptRow* __restrict__ kr, const uint64_t* kc, int lq, bool has1)
 {
     hc.row1 = -1;
     if (has1 && hc.k1 >= 0) {
-        const KeptRow r = kr[hc.k1];
+        const KeptRow r = kept_row(kr, kc, hc.k1);
         hc.row1 = lq - r.a;
         hc.t1 = (uint32_t)(r.m2 + 2 * (lq - r.a)) + BIAS16;
     }
 }
-__device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr, int n_kept, int lq, bool has0, bool has1,
-                                                 int nv0, int nv1)
+__device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr, const uint64_t* kc, int n_kept, int lq,
+                                                 bool has0, bool has1, int nv0, int nv1)
 {
     HitCursor hc;
     hc.k0 = 0;
@@ -544,8 +674,8 @@ __device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr,
     hc.t0 = hc.t1 = 0;
     hc.valid0 = nv0 >= W ? ~0ull : ((1ull << (nv0 > 0 ? nv0 : 0)) - 1ull);
     hc.valid1 = nv1 >= W ? ~0ull : ((1ull << (nv1 > 0 ? nv1 : 0)) - 1ull);
-    cursor_next0(hc, kr, n_kept, has0);
-    cursor_next1(hc, kr, lq, has1);
+    cursor_next0(hc, kr, kc, n_kept, has0);
+    cursor_next1(hc, kr, kc, lq, has1);
     return hc;
 }
 
@@ -575,7 +705,7 @@ __device__ __forceinline__ void equal_columns(const uint32_t (&X)[W], uint32_t t
 
 // At row j: report, for the kept rows met here, the valid columns that attain the row maximum.
 __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int lq, const KeptRow* __restrict__ kr,
-                                            int n_kept, bool has0, bool has1, HitCursor& hc,
+                                            const uint64_t* kc, int n_kept, bool has0, bool has1, HitCursor& hc,
                                             uint64_t* __restrict__ masks, uint32_t mask_begin)
 {
     const bool hit0 = hc.row0 == j, hit1 = hc.row1 == j;
@@ -585,34 +715,31 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
     if (hit0) {
         masks[((uint64_t)mask_begin + hc.k0) * 2] = m0 & hc.valid0;
         ++hc.k0;
-        cursor_next0(hc, kr, n_kept, has0);
+        cursor_next0(hc, kr, kc, n_kept, has0);
     }
     if (hit1) {
         masks[((uint64_t)mask_begin + hc.k1) * 2 + 1] = m1 & hc.valid1;
         --hc.k1;
-        cursor_next1(hc, kr, lq, has1);
+        cursor_next1(hc, kr, kc, lq, has1);
     }
 }
 
 // Table-driven replay (second tail of the fast fill kernel).  The first task of every pair of the
 // workgroup whose tile pair matches its fusion's agreed (M1 tile, M2 tile) is replayed with the same
 // LDS score tables as the fill (no row maxima, no stores: add + max3 per column).  Called by all
-// threads of the workgroup after combine_wg; T is free by then (barriers inside combine_wg).
-__device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, int* s_hist, unsigned short* s_order,
-                                               const WgInfo& wgi, const FinishBufs& fb,
-                                               const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
+// threads of the workgroup after combine_wg<true>, whose LDS hand-off (fl) says what to replay; T is
+// free by then (barriers inside combine_wg).
+__device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const WgInfo& wgi, const FinishBufs& fb,
                                                const uint32_t* __restrict__ refcodes, const uint32_t* __restrict__ rowcodes,
                                                const uint32_t* __restrict__ bnd, const Geom& g)
 {
-    const PairState* __restrict__ state = fb.state;
     const KeptRow* __restrict__ kept = fb.kept;
-    const ReplayTask* __restrict__ tasks = fb.tasks;
     uint64_t* __restrict__ masks = fb.masks;
     int tile[GMAX];
     bool any = false;
 #pragma unroll
     for (int k = 0; k < GMAX; ++k) {
-        tile[k] = s_tile[k];
+        tile[k] = fl->tile[k];
         any |= tile[k] >= 0;
     }
     if (!any) return;                                   // uniform
@@ -631,71 +758,52 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, i
         }
     });
     // Lanes take the workgroup's tasks in order of their first kept read split, so that the lanes of
-    // a wave reach their kept rows (where the column masks are extracted: ~400 instructions) together
-    // and sweep about the same number of rows.  Counting sort in LDS; any tie order gives the same output.
-    for (int e = threadIdx.x; e < 258; e += WG_LANES) s_hist[e] = 0;
-    __syncthreads();
+    // a wave reach their kept rows (where the column masks are extracted) together and sweep about
+    // the same number of rows.  Counting sort in LDS; any tie order gives the same output.
+    for (int e = threadIdx.x; e < 258; e += WG_LANES) fl->hist[e] = 0;
+    __syncthreads();                                    // also: info / kc of combine_wg are complete
     int my_key = 256, my_rank = 0;
     {
-        const int64_t q = (int64_t)blockIdx.x * WG_LANES + threadIdx.x;
-        if (q < g.n_pairs) {
-            const PairState sq = state[q];
-            if (sq.n_kept > 0 && sq.n_tasks > 0 && (tasks[sq.task_begin].last_row & TASK_FAST))
-                my_key = min((int)kept[sq.kept_begin].a, 255);
-        }
-        my_rank = atomicAdd(&s_hist[my_key], 1);
+        const LaneInfo mine = fl->info[threadIdx.x];
+        if (mine.last_row & TASK_FAST) my_key = min((int)(mine.first_a_group & 0x1FFF), 255);
+        my_rank = atomicAdd(&fl->hist[my_key], 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
         for (int e = 0; e < 257; ++e) {
-            const int n = s_hist[e];
-            s_hist[e] = run;
+            const int n = fl->hist[e];
+            fl->hist[e] = run;
             run += n;
         }
     }
     __syncthreads();
-    s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
+    fl->order[fl->hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
     __syncthreads();
 
-    const int64_t p = (int64_t)blockIdx.x * WG_LANES + s_order[threadIdx.x];
+    const int src = fl->order[threadIdx.x];
+    const LaneInfo li = fl->info[src];
+    const int64_t p = (int64_t)blockIdx.x * WG_LANES + src;
     const int lane = (int)(p & 63);
     const int64_t w = p >> 6;
-    bool has = false;
-    PairState st{};
-    ReplayTask rt{};
-    dsa_pair pr{};
-    dsa_fusion fu{};
-    if (p < g.n_pairs) {
-        st = state[p];
-        if (st.n_kept > 0 && st.n_tasks > 0) {
-            rt = tasks[st.task_begin];
-            has = (rt.last_row & TASK_FAST) != 0;
-        }
-        pr = pairs[p];
-        fu = fusions[pr.fusion_idx];
-    }
-    const int R = has ? (rt.last_row & 0x7FFF) : 0;
+    const bool has = (li.last_row & TASK_FAST) != 0;
+    const int R = has ? (li.last_row & 0x7FFF) : 0;
     int Rw = R;                                          // wave maximum
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) Rw = max(Rw, __shfl_xor(Rw, d, 64));
     if (Rw == 0) return;                                  // wave-uniform; no barriers below
-    const bool has0 = has && rt.chunk0 != NO_CHUNK, has1 = has && rt.chunk1 != NO_CHUNK;
-    const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
-    int gsel = 0;
-#pragma unroll
-    for (int k = 0; k < GMAX; ++k)
-        if (k < wgi.n_groups && wgi.group_f[k] == pr.fusion_idx) gsel = k;
-    const uint32_t* tb = T + gsel * TGROUP;
+    const bool has0 = has && li.c0 != NO_CHUNK, has1 = has && li.c1 != NO_CHUNK;
+    const int c0 = has0 ? li.c0 : 0, c1 = has1 ? li.c1 : 0;
+    const uint32_t* tb = T + (li.first_a_group >> 13) * TGROUP;
     const int64_t wr = w < g.n_waves ? w : (int64_t)blockIdx.x * WG_WAVES;   // idle lanes read a valid plane
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + wr * g.lq1 * WAVE) + lane;
     const uint4* bi0 = reinterpret_cast<const uint4*>(bnd + (wr * g.nch + (c0 - 1)) * g.lq1 * WAVE) + lane;
     const uint4* bi1 = reinterpret_cast<const uint4*>(bnd + (wr * g.nch + (c1 - 1)) * g.lq1 * WAVE) + lane;
-    const KeptRow* kr = kept + st.kept_begin;
-    const int lq = pr.read_len;
-    const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
-    const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
-    HitCursor hc = cursor_init(kr, has ? st.n_kept : 0, lq, has0, has1, nv0, nv1);
+    const KeptRow* kr = kept + li.kept_begin;
+    const uint64_t* kc = fl->kc + src;
+    const int lq = li.lq;
+    const int n_kept = has ? li.n_kept : 0;
+    HitCursor hc = cursor_init(kr, kc, n_kept, lq, has0, has1, li.nv0, li.nv1);
 
     uint32_t X[W];
 #pragma unroll
@@ -746,15 +854,15 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, const int* s_tile, i
                     up = X[4 * q + 3];
                     v = vn;
                 }
-                record_hits(X, j, lq, kr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+                record_hits(X, j, lq, kr, kc, n_kept, has0, has1, hc, masks, li.mask_begin);
             }
             bprev = bcur;
         }
     }
     if (has && !has0)
-        for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
+        for (int k = 0; k < n_kept; ++k) masks[((uint64_t)li.mask_begin + k) * 2] = 0;
     if (has && !has1)
-        for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
+        for (int k = 0; k < n_kept; ++k) masks[((uint64_t)li.mask_begin + k) * 2 + 1] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -883,7 +991,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                                                            uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask,
                                                            FinishBufs fb, Geom g)
 {
-    __shared__ int s_tile[GMAX];
+    __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     if (w < g.n_waves) {                         // whole waves past the end only join the combine barriers
@@ -912,7 +1020,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
     }
     const WgInfo wgi = wginfo[blockIdx.x];
-    combine_wg(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, s_tile, fb, g);   // every task goes to k_replay
+    combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -939,9 +1047,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 {
     __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
     __shared__ int s_nch;
-    __shared__ int s_tile[GMAX];
-    __shared__ int s_hist[258];
-    __shared__ unsigned short s_order[WG_LANES];
+    __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
@@ -984,11 +1090,20 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     const uint32_t* tb = T + gsel * TGROUP;
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
 
+#ifdef DSA_PRUNE_STATS
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    unsigned long long t_bar = 0, t_tab = 0;
+#define STAT_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define STAT_T(x)
+#endif
     for (int c = 0; c < nch_wg; ++c) {
+        STAT_T(ts0);
 #ifdef DSA_EXP_NOBARRIER
         if (c == 0)
 #endif
         __syncthreads();                          // previous tile's tables no longer in use
+        STAT_T(ts1);
 #if defined(DSA_EXP_NOTABLE) || defined(DSA_EXP_NOBARRIER)
         if (c == 0)
 #endif
@@ -997,10 +1112,15 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             q0 = code & 0xFFFFu;
             q1 = code >> 16;
         });
+        STAT_T(ts2);
 #ifdef DSA_EXP_NOBARRIER
         if (c == 0)
 #endif
         __syncthreads();
+#ifdef DSA_PRUNE_STATS
+        t_bar += (ts1 - ts0) + (__builtin_readcyclecounter() - ts2);
+        t_tab += ts2 - ts1;
+#endif
         if (!live || c >= wi.nch_max) continue;   // wave-uniform
 
         uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
@@ -1100,6 +1220,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 #endif
         l_in = wave_max(last_bnd);
     }
+    STAT_T(t_tail);
 #ifndef DSA_ABLATE_TAIL
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
@@ -1107,10 +1228,19 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     }
     // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
     // workgroups' sweeps, instead of in kernels of its own.
-    combine_wg(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, s_tile, fb, g);
+    combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, &fl, fb, g);
 #ifndef DSA_ABLATE_REPLAY
-    replay_fast_wg(T, s_tile, s_hist, s_order, wgi, fb, pairs, fusions, refcodes, rowcodes, bnd, g);
+    replay_fast_wg(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
 #endif
+#endif
+#ifdef DSA_PRUNE_STATS
+    if (lane == 0 && live) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicAdd(&g.stats[3], t_end - t_begin);
+        atomicAdd(&g.stats[4], t_bar);
+        atomicAdd(&g.stats[5], t_tab);
+        atomicAdd(&g.stats[6], t_end - t_tail);
+    }
 #endif
 }
 
@@ -1165,7 +1295,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
-        HitCursor hc = cursor_init(kr, st.n_kept, lq, has0, has1, nv0, nv1);
+        HitCursor hc = cursor_init(kr, nullptr, st.n_kept, lq, has0, has1, nv0, nv1);
         uint32_t cj_next = rows[rowidx(1, lane)];
         uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
                           (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
@@ -1178,7 +1308,7 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                      (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
-            record_hits(X, j, lq, kr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+            record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
         }
         // sides that were not replayed report no columns
         if (!has0)
