@@ -68,6 +68,7 @@ struct PipeLane {
     DevBuf<uint32_t> d_gtasks;
     DevBuf<Counters> d_ctr;
     DevBuf<uint8_t> d_scan_tmp;
+    DevBuf<int32_t> d_tstop;
 #ifdef DSA_PRUNE_STATS
     DevBuf<unsigned long long> d_stats;
 #endif
@@ -76,7 +77,7 @@ struct PipeLane {
         d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_refcodes.release(); d_rowcodes.release();
         d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
         d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
-        d_ctr.release(); d_scan_tmp.release();
+        d_ctr.release(); d_scan_tmp.release(); d_tstop.release();
     }
 };
 
@@ -266,6 +267,7 @@ FinishBufs finish_bufs(PipeLane& L)
     fb.task_cap = L.d_tasks.cap;
     fb.mask_cap = L.d_masks.cap / 2;
     fb.gtask_cap = L.d_gtasks.cap;
+    fb.tstop = L.d_tstop.p;
     return fb;
 }
 
@@ -275,8 +277,8 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
 {
     Geom g = s.g;
 #ifdef DSA_PRUNE_STATS
-    HIPC(L.d_stats.reserve(8));
-    HIPC(hipMemsetAsync(L.d_stats.p, 0, 8 * sizeof(unsigned long long), L.stream));
+    HIPC(L.d_stats.reserve(16));
+    HIPC(hipMemsetAsync(L.d_stats.p, 0, 16 * sizeof(unsigned long long), L.stream));
     g.stats = L.d_stats.p;
 #endif
     hipStream_t st = L.stream;
@@ -296,7 +298,7 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipEventRecord(L.ev[2], st));
     hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
-                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
+                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
     hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p,
                        L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr, (uint64_t)0,
                        (int64_t)s.pair_begin, g);
@@ -328,6 +330,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_cmax.reserve(n_rows * g.nch));
     HIPC(L.d_rmax.reserve(n_rows));
     HIPC(L.d_tmask.reserve(n_rows));
+    HIPC(L.d_tstop.reserve((size_t)g.n_waves * g.nch));
     HIPC(L.d_state.reserve(np));
     HIPC(L.d_rec_count.reserve(np + 1));
     HIPC(L.d_rec_offset.reserve(np + 1));
@@ -385,10 +388,10 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     }
 #ifdef DSA_PRUNE_STATS
     {
-        unsigned long long h[8];
+        unsigned long long h[16];
         HIPC(hipMemcpy(h, L.d_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu\n",
-                h[0], h[1], h[3], h[4], h[5], h[6]);
+        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu)\n",
+                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
     }
 #endif
     const int64_t n_rec = L.host->n_rec;

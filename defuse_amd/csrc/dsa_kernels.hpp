@@ -347,7 +347,12 @@ struct FinishBufs {
     uint32_t* gtasks;
     Counters* ctr;
     uint64_t kept_cap, task_cap, mask_cap, gtask_cap;
+    int32_t* tstop;        // [wave][tile]: row groups of the tile whose bnd / cmax were stored (the rest is dead)
 };
+
+// tstop is read in the kernel that writes it, by other lanes and waves of the workgroup: bypass the
+// vector L1, whose lines may predate the store
+__device__ __forceinline__ int load_tstop(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // What combine hands to the table-driven replay of the same workgroup through LDS, so that the replay
 // starts without a chain of dependent global loads (state -> task -> kept row).
@@ -527,10 +532,13 @@ __device__ __forceinline__ void combine_wg(
                     last_a = a;
                     ++n_kept;
                     if (small) {
+                        auto tile_max = [&](int c, int row) -> uint32_t {      // rows past the tile's stop are dead (V = 0)
+                            return (row >> 2) < load_tstop(fb.tstop + w * g.nch + c) ? cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(row, lane)] : BIAS2;
+                        };
                         for (int c = 0; c < nc0; ++c)
-                            if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(a, lane)], 0) == m1 + 2 * a) tiles0 |= 1ull << c;
+                            if (half_of(tile_max(c, a), 0) == m1 + 2 * a) tiles0 |= 1ull << c;
                         for (int c = 0; c < nc1; ++c)
-                            if (half_of(cmax[(w * g.nch + c) * g.lq1 * WAVE + rowidx(b, lane)], 1) == m2 + 2 * b) tiles1 |= 1ull << c;
+                            if (half_of(tile_max(c, b), 1) == m2 + 2 * b) tiles1 |= 1ull << c;
                     }
                 });
             }
@@ -804,6 +812,8 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
     const int lq = li.lq;
     const int n_kept = has ? li.n_kept : 0;
     HitCursor hc = cursor_init(kr, kc, n_kept, lq, has0, has1, li.nv0, li.nv1);
+    const int stop0 = c0 > 0 ? load_tstop(fb.tstop + wr * g.nch + (c0 - 1)) : 0;   // stored row groups of the tiles to the left
+    const int stop1 = c1 > 0 ? load_tstop(fb.tstop + wr * g.nch + (c1 - 1)) : 0;
 
     uint32_t X[W];
 #pragma unroll
@@ -812,8 +822,8 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
     uint32_t bprev = BIAS2;
     const int ngq = (Rw >> 2) + 1;
     auto boundary = [&](int gq) -> uint4 {
-        const uint4 x0 = c0 > 0 ? bi0[(int64_t)gq * WAVE] : bias4;
-        const uint4 x1 = c1 > 0 ? bi1[(int64_t)gq * WAVE] : bias4;
+        const uint4 x0 = gq < stop0 ? bi0[(int64_t)gq * WAVE] : bias4;
+        const uint4 x1 = gq < stop1 ? bi1[(int64_t)gq * WAVE] : bias4;
         return make_uint4((x0.x & 0xFFFFu) | (x1.x & 0xFFFF0000u), (x0.y & 0xFFFFu) | (x1.y & 0xFFFF0000u),
                           (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
     };
@@ -915,11 +925,13 @@ __device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
     const uint32_t x = v ^ m;
     return ((x & 0xFFFFu) == 0u ? (1u << c) : 0u) | ((x >> 16) == 0u ? (1u << (16 + c)) : 0u);
 }
+struct TileStops { int v[8]; };    // stored row groups of a wave's first tiles (wave-uniform)
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
-                                               uint32_t* __restrict__ tmask, const Geom& g, int w, int lane,
-                                               int nch_wave, int lq)
+                                               uint32_t* __restrict__ tmask, const int32_t* tstop, const TileStops& stops,
+                                               const Geom& g, int w, int lane, int nch_wave, int lq)
 {
     const int ngq = (lq >> 2) + 1;
+    const uint4 dead4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);   // what the rows past a tile's stop stand for
     uint4* out = reinterpret_cast<uint4*>(rmax + (int64_t)w * g.lq1 * WAVE) + lane;
     uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
     const uint4* src = reinterpret_cast<const uint4*>(cmax + (int64_t)w * g.nch * g.lq1 * WAVE) + lane;
@@ -931,7 +943,7 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
             uint4 v[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
-                v[c] = c < nch_wave ? src[c * cstride + (int64_t)gq * WAVE] : make_uint4(0, 0, 0, 0);
+                v[c] = c < nch_wave ? (gq < stops.v[c] ? src[c * cstride + (int64_t)gq * WAVE] : dead4) : make_uint4(0, 0, 0, 0);
             uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
 #pragma unroll
             for (int c = 0; c < NC; ++c)
@@ -958,7 +970,7 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
     for (int gq = 0; gq < ngq; ++gq) {
         uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         for (int c = 0; c < nch_wave; ++c) {
-            const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
+            const uint4 v = gq < load_tstop(tstop + (int64_t)w * g.nch + c) ? src[c * cstride + (int64_t)gq * WAVE] : dead4;
             m.x = max2(m.x, v.x);
             m.y = max2(m.y, v.y);
             m.z = max2(m.z, v.z);
@@ -968,7 +980,7 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
         if (nch_wave <= TMASK_TILES) {
             uint4 t = make_uint4(0, 0, 0, 0);
             for (int c = 0; c < nch_wave; ++c) {
-                const uint4 v = src[c * cstride + (int64_t)gq * WAVE];
+                const uint4 v = gq < load_tstop(tstop + (int64_t)w * g.nch + c) ? src[c * cstride + (int64_t)gq * WAVE] : dead4;
                 t.x |= eq_bits(v.x, m.x, c);
                 t.y |= eq_bits(v.y, m.y, c);
                 t.z |= eq_bits(v.z, m.z, c);
@@ -1015,9 +1027,13 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                 sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
             else
                 sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
+            if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = (wi.lq_max >> 2) + 1;    // no pruning here: every row group is stored
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
+        TileStops all;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) all.v[k] = (wi.lq_max >> 2) + 1;
+        reduce_row_max(cmax, rmax, tmask, fb.tstop, all, g, w, lane, wi.nch_max, wi.lq_max);
     }
     const WgInfo wgi = wginfo[blockIdx.x];
     combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
@@ -1089,6 +1105,8 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
         if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
     const uint32_t* tb = T + gsel * TGROUP;
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+    int stop_prev = 0;                   // stored row groups of the tile to the left
+    TileStops stops = {};
 
 #ifdef DSA_PRUNE_STATS
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -1133,14 +1151,14 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
         uint32_t bprev = BIAS2;
         const int ngq = (wi.lq_max >> 2) + 1;
         uint4 rc_n = rows4[0];
-        uint4 b_n = (c == 0) ? bias4 : bi4[0];
+        uint4 b_n = (c == 0) ? bias4 : bi4[0];              // every tile stores at least its first row group
         int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
         int gq = 0;
         for (; gq < ngq; ++gq) {
             const uint4 rc = rc_n, b = b_n;
             const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
             rc_n = rows4[(int64_t)gn * WAVE];
-            b_n = (c == 0) ? bias4 : bi4[(int64_t)gn * WAVE];
+            b_n = gn < stop_prev ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
             const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
             uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
             bool alive = false;
@@ -1212,23 +1230,25 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             atomicAdd(&g.stats[2], (unsigned long long)l_in);
         }
 #endif
-#ifndef DSA_EXP_NODEADSTORE
-        for (; gq < ngq; ++gq) {                            // dead remainder of the tile
-            cm4[(int64_t)gq * WAVE] = bias4;
-            bo4[(int64_t)gq * WAVE] = bias4;
-        }
-#endif
+        // the dead remainder of the tile is not stored: its readers substitute V = 0 past the stop
+        if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = gq;
+        stop_prev = gq;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k == c) stops.v[k] = gq;
         l_in = wave_max(last_bnd);
     }
     STAT_T(t_tail);
 #ifndef DSA_ABLATE_TAIL
     if (live) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, tmask, g, w, lane, wi.nch_max, wi.lq_max);
+        reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
+    STAT_T(t_comb);
     // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
     // workgroups' sweeps, instead of in kernels of its own.
     combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, &fl, fb, g);
+    STAT_T(t_rep);
 #ifndef DSA_ABLATE_REPLAY
     replay_fast_wg(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
 #endif
@@ -1240,6 +1260,11 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
         atomicAdd(&g.stats[4], t_bar);
         atomicAdd(&g.stats[5], t_tab);
         atomicAdd(&g.stats[6], t_end - t_tail);
+#ifndef DSA_ABLATE_TAIL
+        atomicAdd(&g.stats[7], t_comb - t_tail);
+        atomicAdd(&g.stats[8], t_rep - t_comb);
+        atomicAdd(&g.stats[9], t_end - t_rep);
+#endif
     }
 #endif
 }
@@ -1257,8 +1282,8 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                                                    const dsa_fusion* __restrict__ fusions,
                                                    const uint32_t* __restrict__ refcodes,
                                                    const uint32_t* __restrict__ rowcodes,
-                                                   const uint32_t* __restrict__ bnd, uint64_t* __restrict__ masks,
-                                                   uint64_t mask_cap, Geom g)
+                                                   const uint32_t* __restrict__ bnd, const int32_t* __restrict__ tstop,
+                                                   uint64_t* __restrict__ masks, uint64_t mask_cap, Geom g)
 {
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
@@ -1297,15 +1322,19 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
         HitCursor hc = cursor_init(kr, nullptr, st.n_kept, lq, has0, has1, nv0, nv1);
         uint32_t cj_next = rows[rowidx(1, lane)];
-        uint32_t b_next = (c0 > 0 ? (bi0[rowidx(1, lane)] & 0xFFFFu) : BIAS16) |
-                          (c1 > 0 ? (bi1[rowidx(1, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+        const int stop0 = c0 > 0 ? tstop[w * g.nch + (c0 - 1)] : 0;   // stored row groups of the tiles to the left
+        const int stop1 = c1 > 0 ? tstop[w * g.nch + (c1 - 1)] : 0;
+        auto boundary = [&](int j) -> uint32_t {
+            return ((j >> 2) < stop0 ? (bi0[rowidx(j, lane)] & 0xFFFFu) : BIAS16) |
+                   ((j >> 2) < stop1 ? (bi1[rowidx(j, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+        };
+        uint32_t b_next = boundary(1);
         for (int j = 1; j <= R; ++j) {
             const uint32_t cj = cj_next;
             const uint32_t bcur = b_next;
             const int jn = j < R ? j + 1 : j;
             cj_next = rows[rowidx(jn, lane)];
-            b_next = (c0 > 0 ? (bi0[rowidx(jn, lane)] & 0xFFFFu) : BIAS16) |
-                     (c1 > 0 ? (bi1[rowidx(jn, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+            b_next = boundary(jn);
             row_step(X, r, cj, bprev, bcur);
             bprev = bcur;
             record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);

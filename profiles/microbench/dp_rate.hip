@@ -3,7 +3,7 @@
 //   MODE 0: score operand from a register        (pure VALU ceiling of the pattern)
 //   MODE 1: score operand from LDS tables, one ds_read_b128 per 4 columns, 2 reads in flight (as k_fill_fast)
 //   MODE 2: as 1, plus one dwordx4 load and two dwordx4 stores per 4 rows (the kernel's HBM streams)
-// Prints nominal-2.4-GHz cycles per (wave, column, row) at 4 waves per SIMD; k_fill_fast needs ~21.
+// Prints nominal-2.4-GHz cycles per (wave, column, row) at 4 (then 3, 2, 1) waves per SIMD.
 // hipcc --offload-arch=gfx950 -O3 -o dp_rate dp_rate.hip && ./dp_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -82,9 +82,11 @@ __global__ __launch_bounds__(256, 4) void k_dp(uint32_t* out, const uint4* in, u
 }
 
 template <int MODE>
-void run(const char* name)
+void run(const char* name, int wg_per_cu = 4)
 {
-    const int grid = 1024 * 4;   // 4 rounds of 4 workgroups per CU
+    const int grid = 256 * wg_per_cu * 4;   // 4 rounds of wg_per_cu workgroups per CU
+    // dynamic LDS pads the workgroup so that only wg_per_cu of them fit a CU (160 KB)
+    const size_t pad = wg_per_cu >= 4 ? 0 : (size_t)(160 * 1024 / wg_per_cu) - 27200 - 2048;
     uint32_t* out;
     uint4 *in, *st;
     hipMalloc(&out, (size_t)grid * 256 * 4);
@@ -94,16 +96,17 @@ void run(const char* name)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    k_dp<MODE><<<grid, 256>>>(out, in, st, 1);
+    hipFuncSetAttribute((const void*)k_dp<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    k_dp<MODE><<<grid, 256, pad>>>(out, in, st, 1);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k_dp<MODE><<<grid, 256>>>(out, in, st, 1);
+    k_dp<MODE><<<grid, 256, pad>>>(out, in, st, 1);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double colsteps_per_simd = (double)grid * 4 / 1024.0 * ROWS * W;
-    printf("%-28s %8.3f ms  %6.2f nominal cycles per column step\n", name, ms, ms * 1e-3 * 2.4e9 / colsteps_per_simd);
+    printf("%-24s %d waves/SIMD %8.3f ms  %6.2f nominal cycles per column step\n", name, wg_per_cu, ms, ms * 1e-3 * 2.4e9 / colsteps_per_simd);
     hipFree(out);
     hipFree(in);
     hipFree(st);
@@ -114,5 +117,6 @@ int main()
     run<0>("registers only");
     run<1>("+ LDS score tables");
     run<2>("+ HBM row streams");
+    for (int n = 3; n >= 1; --n) run<2>("+ HBM row streams", n);
     return 0;
 }
