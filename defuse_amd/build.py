@@ -31,14 +31,15 @@ def _run(cmd):
 
 def build_lib(force=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h")]
+           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h")]
     if force or _newer(LIB, srcs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip")])
+              "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip"),
+              os.path.join(CSRC, "la_api.hip")])
     return LIB
 
 
-TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs"]
+TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign"]
 
 
 def build_tools(force=False):
@@ -51,7 +52,8 @@ def build_tools(force=False):
         src = os.path.join(ROOT, "tools_src", t + ".cpp")
         out = os.path.join(bindir, t)
         deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
-                os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"), lib]
+                os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
+                os.path.join(ROOT, "include", "defuse_la.h"), lib]
         if force or _newer(out, deps):
             _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out, src, lib,
                   "-Wl,-rpath,$ORIGIN/../defuse_amd"])

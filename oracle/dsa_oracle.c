@@ -244,3 +244,37 @@ void ora_row_maxima(const uint8_t* ref, int lr, const uint8_t* read, int lq, int
     }
     free(m);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * localalign.  Restates SimpleAligner::Align, tools/SimpleAligner.cpp:24-64: the
+ * same full-matrix sweep (i outer over the reference, j inner over the sequence), row 0 (j == 0) all
+ * zero, column 0 (i == 0) j*gap, exact byte comparison, the running maximum taken over the cells with
+ * i >= 1 and j >= 1 only and started at 0.  Parity unpinned: the reference holds no test or golden
+ * output for this tool and its sources need Boost headers (Common.h) that this image lacks; the tests
+ * cross-check this restatement against an independently written recursion instead.
+ * ---------------------------------------------------------------------------------------------- */
+int ora_simple_align(int match, int mismatch, int gap, const uint8_t* reference, int lr, const uint8_t* sequence, int ls)
+{
+    const int length = lr + 1, height = ls + 1;
+    int* m = (int*)malloc(sizeof(int) * (size_t)length * (size_t)height);
+    int overall = 0;
+    for (int i = 0; i < length; i++) {
+        for (int j = 0; j < height; j++) {
+            if (j == 0) {
+                M(m, length, i, j) = 0;
+            } else if (i == 0) {
+                M(m, length, i, j) = M(m, length, i, j - 1) + gap;
+            } else {
+                int diag = M(m, length, i - 1, j - 1) + (reference[i - 1] == sequence[j - 1] ? match : mismatch);
+                int gap_ref = M(m, length, i - 1, j) + gap;
+                int gap_read = M(m, length, i, j - 1) + gap;
+                int best = gap_ref > gap_read ? gap_ref : gap_read;
+                if (diag > best) best = diag;
+                if (best > overall) overall = best;
+                M(m, length, i, j) = best;
+            }
+        }
+    }
+    free(m);
+    return overall;
+}

@@ -102,11 +102,17 @@ inline int pack_id(int index, int end) { return (int)(((uint32_t)index & 0x7FFFF
 // ---------------------------------------------------------------------------------------------
 class CmdLine {
 public:
-    struct Arg { std::string flag, name, desc, type; std::string value; bool set = false; };
+    struct Arg { std::string flag, name, desc, type; std::string value; bool set = false; bool required = true; };
     CmdLine(std::string message, std::string version = "none") : message_(std::move(message)), version_(std::move(version)) {}
     void add(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type)
     {
-        args_.push_back({flag, name, desc, type, "", false});
+        args_.push_back({flag, name, desc, type, "", false, true});
+    }
+    // an argument that may be left out (tclap ValueArg with req = false): keeps its default then
+    void add_optional(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type,
+                      const std::string& default_value)
+    {
+        args_.push_back({flag, name, desc, type, default_value, false, false});
     }
     void parse(int argc, char** argv)
     {
@@ -124,12 +130,12 @@ public:
             if (i + 1 >= argc) fail("Argument: " + id(*a), "Missing a value for this argument!");
             a->value = argv[++i];
             a->set = true;
-            if (a->type == "integer") { int v; if (!strict_int(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
+            if (a->type == "integer" || a->type == "int") { int v; if (!strict_int(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
             if (a->type == "float") { double v; if (!strict_double(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
         }
         std::string missing;
         for (const Arg& a : args_)
-            if (!a.set) missing += (missing.empty() ? "" : ", ") + a.name;
+            if (!a.set && a.required) missing += (missing.empty() ? "" : ", ") + a.name;
         if (!missing.empty()) fail("", "Required arguments missing: " + missing);
     }
     std::string str(const std::string& name) const { return get(name).value; }
@@ -165,7 +171,7 @@ private:
     void short_usage(std::ostream& os) const
     {
         os << "   " << prog_;
-        for (const Arg& a : args_) os << " -" << a.flag << " <" << a.type << ">";
+        for (const Arg& a : args_) os << (a.required ? " -" : " [-") << a.flag << " <" << a.type << ">" << (a.required ? "" : "]");
         os << " [--] [--version] [-h]" << std::endl;
     }
     void usage(std::ostream& os) const
@@ -175,7 +181,7 @@ private:
         os << std::endl << std::endl << "Where: " << std::endl << std::endl;
         for (const Arg& a : args_)
             os << "   -" << a.flag << " <" << a.type << ">,  --" << a.name << " <" << a.type << ">" << std::endl
-               << "     (required)  " << a.desc << std::endl << std::endl;
+               << "     " << (a.required ? "(required)  " : "") << a.desc << std::endl << std::endl;
         os << "   --,  --ignore_rest" << std::endl << "     Ignores the rest of the labeled arguments following this flag." << std::endl << std::endl
            << "   --version" << std::endl << "     Displays version information and exits." << std::endl << std::endl
            << "   -h,  --help" << std::endl << "     Displays usage information and exits." << std::endl << std::endl << std::endl

@@ -1,0 +1,83 @@
+// localalign — drop-in replacement of the reference tool (tools/localalign.cpp:31-92): same command
+// line (-m match, -x mismatch, -g gap, optional -t threshold), stdin lines `id \t reference \t sequence`,
+// stdout lines `id \t score \t percent` for the pairs whose percent reaches the threshold.  The scores
+// (SimpleAligner::Align, tools/SimpleAligner.cpp:24-64) come from the GPU through include/defuse_la.h;
+// there is no CPU fallback: without a HIP device the tool exits 1.
+#include "../include/defuse_la.h"
+#include "defuse_host.hpp"
+
+using namespace defuse;
+
+namespace {
+
+struct Batch {
+    std::vector<std::string> ids;
+    std::vector<la_item> items;
+    std::vector<uint8_t> pool;
+};
+
+// scores the batch and writes its lines; the reference prints each line as soon as it has read it, so a
+// later input error still leaves the earlier lines on stdout
+void flush(Batch& b, int matchScore, int misMatchScore, int gapScore, double threshold)
+{
+    if (b.items.empty()) return;
+    std::vector<int32_t> scores(b.items.size());
+    const char* dev = std::getenv("DEFUSE_GPU");          // as the other tools: device ordinal, default 0
+    const int device = dev ? std::atoi(dev) : 0;
+    if (la_align_batch(device, matchScore, misMatchScore, gapScore, b.pool.data(), (int64_t)b.pool.size(), b.items.data(),
+                       (int64_t)b.items.size(), scores.data(), nullptr) != 0)
+        die(std::string("Error: GPU alignment failed: ") + la_last_error());
+    for (size_t k = 0; k < b.items.size(); ++k) {
+        const int score = scores[k];
+        const int maxScore = (size_t)b.items[k].seq_len * matchScore;      // tools/localalign.cpp:86
+        const double percent = (double)score / (double)maxScore;
+        if (percent < threshold) continue;
+        std::cout << b.ids[k] << "\t" << score << "\t" << percent << std::endl;
+    }
+    b = Batch();
+}
+
+}  // namespace
+
+int main(int argc, char* argv[])
+{
+    CmdLine cmd("Local realignment tool");
+    cmd.add("m", "match", "Match Score", "int");
+    cmd.add("x", "mismatch", "Mismatch Score", "int");
+    cmd.add("g", "gap", "Gap Score", "int");
+    cmd.add_optional("t", "threshold", "Percent Perfect Threshold", "float", "0");
+    cmd.parse(argc, argv);
+    const int matchScore = cmd.integer("match"), misMatchScore = cmd.integer("mismatch"), gapScore = cmd.integer("gap");
+    const double threshold = cmd.real("threshold");
+
+    Batch batch;
+    const size_t flush_bytes = (size_t)1 << 30;           // bounds host memory on very large inputs
+    std::string line;
+    int lineNumber = 0;
+    while (std::getline(std::cin, line)) {
+        lineNumber++;
+        if (line.length() == 0) {
+            flush(batch, matchScore, misMatchScore, gapScore, threshold);
+            std::cerr << "Error: Empty line " << lineNumber << std::endl;
+            return 1;
+        }
+        std::vector<std::string> f = split_tabs(line);
+        if (f.size() < 3) {
+            flush(batch, matchScore, misMatchScore, gapScore, threshold);
+            std::cerr << "Error: Format error for line " << lineNumber << std::endl;
+            return 1;
+        }
+        la_item it;
+        it.ref_off = (int64_t)batch.pool.size();
+        it.ref_len = (int32_t)f[1].size();
+        batch.pool.insert(batch.pool.end(), f[1].begin(), f[1].end());
+        it.seq_off = (int64_t)batch.pool.size();
+        it.seq_len = (int32_t)f[2].size();
+        batch.pool.insert(batch.pool.end(), f[2].begin(), f[2].end());
+        batch.items.push_back(it);
+        batch.ids.push_back(f[0]);
+        if (batch.pool.size() >= flush_bytes) flush(batch, matchScore, misMatchScore, gapScore, threshold);
+    }
+    flush(batch, matchScore, misMatchScore, gapScore, threshold);
+    return 0;
+}
