@@ -154,6 +154,7 @@ def main():
             "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)) * max(1, t.fill_launches),
                          "finish": float(np.mean(finish_ms))},
             "replay_tiles_per_align": round(t.n_replay_tasks / len(pairs), 4),
+            "generic_replay_tiles_per_align": round(t.n_generic_tasks / len(pairs), 4),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, fus, reads, pairs)

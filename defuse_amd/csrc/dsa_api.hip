@@ -290,13 +290,13 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipEventRecord(L.ev[1], st));
     // every workgroup is run by exactly one of the two fill kernels
     hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,
-                       L.d_wg_generic.p, L.d_refcodes.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_wg_generic.p, L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     HIPC(hipEventRecord(L.ev[2], st));
-    hipLaunchKernelGGL(k_replay, dim3(256 * 4), dim3(256), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
+    hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
                        L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
     hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p,
@@ -347,9 +347,6 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
         int64_t total = (int64_t)g.n_fusions * g.lrp;
         hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
                            L.d_refcodes.p, g);
-        total = (int64_t)n_rows / 4;
-        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_reads.p, pairs,
-                           L.d_rowcodes.p, L.d_wg_generic.p, g);
     }
     HIPC(hipEventRecord(L.ev[4], st));      // end of pack (ev[1] is re-recorded by every launch_compute)
     if (int rc = launch_compute(ctx, L, s)) return rc;
@@ -390,8 +387,8 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     {
         unsigned long long h[16];
         HIPC(hipMemcpy(h, L.d_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu)\n",
-                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu); generic replay: %llu waves, setup %llu, sweep %llu cycles, %llu row groups (lane 0)\n",
+                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11], h[13]);
     }
 #endif
     const int64_t n_rec = L.host->n_rec;
@@ -409,6 +406,7 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     ctx->timing.finish_ms += elapsed(L.ev[2], L.ev[3]);
     ctx->timing.fill_launches += 1;
     ctx->timing.n_replay_tasks += (int64_t)L.host->ctr.n_tasks;
+    ctx->timing.n_generic_tasks += (int32_t)L.host->ctr.n_gtasks;
     L.slice = -1;
     return DSA_OK;
 }

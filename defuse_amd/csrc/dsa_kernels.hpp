@@ -130,6 +130,8 @@ struct ReplayTask {
     uint16_t last_row;     // largest row either matrix needs; bit 15 = replayed by the table-driven kernel
     uint8_t  chunk0;       // NO_CHUNK = nothing to replay on that side
     uint8_t  chunk1;
+    uint16_t first_a;      // first kept read split of the pair: the generic replay sorts its lanes by it
+    uint16_t pad_;
 };
 constexpr uint16_t TASK_FAST = 0x8000u;
 
@@ -228,36 +230,33 @@ __device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_gro
     }
 }
 
-// one thread = four consecutive rows of one pair (one dwordx4 of the rowcodes plane)
-__global__ void k_pack_rows(const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
-                            uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ wg_generic, Geom g)
+// Row codes of one wave's pairs, written by the wave itself in the prologue of the fill kernels (each lane
+// its own pair, four rows per dwordx4).  Returns whether the lane met a read byte outside {A,C,G,T,N}.
+__device__ __forceinline__ bool pack_rows_wave(const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
+                                               uint32_t* __restrict__ rowcodes, const Geom& g, int w, int lane, int lq_wave)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lq4 = g.lq1 >> 2;
-    int64_t total = (int64_t)g.n_waves * lq4 * WAVE;
-    if (t >= total) return;
-    const int lane = (int)(t & 63);
-    const int gq = (int)((t >> 6) % lq4);
-    const int w = (int)((t >> 6) / lq4);
     const int64_t p = (int64_t)w * WAVE + lane;
-    uint32_t out[4];
-    bool exotic = false;
+    const bool valid = p < g.n_pairs;
     dsa_pair pr{};
-    if (p < g.n_pairs) pr = pairs[p];
+    if (valid) pr = pairs[p];
+    uint4* out = reinterpret_cast<uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+    bool exotic = false;
+    for (int gq = 0; gq <= (lq_wave >> 2); ++gq) {
+        uint32_t code[4];
 #pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-        const int j = 4 * gq + sidx;
-        uint32_t code = ROW_PAD16 | (ROW_PAD16 << 16);
-        if (p < g.n_pairs && j >= 1 && j <= pr.read_len) {
-            const uint32_t b0 = read_bytes[(int64_t)pr.read_off + (j - 1)];
-            const uint32_t b1 = read_bytes[(int64_t)pr.read_off + (pr.read_len - j)];
-            exotic |= !is_fast_base(b0);                       // b1 is some other row's b0
-            code = (b0 << 8) | (b1 << 24) | table_row(base_class(b0), base_class(b1));
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * gq + sidx;
+            code[sidx] = ROW_PAD16 | (ROW_PAD16 << 16);
+            if (valid && j >= 1 && j <= pr.read_len) {
+                const uint32_t b0 = read_bytes[(int64_t)pr.read_off + (j - 1)];
+                const uint32_t b1 = read_bytes[(int64_t)pr.read_off + (pr.read_len - j)];
+                exotic |= !is_fast_base(b0);                       // b1 is some other row's b0
+                code[sidx] = (b0 << 8) | (b1 << 24) | table_row(base_class(b0), base_class(b1));
+            }
         }
-        out[sidx] = code;
+        out[(int64_t)gq * WAVE] = make_uint4(code[0], code[1], code[2], code[3]);
     }
-    reinterpret_cast<uint4*>(rowcodes)[t] = make_uint4(out[0], out[1], out[2], out[3]);
-    if (exotic) atomicOr(&wg_generic[w / WG_WAVES], 1u);
+    return exotic;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,16 +269,27 @@ __device__ __forceinline__ void row_step(uint32_t (&X)[W], const uint32_t (&r)[W
                                          uint32_t bcur)
 {
     // X[i] carries drift 2i; bprev/bcur are drift-free.  Diagonal into column i>0 gains +2 of drift.
+    // The substitution terms do not depend on X: they are formed 16 columns at a time, ahead of the
+    // chain, so that only max3 -> max3 is serial (left to itself the compiler recycles two registers
+    // and serialises xor/min/sub/add/max3 of every column).
     cj &= CODE_MASK;
+    constexpr int BLK = 16;
     uint32_t a = (bprev + FOUR2) - min3u(cj ^ r[0]);
     uint32_t up = bcur - TWO2;
 #pragma unroll
-    for (int i = 0; i < W; ++i) {
-        uint32_t a_next = 0;
-        if (i + 1 < W) a_next = (X[i] + SIX2) - min3u(cj ^ r[i + 1]);
-        X[i] = max3(a, X[i], up);
-        up = X[i];                      // drift makes the next column's "up - 2" equal to this value
-        a = a_next;
+    for (int b = 0; b < W; b += BLK) {
+        uint32_t d[BLK];
+#pragma unroll
+        for (int k = 0; k < BLK; ++k)
+            d[k] = b + k + 1 < W ? SIX2 - min3u(cj ^ r[b + k + 1]) : 0u;
+#pragma unroll
+        for (int k = 0; k < BLK; ++k) {
+            const int i = b + k;
+            const uint32_t a_next = X[i] + d[k];
+            X[i] = max3(a, X[i], up);
+            up = X[i];                  // drift makes the next column's "up - 2" equal to this value
+            a = a_next;
+        }
     }
 }
 
@@ -559,9 +569,40 @@ __device__ __forceinline__ void combine_wg(
         const int c0 = nth_set_bit(tiles0, 0), c1 = nth_set_bit(tiles1, 0);
         key = ((c0 >= 0 ? c0 : (int)NO_CHUNK) << 8) | (c1 >= 0 ? c1 : (int)NO_CHUNK);
     }
+    // Per fusion group the most frequent tile pair wins (any choice gives the same records: the pairs that
+    // lose go to the generic replay).  Votes are 16-bit counters in the LDS words that later serve the
+    // replay's counting sort; windows of more than VOTE_TILES tiles take the first offer instead.
+    constexpr int VOTE_TILES = 8, VOTE_KEYS = (VOTE_TILES + 1) * (VOTE_TILES + 1);
+    static_assert(GMAX * VOTE_KEYS <= 2 * 258, "votes must fit the histogram words");
+    const bool vote = g.nch <= VOTE_TILES;                     // uniform
+    auto vote_slot = [&](int k) -> int {
+        const int c0 = k >> 8, c1 = k & 0xFF;
+        return (c0 == (int)NO_CHUNK ? VOTE_TILES : c0) * (VOTE_TILES + 1) + (c1 == (int)NO_CHUNK ? VOTE_TILES : c1);
+    };
+    if (vote)
+        for (int e = tid; e < 258; e += WG_LANES) fl->hist[e] = 0;
     __syncthreads();
-    if (key >= 0) atomicCAS(&fl->tile[gsel], -1, key);
+    if (key >= 0) {
+        if (vote) {
+            const int slot = gsel * VOTE_KEYS + vote_slot(key);
+            atomicAdd(&fl->hist[slot >> 1], 1 << (16 * (slot & 1)));
+        } else
+            atomicCAS(&fl->tile[gsel], -1, key);
+    }
     __syncthreads();
+    if (vote && tid < GMAX) {                                  // one thread per group picks its winner
+        int best = 0, best_slot = -1;
+        for (int e = 0; e < VOTE_KEYS; ++e) {
+            const int slot = tid * VOTE_KEYS + e;
+            const int n = (fl->hist[slot >> 1] >> (16 * (slot & 1))) & 0xFFFF;
+            if (n > best) { best = n; best_slot = e; }
+        }
+        if (best_slot >= 0) {
+            const int c0 = best_slot / (VOTE_TILES + 1), c1 = best_slot % (VOTE_TILES + 1);
+            fl->tile[tid] = ((c0 == VOTE_TILES ? (int)NO_CHUNK : c0) << 8) | (c1 == VOTE_TILES ? (int)NO_CHUNK : c1);
+        }
+    }
+    if (vote) __syncthreads();
     bool fast = key >= 0 && fl->tile[gsel] == key;
     const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
 
@@ -632,6 +673,8 @@ __device__ __forceinline__ void combine_wg(
         rt.last_row = (uint16_t)(r0 > r1 ? r0 : r1);
         rt.chunk0 = c0 >= 0 ? (uint8_t)c0 : NO_CHUNK;
         rt.chunk1 = c1 >= 0 ? (uint8_t)c1 : NO_CHUNK;
+        rt.first_a = (uint16_t)first_a;
+        rt.pad_ = 0;
         if (t == 0 && fast)
             rt.last_row |= TASK_FAST;
         else
@@ -997,7 +1040,8 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                                                            const dsa_fusion* __restrict__ fusions,
                                                            const uint32_t* __restrict__ wg_generic,
                                                            const uint32_t* __restrict__ refcodes,
-                                                           const uint32_t* __restrict__ rowcodes,
+                                                           const uint8_t* __restrict__ read_bytes,
+                                                           uint32_t* __restrict__ rowcodes,
                                                            const int32_t* __restrict__ min_score_tab,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
                                                            uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask,
@@ -1010,6 +1054,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         const int lane = threadIdx.x & 63;
         const int64_t p = min((int64_t)w * WAVE + lane, g.n_pairs - 1);   // tail lanes shadow the last pair
         const WaveInfo wi = winfo[w];
+        (void)pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);   // the fast kernel packs only what it keeps
         const int f = pairs[p].fusion_idx;
         const dsa_fusion fu = fusions[f];
         const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
@@ -1052,9 +1097,10 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            const WaveInfo* __restrict__ winfo,
                                                            const WgInfo* __restrict__ wginfo,
-                                                           const uint32_t* __restrict__ wg_generic,
+                                                           uint32_t* __restrict__ wg_generic,
                                                            const uint32_t* __restrict__ refcodes,
-                                                           const uint32_t* __restrict__ rowcodes,
+                                                           const uint8_t* __restrict__ read_bytes,
+                                                           uint32_t* __restrict__ rowcodes,
                                                            const int32_t* __restrict__ min_score_tab,
                                                            const dsa_fusion* __restrict__ fusions,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
@@ -1062,7 +1108,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                                                            FinishBufs fb, Geom g)
 {
     __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
-    __shared__ int s_nch;
+    __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
@@ -1093,10 +1139,18 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     };
     // rows up to which the boundary entering the next tile may still be alive (tile 0: column 0, V = 0)
     int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
-    if (threadIdx.x == 0) s_nch = 0;
+    // Row codes are packed here, by the wave that uses them.  A read byte outside {A,C,G,T,N} hands the
+    // whole workgroup to the generic kernel, which is launched after this one and re-packs its rows.
+    const bool exotic = live && pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);
+    if (threadIdx.x == 0) { s_nch = 0; s_exotic = 0; }
     __syncthreads();
     if (lane == 0 && live) atomicMax(&s_nch, wi.nch_max);
+    if (__builtin_amdgcn_ballot_w64(exotic) != 0 && lane == 0) atomicOr(&s_exotic, 1);
     __syncthreads();
+    if (s_exotic != 0) {                         // uniform
+        if (threadIdx.x == 0) wg_generic[blockIdx.x] = 1u;
+        return;
+    }
     const int nch_wg = s_nch;
 
     int gsel = 0;
@@ -1271,9 +1325,12 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 
 // K3g: replay one tile pair per lane from the stored boundaries (generic scoring, any pair mix); for
 // every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
-// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Grid-stride over the device list
-// of tasks the table-driven kernel does not cover.
-__global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Covers the device list of tasks the
+// table-driven replay left over.  A block takes REPLAY_BLOCK consecutive tasks and hands them to its
+// lanes in order of their first kept read split (counting sort in LDS), so that the lanes of a wave
+// reach their kept rows — where the column masks are extracted — in the same few rows.
+constexpr int REPLAY_BLOCK = 256;
+__global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
                                                    const uint32_t* __restrict__ gtasks, uint64_t gtask_cap,
                                                    const Counters* __restrict__ ctr,
                                                    const PairState* __restrict__ state,
@@ -1285,11 +1342,41 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
                                                    const uint32_t* __restrict__ bnd, const int32_t* __restrict__ tstop,
                                                    uint64_t* __restrict__ masks, uint64_t mask_cap, Geom g)
 {
+    __shared__ int s_hist[258];
+    __shared__ unsigned short s_order[REPLAY_BLOCK];
+    __shared__ ReplayTask s_task[REPLAY_BLOCK];
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_g;
-         t += (unsigned long long)gridDim.x * blockDim.x) {
-        const ReplayTask rt = tasks[gtasks[t]];
+    for (unsigned long long base = (unsigned long long)blockIdx.x * REPLAY_BLOCK; base < n_g;
+         base += (unsigned long long)gridDim.x * REPLAY_BLOCK) {                 // uniform per block
+        __syncthreads();                                  // previous round's LDS no longer in use
+        for (int e = threadIdx.x; e < 258; e += REPLAY_BLOCK) s_hist[e] = 0;
+        __syncthreads();
+        int my_key = 256, my_rank = 0;
+        if (base + threadIdx.x < n_g) {
+            const ReplayTask mine = tasks[gtasks[base + threadIdx.x]];
+            s_task[threadIdx.x] = mine;
+            my_key = min((int)mine.first_a, 255);
+        }
+        my_rank = atomicAdd(&s_hist[my_key], 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int e = 0; e < 257; ++e) {
+                const int n = s_hist[e];
+                s_hist[e] = run;
+                run += n;
+            }
+        }
+        __syncthreads();
+        s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
+        __syncthreads();
+        const int src = s_order[threadIdx.x];
+        if (base + src >= n_g) continue;                  // sorted last: whole waves drop out together
+        const ReplayTask rt = s_task[src];
+#ifdef DSA_PRUNE_STATS
+        const unsigned long long tr0 = __builtin_readcyclecounter();
+#endif
         const int64_t p = rt.pair;
         const int64_t w = p >> 6;
         const int lane = (int)(p & 63);
@@ -1321,29 +1408,60 @@ __global__ __launch_bounds__(256, 3) void k_replay(const ReplayTask* __restrict_
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
         HitCursor hc = cursor_init(kr, nullptr, st.n_kept, lq, has0, has1, nv0, nv1);
-        uint32_t cj_next = rows[rowidx(1, lane)];
         const int stop0 = c0 > 0 ? tstop[w * g.nch + (c0 - 1)] : 0;   // stored row groups of the tiles to the left
         const int stop1 = c1 > 0 ? tstop[w * g.nch + (c1 - 1)] : 0;
-        auto boundary = [&](int j) -> uint32_t {
-            return ((j >> 2) < stop0 ? (bi0[rowidx(j, lane)] & 0xFFFFu) : BIAS16) |
-                   ((j >> 2) < stop1 ? (bi1[rowidx(j, lane)] & 0xFFFF0000u) : (BIAS16 << 16));
+        // four rows per step: one dwordx4 of row codes and of either boundary, fetched one step ahead
+        const uint4* rows4 = reinterpret_cast<const uint4*>(rows) + lane;
+        const uint4* bi0_4 = reinterpret_cast<const uint4*>(bi0) + lane;
+        const uint4* bi1_4 = reinterpret_cast<const uint4*>(bi1) + lane;
+        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+        auto boundary = [&](int gq) -> uint4 {
+            const uint4 x0 = gq < stop0 ? bi0_4[(int64_t)gq * WAVE] : bias4;
+            const uint4 x1 = gq < stop1 ? bi1_4[(int64_t)gq * WAVE] : bias4;
+            return make_uint4((x0.x & 0xFFFFu) | (x1.x & 0xFFFF0000u), (x0.y & 0xFFFFu) | (x1.y & 0xFFFF0000u),
+                              (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
         };
-        uint32_t b_next = boundary(1);
-        for (int j = 1; j <= R; ++j) {
-            const uint32_t cj = cj_next;
-            const uint32_t bcur = b_next;
-            const int jn = j < R ? j + 1 : j;
-            cj_next = rows[rowidx(jn, lane)];
-            b_next = boundary(jn);
-            row_step(X, r, cj, bprev, bcur);
-            bprev = bcur;
-            record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+        const int ngq = (R >> 2) + 1;
+        uint4 rc_n = rows4[0];
+        uint4 b_n = boundary(0);
+#ifdef DSA_PRUNE_STATS
+        const unsigned long long tr1 = __builtin_readcyclecounter();
+#endif
+        for (int gq = 0; gq < ngq; ++gq) {
+            const uint4 rcq = rc_n, b = b_n;
+            const int gn = gq + 1 < ngq ? gq + 1 : gq;
+            rc_n = rows4[(int64_t)gn * WAVE];
+            b_n = boundary(gn);
+            const uint32_t rcv[4] = {rcq.x, rcq.y, rcq.z, rcq.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int j = 4 * gq + sidx;
+                const uint32_t bcur = bv[sidx];
+                if (j >= 1 && j <= R) {
+#ifndef DSA_EXP_REPLAY_NOSTEP
+                    row_step(X, r, rcv[sidx], bprev, bcur);
+#endif
+#ifndef DSA_EXP_REPLAY_NOHITS
+                    record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+#endif
+                }
+                bprev = bcur;
+            }
         }
         // sides that were not replayed report no columns
         if (!has0)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
         if (!has1)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
+#ifdef DSA_PRUNE_STATS
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long tr2 = __builtin_readcyclecounter();
+            atomicAdd(&g.stats[10], tr1 - tr0);
+            atomicAdd(&g.stats[11], tr2 - tr1);
+            atomicAdd(&g.stats[12], 1ull);
+            atomicAdd(&g.stats[13], (unsigned long long)ngq);
+        }
+#endif
     }
 }
 

@@ -31,7 +31,7 @@ class Limits(ctypes.Structure):
 
 class Timing(ctypes.Structure):
     _fields_ = [("pack_ms", ctypes.c_float), ("fill_ms", ctypes.c_float), ("finish_ms", ctypes.c_float),
-                ("total_ms", ctypes.c_float), ("fill_launches", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("total_ms", ctypes.c_float), ("fill_launches", ctypes.c_int32), ("n_generic_tasks", ctypes.c_int32),
                 ("cells", ctypes.c_int64), ("n_records", ctypes.c_int64), ("n_replay_tasks", ctypes.c_int64)]
 
 

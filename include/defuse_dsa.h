@@ -89,7 +89,7 @@ typedef struct dsa_timing {
     float   finish_ms;            /* combine + tile replay + emit kernels                        */
     float   total_ms;             /* elapsed host time of dsa_run (stage times overlap between slices) */
     int32_t fill_launches;        /* number of DP fill launches in fill_ms                       */
-    int32_t pad_;
+    int32_t n_generic_tasks;      /* of n_replay_tasks: tiles re-run by the generic replay kernel   */
     int64_t cells;                /* DP cells filled: sum over pairs of 2*(Lref+1)*(Lread+1)     */
     int64_t n_records;
     int64_t n_replay_tasks;       /* tiles re-run to enumerate tied columns                      */
