@@ -6,14 +6,17 @@
 //
 // FP64 throughout, no contraction into FMA, and every sum is taken in the reference's serial order
 // (MaxLikelihood compares two prefix sums for exact equality, so a tree reduction would change
-// results).  One problem (bin pair) per lane: the problems are independent and there are thousands
-// of them per chromosome pair; a problem's working set lives in a per-problem slice of one global
-// workspace.  Round-1 mapping: correctness first — moving the O(N*K) loops of big problems onto the
-// lanes of a wave is the next step.
+// results).  The model selection loop of DoClustering (K = 1..min(10,N), :599-606) runs its K fits
+// independently, so k_mpe_fit gives every (problem, K) its own lane and workspace slice; lanes are
+// ordered K-major over problems sorted by size, so a wave holds fits of one K and of similar N.
+// k_mpe_final then picks the K of minimal BIC per problem (first minimum in K order, as the
+// reference's strict '<'), refits it and derives the memberships, one problem per lane.
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -56,7 +59,8 @@ struct Work {
     int fail;
 };
 
-__host__ __device__ inline size_t work_doubles(int n) { return (size_t)n * (2 + 4 * MPE_KMAX + 2 + 12 + 4) + 16; }
+// workspace of one fit with K components
+__host__ __device__ inline size_t work_doubles(int n, int K) { return (size_t)n * (2 + 4 * K + 2 + 12 + 4) + 16; }
 __host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
 
 __device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
@@ -414,31 +418,19 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
     return true;
 }
 
-__global__ void k_mpe(mpe_params prm, const int64_t* __restrict__ prob_off, int n_problems, const double* __restrict__ x,
-                      const double* __restrict__ y, const double* __restrict__ u, const int32_t* __restrict__ to_xo,
-                      const int32_t* __restrict__ to_yo, const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off,
-                      double* __restrict__ wdoubles, int* __restrict__ wints, int32_t* __restrict__ n_clusters,
-                      uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters)
+// carve the workspace of a fit with up to K components and set up the sorted copies
+__device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, const double* y, const double* u, const int32_t* to_xo,
+                          const int32_t* to_yo, double* d, int* ip, double sd)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_problems) return;
-    const int64_t b = prob_off[p];
-    const int N = (int)(prob_off[p + 1] - b);
-    n_clusters[p] = 0;
-    status[p] = 0;
-    for (int i = 0; i < N; ++i) member[b + i] = 0;
-    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
-    Work w;
     w.N = N;
     w.X = x + b; w.Y = y + b; w.U = u + b;
     w.ToXO = to_xo + b; w.ToYO = to_yo + b;
-    double* d = wdoubles + wd_off[p];
     w.XO = d; d += N;
     w.YO = d; d += N;
-    w.R = d; d += (size_t)MPE_KMAX * N;
-    w.RXO = d; d += (size_t)MPE_KMAX * N;
-    w.RYO = d; d += (size_t)MPE_KMAX * N;
-    w.EX = d; d += (size_t)MPE_KMAX * N;
+    w.R = d; d += (size_t)K * N;
+    w.RXO = d; d += (size_t)K * N;
+    w.RYO = d; d += (size_t)K * N;
+    w.EX = d; d += (size_t)K * N;
     w.SX = d; d += N;
     w.SY = d; d += N;
     w.CX = d; d += 4 * (size_t)N + 4;
@@ -447,10 +439,9 @@ __global__ void k_mpe(mpe_params prm, const int64_t* __restrict__ prob_off, int 
     w.ka = d; d += 2 * (size_t)N;
     w.kd = d; d += N;
     w.dist = d; d += N;
-    int* ip = wints + wi_off[p];
     w.ic1 = ip;
     w.ic2 = ip + N;
-    w.sd = prm.fragment_stddev;
+    w.sd = sd;
     w.iters = 0;
     w.fail = 0;
     for (int j = 0; j < MPE_KMAX; ++j) w.W[j] = w.A[j] = w.B[j] = 0.0;
@@ -458,18 +449,75 @@ __global__ void k_mpe(mpe_params prm, const int64_t* __restrict__ prob_off, int 
         w.XO[w.ToXO[i]] = w.X[i];
         w.YO[w.ToYO[i]] = w.Y[i];
     }
-    double min_bic = 0.0;
-    bool have = false;
-    int k_min = 1;
-    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
-    for (int K = 1; K <= kmax && !w.fail; ++K) {
-        double ll;
-        if (!expectation_maximization(w, K, ll)) continue;
-        const double bic = -2.0 * ll + K * 2.0 * log((double)N);
-        if (!have || bic < min_bic) { min_bic = bic; k_min = K; have = true; }
-    }
+}
+
+// fit_state[(p - p0) * MPE_KMAX + K - 1]: 0 = the fit gave no likelihood (the reference `continue`s),
+// 1 = bic valid, 2 = the reference would have exited through a DebugCheck
+__global__ void k_mpe_fit(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int n_chunk,
+                          const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
+                          const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
+                          const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
+                          int* __restrict__ wints, double* __restrict__ bic, int32_t* __restrict__ fit_state,
+                          unsigned long long* __restrict__ iters)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_chunk * MPE_KMAX) return;
+    const int K = (int)(t / n_chunk) + 1;                 // K-major: a wave fits one K
+    const int q = order[t % n_chunk];                     // chunk-relative problem, largest first
+    const int p = p0 + q;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    const int slot = q * MPE_KMAX + K - 1;
+    fit_state[slot] = 0;
+    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
+    if (K > (N < MPE_KMAX ? N : MPE_KMAX)) return;
+    Work w;
+    init_work(w, N, K, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev);
     double ll;
-    if (!w.fail && expectation_maximization(w, k_min, ll)) {
+    if (expectation_maximization(w, K, ll)) {
+        bic[slot] = -2.0 * ll + K * 2.0 * log((double)N);
+        fit_state[slot] = 1;
+    }
+    if (w.fail) fit_state[slot] = 2;
+    atomicAdd(iters, (unsigned long long)w.iters);
+}
+
+__global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int n_chunk,
+                            const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ u,
+                            const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
+                            const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
+                            int* __restrict__ wints, const double* __restrict__ bic, const int32_t* __restrict__ fit_state,
+                            int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status,
+                            unsigned long long* __restrict__ iters)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_chunk) return;
+    const int p = p0 + q;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    n_clusters[p] = 0;
+    status[p] = 0;
+    for (int i = 0; i < N; ++i) member[b + i] = 0;
+    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
+    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
+    // model selection :599-606; a fit that tripped a DebugCheck ends the reference's run there
+    double min_bic = 0.0;
+    bool have = false, failed = false;
+    int k_min = 1;
+    for (int K = 1; K <= kmax; ++K) {
+        const int st = fit_state[q * MPE_KMAX + K - 1];
+        if (st == 2) { failed = true; break; }
+        if (st != 1) continue;
+        const double v = bic[q * MPE_KMAX + K - 1];
+        if (!have || v < min_bic) { min_bic = v; k_min = K; have = true; }
+    }
+    if (failed) { status[p] = 1; return; }
+    // the refit reuses the workspace of the problem's largest fit
+    const int slot = q * MPE_KMAX + kmax - 1;
+    Work w;
+    init_work(w, N, kmax, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev);
+    double ll;
+    if (expectation_maximization(w, k_min, ll)) {
         const double coeff = 1.0 / (w.sd * sqrt(2 * M_PI));                // normalpdf, tools/Common.cpp:61-69
         int emitted = 0;
         for (int j = 0; j < k_min; ++j) {
@@ -519,26 +567,19 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_mpe_err = "no usable HIP device"; return -2; }
     MPE_HIP(hipSetDevice(device));
-    std::vector<int64_t> wd(n_problems + 1, 0), wi(n_problems + 1, 0);
     for (int p = 0; p < n_problems; ++p) {
         const int64_t n = prob_off[p + 1] - prob_off[p];
         if (n < 0 || n > 0x7FFFFFF) { g_mpe_err = "problem too large"; return -4; }
-        wd[p + 1] = wd[p] + (int64_t)work_doubles((int)n);
-        wi[p + 1] = wi[p] + (int64_t)work_ints((int)n);
     }
-    DBuf<int64_t> d_off, d_wd, d_wi;
-    DBuf<double> d_x, d_y, d_u, d_work;
+    DBuf<int64_t> d_off;
+    DBuf<double> d_x, d_y, d_u;
     DBuf<int32_t> d_txo, d_tyo, d_nc, d_status;
-    DBuf<int> d_iwork;
     DBuf<uint16_t> d_member;
     DBuf<unsigned long long> d_iters;
-    MPE_HIP(d_off.alloc(n_problems + 1)); MPE_HIP(d_wd.alloc(n_problems + 1)); MPE_HIP(d_wi.alloc(n_problems + 1));
+    MPE_HIP(d_off.alloc(n_problems + 1));
     MPE_HIP(d_x.alloc(n_mp)); MPE_HIP(d_y.alloc(n_mp)); MPE_HIP(d_u.alloc(n_mp)); MPE_HIP(d_txo.alloc(n_mp)); MPE_HIP(d_tyo.alloc(n_mp));
-    MPE_HIP(d_work.alloc(wd[n_problems])); MPE_HIP(d_iwork.alloc(wi[n_problems]));
     MPE_HIP(d_nc.alloc(n_problems)); MPE_HIP(d_status.alloc(n_problems)); MPE_HIP(d_member.alloc(n_mp)); MPE_HIP(d_iters.alloc(1));
     MPE_HIP(hipMemcpy(d_off.p, prob_off, (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    MPE_HIP(hipMemcpy(d_wd.p, wd.data(), (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    MPE_HIP(hipMemcpy(d_wi.p, wi.data(), (n_problems + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     if (n_mp) {
         MPE_HIP(hipMemcpy(d_x.p, x, n_mp * sizeof(double), hipMemcpyHostToDevice));
         MPE_HIP(hipMemcpy(d_y.p, y, n_mp * sizeof(double), hipMemcpyHostToDevice));
@@ -550,18 +591,70 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     hipEvent_t e0, e1;
     MPE_HIP(hipEventCreate(&e0));
     MPE_HIP(hipEventCreate(&e1));
-    MPE_HIP(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_mpe, dim3((unsigned)((n_problems + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, n_problems, d_x.p, d_y.p,
-                       d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p, d_iters.p);
-    MPE_HIP(hipEventRecord(e1));
-    MPE_HIP(hipDeviceSynchronize());
-    MPE_HIP(hipGetLastError());
+
+    // problems are taken in chunks whose fit workspaces (one per problem and K) fit the budget
+    size_t budget = (size_t)8 << 30;
+    if (const char* e = getenv("DEFUSE_MPE_SCRATCH_MB")) budget = std::max<size_t>(1, (size_t)atoll(e)) << 20;
+    auto slot_doubles = [&](int p, int K) -> size_t {
+        const int n = (int)(prob_off[p + 1] - prob_off[p]);
+        const int kmax = n < MPE_KMAX ? n : MPE_KMAX;
+        return (n >= params->min_cluster_size && n > 0 && K <= kmax) ? work_doubles(n, K) : 0;
+    };
+    int p0 = 0;
+    while (p0 < n_problems) {
+        int p1 = p0;
+        size_t bytes = 0;
+        while (p1 < n_problems) {
+            size_t add = 0;
+            for (int K = 1; K <= MPE_KMAX; ++K) add += slot_doubles(p1, K) * sizeof(double) + (slot_doubles(p1, K) ? work_ints((int)(prob_off[p1 + 1] - prob_off[p1])) * sizeof(int) : 0);
+            if (p1 > p0 && bytes + add > budget) break;
+            bytes += add;
+            ++p1;
+        }
+        const int n_chunk = p1 - p0;
+        std::vector<int64_t> wd((size_t)n_chunk * MPE_KMAX + 1, 0), wi((size_t)n_chunk * MPE_KMAX + 1, 0);
+        for (int q = 0; q < n_chunk; ++q)
+            for (int K = 1; K <= MPE_KMAX; ++K) {
+                const size_t sl = (size_t)q * MPE_KMAX + K - 1;
+                const size_t nd = slot_doubles(p0 + q, K);
+                wd[sl + 1] = wd[sl] + (int64_t)nd;
+                wi[sl + 1] = wi[sl] + (int64_t)(nd ? work_ints((int)(prob_off[p0 + q + 1] - prob_off[p0 + q])) : 0);
+            }
+        std::vector<int32_t> order((size_t)n_chunk);
+        for (int q = 0; q < n_chunk; ++q) order[q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return prob_off[p0 + a + 1] - prob_off[p0 + a] > prob_off[p0 + b + 1] - prob_off[p0 + b];
+        });
+        DBuf<int64_t> d_wd, d_wi;
+        DBuf<int32_t> d_order, d_state;
+        DBuf<double> d_work, d_bic;
+        DBuf<int> d_iwork;
+        MPE_HIP(d_wd.alloc(wd.size())); MPE_HIP(d_wi.alloc(wi.size())); MPE_HIP(d_order.alloc(order.size()));
+        MPE_HIP(d_state.alloc((size_t)n_chunk * MPE_KMAX)); MPE_HIP(d_bic.alloc((size_t)n_chunk * MPE_KMAX));
+        MPE_HIP(d_work.alloc((size_t)wd.back())); MPE_HIP(d_iwork.alloc((size_t)wi.back()));
+        MPE_HIP(hipMemcpy(d_wd.p, wd.data(), wd.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_wi.p, wi.data(), wi.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        MPE_HIP(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        MPE_HIP(hipEventRecord(e0));
+        const int64_t n_fit = (int64_t)n_chunk * MPE_KMAX;
+        hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_chunk, d_order.p, d_x.p,
+                           d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
+        hipLaunchKernelGGL(k_mpe_final, dim3((unsigned)((n_chunk + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_chunk, d_x.p, d_y.p,
+                           d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p, d_member.p,
+                           d_status.p, d_iters.p);
+        MPE_HIP(hipEventRecord(e1));
+        MPE_HIP(hipDeviceSynchronize());
+        MPE_HIP(hipGetLastError());
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        t.kernel_ms += ms;
+        p0 = p1;
+    }
     MPE_HIP(hipMemcpy(n_clusters, d_nc.p, n_problems * sizeof(int32_t), hipMemcpyDeviceToHost));
     MPE_HIP(hipMemcpy(status, d_status.p, n_problems * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n_mp) MPE_HIP(hipMemcpy(member, d_member.p, n_mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
     unsigned long long it = 0;
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
-    (void)hipEventElapsedTime(&t.kernel_ms, e0, e1);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     t.em_iterations = (int64_t)it;
