@@ -69,6 +69,24 @@ def test_parity_single_fusion_fast_path(gpu_ctx, ora):
     assert len(got) > 300
 
 
+def test_parity_exotic_reads_hand_workgroups_over(gpu_ctx, ora):
+    """Several workgroups of two fusions; a lowercase read every 300 pairs makes the fast kernel hand just
+    those workgroups to the generic one (decided on the device while packing the rows)."""
+    import numpy as np
+    rng = np.random.default_rng(78)
+    bb = cases.BatchBuilder()
+    for _ in range(2):
+        ref0, ref1 = cases.rnd(rng, 389), cases.rnd(rng, 300)
+        f = bb.add_fusion(ref0, ref1)
+        for r in range(900):
+            read = cases.mutate(rng, cases.split_read(rng, ref0, ref1, 76), 0.01)
+            if r % 300 == 150:
+                read = read.lower()
+            bb.add_read(f, read)
+    got = check_batch(gpu_ctx, ora, bb.arrays())
+    assert len(got) > 800
+
+
 def test_parity_ties(gpu_ctx, ora):
     got = check_batch(gpu_ctx, ora, cases.tie_batch(4))
     # the tie cases must really produce multi-record pairs
