@@ -14,12 +14,12 @@ def rc(s: bytes) -> bytes:
     return s[::-1].translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))
 
 
-def build(outdir, seed=5, n_fusions=6, reads_per_fusion=30, lq=50, ufrag=300.0, sfrag=30.0):
+def build(outdir, seed=5, n_fusions=6, reads_per_fusion=30, lq=50, ufrag=300.0, sfrag=30.0, chrom_len=5000, transcripts=True):
     from oracle import dosplitalign_oracle as ora
     rng = np.random.default_rng(seed)
     os.makedirs(outdir, exist_ok=True)
     P = lambda n: os.path.join(outdir, n)
-    chroms = {"chr%d" % k: rnd(rng, 5000 + 700 * k) for k in range(1, 4)}
+    chroms = {"chr%d" % k: rnd(rng, chrom_len + 700 * k) for k in range(1, 4)}   # chrom_len: spreads many fusions out
     # two transcripts given as cDNA sequences with their own names "gene|transcript"
     tx = {"ENSG01|ENST01": ("chr1", "+", [(501, 900), (1501, 2100), (3001, 3800)]),
           "ENSG02|ENST02": ("chr2", "-", [(801, 1500), (2501, 3300)])}
@@ -39,7 +39,7 @@ def build(outdir, seed=5, n_fusions=6, reads_per_fusion=30, lq=50, ufrag=300.0, 
         f.write("ENSG03\tENST03\tchr3\t+\t100\t4000\t\n")
         f.write("short line\n\n")
     # fusion regions: all strand combinations, chromosome and transcript references, one near a sequence start
-    names = list(seqs)
+    names = list(seqs) if transcripts else list(chroms)       # transcripts=False: regions on chromosomes only
     regions = []
     for k in range(n_fusions):
         ends = []

@@ -91,6 +91,12 @@ def test_dosplitalign_matches_oracle(tools, tmp_path, seed):
     assert r.returncode == 0, r.stderr
     assert len(exp.splitlines()) > 20
     assert out.read_text() == exp
+    # the same run streamed to the GPU in batches of a few candidates: identical file
+    out2 = tmp_path / "split.align.batched"
+    r = subprocess.run([TOOL] + pipeline_case.tool_args(case, str(out2)), capture_output=True, text=True,
+                       env=dict(os.environ, DEFUSE_DSA_BATCH_PAIRS="7"))
+    assert r.returncode == 0, r.stderr
+    assert out2.read_text() == exp
 
 
 EVAL = os.path.join(ROOT, "bin", "evalsplitalign")

@@ -55,6 +55,75 @@ int main(int argc, char* argv[])
     std::unordered_map<int, int> fusion_index;     // fusion id -> index into fusions
     std::unordered_map<int, std::set<std::pair<int, int>>> candidate_unique;   // :268, :292
 
+    std::ofstream out(cmd.str("align").c_str());
+    if (!out.good()) die("Error: Unable to open " + cmd.str("align"));
+
+    // Candidates go to the GPU in batches (DEFUSE_DSA_BATCH_PAIRS, default 4 M) and their lines are
+    // written in the reference's visiting order, so a run of any size streams through.
+    dsa_ctx* ctx = nullptr;
+    size_t batch_pairs = (size_t)4 << 20;
+    if (const char* e = std::getenv("DEFUSE_DSA_BATCH_PAIRS")) batch_pairs = std::max<size_t>(1, (size_t)std::atoll(e));
+    auto flush = [&]() {
+        if (cand.empty()) return;
+        // group by fusion for the kernels, fusions with many candidates first: the table-driven kernels take
+        // workgroups (256 consecutive pairs) of at most four fusions, so the small fusions are kept together
+        // at the end instead of dragging their big neighbours onto the generic path (stable: keeps the
+        // visiting order inside a fusion)
+        std::vector<int64_t> per_fusion(fusions.size(), 0);
+        for (const dsa_pair& c : cand) ++per_fusion[c.fusion_idx];
+        std::vector<int64_t> order(cand.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+            const int fa = cand[a].fusion_idx, fb = cand[b].fusion_idx;
+            if (per_fusion[fa] != per_fusion[fb]) return per_fusion[fa] > per_fusion[fb];
+            return fa < fb;
+        });
+        std::vector<dsa_pair> pairs(cand.size());
+        for (size_t k = 0; k < order.size(); ++k) pairs[k] = cand[order[k]];
+
+        if (!ctx) {
+            const char* dev = std::getenv("DEFUSE_GPU");
+            if (dsa_create(&ctx, dev ? std::atoi(dev) : 0) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
+        }
+        std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
+        int64_t n = 0;
+        int rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
+                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
+                                 (int64_t)recs.size(), &n);
+        if (rc == DSA_E_CAPACITY) {
+            recs.resize((size_t)n);
+            rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
+                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
+                                 recs.data(), (int64_t)recs.size(), &n);
+        }
+        if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
+
+        // back to the visiting order: records arrive grouped by batch pair index
+        std::vector<int64_t> first(pairs.size() + 1, 0);
+        for (int64_t k = 0; k < n; ++k) ++first[recs[k].pair_idx + 1];
+        for (size_t k = 0; k < pairs.size(); ++k) first[k + 1] += first[k];
+        std::vector<int64_t> slot_of(cand.size());
+        for (size_t k = 0; k < order.size(); ++k) slot_of[order[k]] = (int64_t)k;
+        std::string buf;
+        for (size_t c = 0; c < cand.size(); ++c) {
+            const int64_t k = slot_of[c];
+            for (int64_t r = first[k]; r < first[k + 1]; ++r) {
+                const dsa_record& a = recs[r];
+                // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
+                buf += std::to_string(a.fusion_id) + "\t" + std::to_string(a.frag) + "\t" + std::to_string(a.read_end) + "\t" +
+                       std::to_string(a.revcomp) + "\t" + std::to_string(a.ref_first) + "\t" + std::to_string(a.ref_second) + "\t" +
+                       std::to_string(a.read_first) + "\t" + std::to_string(a.read_second) + "\t" + std::to_string(a.score) + "\t\n";
+            }
+            if (buf.size() > (1u << 20)) { out << buf; buf.clear(); }
+        }
+        out << buf;
+        ref_bytes.clear();
+        read_bytes.clear();
+        fusions.clear();
+        cand.clear();
+        fusion_index.clear();
+    };
+
     SamAlignmentStream sam(cmd.str("improper"));
     RawAlignment mate;
     while (sam.GetNextAlignment(mate)) {
@@ -92,59 +161,13 @@ int main(int argc, char* argv[])
             p.read_end = (uint8_t)read_end;
             p.revcomp = (uint8_t)revcomp;
             read_bytes.insert(read_bytes.end(), seq.begin(), seq.end());
-            if (read_bytes.size() > 0x7FFFFFF0u) die("Error: more than 2 GiB of candidate read sequence in one run");
             cand.push_back(p);
         }
+        // between two SAM records: a batch never splits the candidates of one record
+        if (cand.size() >= batch_pairs || read_bytes.size() > ((size_t)1 << 30) || ref_bytes.size() > ((size_t)1 << 30)) flush();
     }
-
-    std::ofstream out(cmd.str("align").c_str());
-    if (!out.good()) die("Error: Unable to open " + cmd.str("align"));
-
-    if (!cand.empty()) {
-        // group by fusion for the kernels (stable: keeps the visiting order inside a fusion)
-        std::vector<int64_t> order(cand.size());
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return cand[a].fusion_idx < cand[b].fusion_idx; });
-        std::vector<dsa_pair> pairs(cand.size());
-        for (size_t k = 0; k < order.size(); ++k) pairs[k] = cand[order[k]];
-
-        dsa_ctx* ctx = nullptr;
-        const char* dev = std::getenv("DEFUSE_GPU");
-        if (dsa_create(&ctx, dev ? std::atoi(dev) : 0) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
-        std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
-        int64_t n = 0;
-        int rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
-                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
-                                 (int64_t)recs.size(), &n);
-        if (rc == DSA_E_CAPACITY) {
-            recs.resize((size_t)n);
-            rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
-                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
-                                 recs.data(), (int64_t)recs.size(), &n);
-        }
-        if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
-        dsa_destroy(ctx);
-
-        // back to the visiting order: records arrive grouped by batch pair index
-        std::vector<int64_t> first(pairs.size() + 1, 0);
-        for (int64_t k = 0; k < n; ++k) ++first[recs[k].pair_idx + 1];
-        for (size_t k = 0; k < pairs.size(); ++k) first[k + 1] += first[k];
-        std::vector<int64_t> slot_of(cand.size());
-        for (size_t k = 0; k < order.size(); ++k) slot_of[order[k]] = (int64_t)k;
-        std::string buf;
-        for (size_t c = 0; c < cand.size(); ++c) {
-            const int64_t k = slot_of[c];
-            for (int64_t r = first[k]; r < first[k + 1]; ++r) {
-                const dsa_record& a = recs[r];
-                // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
-                buf += std::to_string(a.fusion_id) + "\t" + std::to_string(a.frag) + "\t" + std::to_string(a.read_end) + "\t" +
-                       std::to_string(a.revcomp) + "\t" + std::to_string(a.ref_first) + "\t" + std::to_string(a.ref_second) + "\t" +
-                       std::to_string(a.read_first) + "\t" + std::to_string(a.read_second) + "\t" + std::to_string(a.score) + "\t\n";
-            }
-            if (buf.size() > (1u << 20)) { out << buf; buf.clear(); }
-        }
-        out << buf;
-    }
+    flush();
+    if (ctx) dsa_destroy(ctx);
     out.close();
     if (!out.good()) die("Error: failed writing " + cmd.str("align"));
     return 0;
