@@ -85,7 +85,7 @@ struct Slice {
     int64_t pair_begin = 0, pair_end = 0;
     std::vector<WaveInfo> waves;     // one per 64 pairs
     std::vector<WgInfo> wgs;         // one per 256 pairs
-    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GMAX fusions)
+    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GSPLIT fusions)
     Geom g{};
 };
 
@@ -199,7 +199,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
                     bool found = false;
                     for (int k = 0; k < wg.n_groups; ++k) found |= wg.group_f[k] == f;
                     if (!found) {
-                        if (wg.n_groups < GMAX)
+                        if (wg.n_groups < GSPLIT)
                             wg.group_f[wg.n_groups++] = f;
                         else
                             too_many = true;
@@ -289,7 +289,10 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
     HIPC(hipEventRecord(L.ev[1], st));
     // every workgroup is run by exactly one of the two fill kernels
-    hipLaunchKernelGGL(k_fill_fast, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+    hipLaunchKernelGGL(k_fill_fast<false>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_tmask.p, fb, g);
+    hipLaunchKernelGGL(k_fill_fast<true>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
                        L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,

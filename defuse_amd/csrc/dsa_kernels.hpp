@@ -59,8 +59,14 @@ constexpr int TROW = W + 4;           // table row stride in dwords: table row t
 #ifndef FILL_PF
 #define FILL_PF 2               // LDS table reads kept in flight ahead of the column being updated
 #endif
-constexpr int GMAX = 4;               // max distinct fusions per workgroup on the fast path
+constexpr int GMAX = 4;               // max distinct fusions per workgroup with one 25-row table per fusion
 constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
+// Workgroups of 5..GSPLIT fusions keep two 5-row tables per fusion in the same LDS instead (M1 terms by
+// M1 class, M2 terms by M2 class): a cell then adds two table terms (v_add3_u32 instead of v_add_u32)
+// from two ds_read_b128 per four columns.
+constexpr int GSPLIT = 10;
+constexpr int TGROUP_SPLIT = 2 * NCLS * TROW;
+static_assert(GSPLIT * TGROUP_SPLIT <= GMAX * TGROUP, "split tables must fit the LDS of the combined ones");
 // Stored values are V + 1024 per int16 field: always a positive normal fp16 bit pattern.
 constexpr uint32_t BIAS16 = 0x0400u;
 constexpr uint32_t BIAS2 = 0x04000400u;
@@ -97,8 +103,8 @@ struct WaveInfo {
 
 // Per workgroup (WG_WAVES waves = WG_LANES pairs): the distinct fusions of its pairs, for the fast path.
 struct WgInfo {
-    int32_t n_groups;              // 0 => not eligible for the fast path (more than GMAX fusions)
-    int32_t group_f[GMAX];         // fusion_idx
+    int32_t n_groups;              // 0 => generic kernel (more than GSPLIT fusions); > GMAX => split tables
+    int32_t group_f[GSPLIT];       // fusion_idx
 };
 
 // Geometry shared by all kernels of one run (one slice).  Pair p <-> wave p>>6, lane p&63.
@@ -154,7 +160,7 @@ __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; 
 // lane in one 16-byte word, so the fill kernels move them with dwordx4 loads and stores:
 // element (row j, lane) of a plane sits at rowidx(j, lane); geometry lq1 is a multiple of 4.
 __host__ __device__ __forceinline__ int64_t rowidx(int j, int lane) { return ((int64_t)(j >> 2) * WAVE + lane) * 4 + (j & 3); }
-constexpr uint32_t CODE_MASK = 0xFF00FF00u;   // rowcodes: byte codes; the low byte carries the fast-path table row
+constexpr uint32_t CODE_MASK = 0xFF00FF00u;   // rowcodes: byte codes; bytes 0 and 2 carry the table row / the two classes
 // unbiased V of one field
 __device__ __forceinline__ int half_of(uint32_t v, int h) { return (int)((v >> (16 * h)) & 0xFFFFu) - (int)BIAS16; }
 
@@ -204,7 +210,7 @@ __device__ __forceinline__ void table_row_classes(int t, int& k1, int& k2)   // 
 // (group, column): the five per-class terms of either field are formed once and combined into the 25
 // table rows, so a tile's tables cost ~100 instructions per thread.  code_of(gi, i, q0, q1) returns the
 // 16-bit reference codes of column i (REF_PAD16 = padding) for M1 / M2.
-template <class CodeFn>
+template <bool SPLIT, class CodeFn>
 __device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_groups, CodeFn&& code_of)
 {
     for (int e = threadIdx.x; e < n_groups * W; e += WG_LANES) {
@@ -220,12 +226,21 @@ __device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_gro
         }
         // +2 per field for i > 0: the diagonal move from column i-1 to i picks up the drift
         const uint32_t drift = i > 0 ? TWO2 : 0u;
-        uint32_t* col = T + gi * TGROUP + i;
+        if (SPLIT) {                   // rows 0..4: M1 term by M1 class (lo field), rows 5..9: M2 term (hi field)
+            uint32_t* col = T + gi * TGROUP_SPLIT + i;
 #pragma unroll
-        for (int t = 0; t < NCOMBO; ++t) {
-            int k1, k2;
-            table_row_classes(t, k1, k2);
-            col[t * TROW] = (lo[k1] | hi[k2]) + drift;
+            for (int k = 0; k < NCLS; ++k) {
+                col[k * TROW] = lo[k] + (drift & 0xFFFFu);
+                col[(NCLS + k) * TROW] = hi[k] + (drift & 0xFFFF0000u);
+            }
+        } else {
+            uint32_t* col = T + gi * TGROUP + i;
+#pragma unroll
+            for (int t = 0; t < NCOMBO; ++t) {
+                int k1, k2;
+                table_row_classes(t, k1, k2);
+                col[t * TROW] = (lo[k1] | hi[k2]) + drift;
+            }
         }
     }
 }
@@ -251,7 +266,8 @@ __device__ __forceinline__ bool pack_rows_wave(const uint8_t* __restrict__ read_
                 const uint32_t b0 = read_bytes[(int64_t)pr.read_off + (j - 1)];
                 const uint32_t b1 = read_bytes[(int64_t)pr.read_off + (pr.read_len - j)];
                 exotic |= !is_fast_base(b0);                       // b1 is some other row's b0
-                code[sidx] = (b0 << 8) | (b1 << 24) | table_row(base_class(b0), base_class(b1));
+                const uint32_t k1 = base_class(b0), k2 = base_class(b1);
+                code[sidx] = (b0 << 8) | (b1 << 24) | table_row(k1, k2) | ((k1 | (k2 << 4)) << 16);   // byte 2: classes, split tables
             }
         }
         out[(int64_t)gq * WAVE] = make_uint4(code[0], code[1], code[2], code[3]);
@@ -371,13 +387,13 @@ struct LaneInfo {
     uint16_t n_kept;
     uint16_t last_row;        // bit 15 (TASK_FAST): the pair's first task is replayed by the workgroup
     uint8_t  c0, c1;          // its tile pair (NO_CHUNK: side not replayed)
-    uint16_t first_a_group;   // first kept a (13 bits) | fusion group of the pair << 13
+    uint16_t key_group;       // sort key min(first kept a, 255) | fusion group of the pair << 8
     uint16_t lq;
     uint8_t  nv0, nv1;        // valid columns of the two tiles
 };
 constexpr int KCACHE = 3;     // kept rows per pair that travel through LDS as well
 struct FinishLds {
-    int tile[GMAX];
+    int tile[GSPLIT];
     int hist[258];
     unsigned short order[WG_LANES];
     LaneInfo info[WG_LANES];
@@ -427,7 +443,7 @@ __device__ __forceinline__ void combine_wg(
     const bool active = p < g.n_pairs;
     const int64_t w = p >> 6;
     const int lane = (int)(p & 63);
-    if (tid < GMAX) fl->tile[tid] = -1;
+    if (tid < GSPLIT) fl->tile[tid] = -1;
     const uint32_t* rm = rmax + w * g.lq1 * WAVE;
     const uint4* rm4 = reinterpret_cast<const uint4*>(rm) + lane;
     const uint4* tm4 = reinterpret_cast<const uint4*>(tmask + w * g.lq1 * WAVE) + lane;
@@ -562,7 +578,7 @@ __device__ __forceinline__ void combine_wg(
     // offer the first tile pair to the table-driven replay
     int gsel = -1;
 #pragma unroll
-    for (int k = 0; k < GMAX; ++k)
+    for (int k = 0; k < GSPLIT; ++k)
         if (k < wgi.n_groups && wgi.group_f[k] == fidx) gsel = k;
     int key = -1;
     if (n_tasks > 0 && small && fast_wg && gsel >= 0) {
@@ -574,7 +590,7 @@ __device__ __forceinline__ void combine_wg(
     // replay's counting sort; windows of more than VOTE_TILES tiles take the first offer instead.
     constexpr int VOTE_TILES = 8, VOTE_KEYS = (VOTE_TILES + 1) * (VOTE_TILES + 1);
     static_assert(GMAX * VOTE_KEYS <= 2 * 258, "votes must fit the histogram words");
-    const bool vote = g.nch <= VOTE_TILES;                     // uniform
+    const bool vote = g.nch <= VOTE_TILES && wgi.n_groups <= GMAX;   // uniform
     auto vote_slot = [&](int k) -> int {
         const int c0 = k >> 8, c1 = k & 0xFF;
         return (c0 == (int)NO_CHUNK ? VOTE_TILES : c0) * (VOTE_TILES + 1) + (c1 == (int)NO_CHUNK ? VOTE_TILES : c1);
@@ -625,7 +641,7 @@ __device__ __forceinline__ void combine_wg(
         li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST) : (uint16_t)0;
         li.c0 = here ? (uint8_t)c0 : NO_CHUNK;
         li.c1 = here ? (uint8_t)c1 : NO_CHUNK;
-        li.first_a_group = (uint16_t)((first_a & 0x1FFF) | ((gsel >= 0 ? gsel : 0) << 13));
+        li.key_group = (uint16_t)((first_a < 255 ? first_a : 255) | ((gsel >= 0 ? gsel : 0) << 8));
         li.lq = (uint16_t)lq;
         const int v0 = len0 - c0 * W, v1 = len1 - c1 * W;
         li.nv0 = (uint8_t)(here && c0 != NO_CHUNK ? (v0 < W ? (v0 > 0 ? v0 : 0) : W) : 0);
@@ -780,26 +796,20 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
 // LDS score tables as the fill (no row maxima, no stores: add + max3 per column).  Called by all
 // threads of the workgroup after combine_wg<true>, whose LDS hand-off (fl) says what to replay; T is
 // free by then (barriers inside combine_wg).
+template <bool SPLIT>
 __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const WgInfo& wgi, const FinishBufs& fb,
                                                const uint32_t* __restrict__ refcodes, const uint32_t* __restrict__ rowcodes,
                                                const uint32_t* __restrict__ bnd, const Geom& g)
 {
     const KeptRow* __restrict__ kept = fb.kept;
     uint64_t* __restrict__ masks = fb.masks;
-    int tile[GMAX];
+    constexpr int NG = SPLIT ? GSPLIT : GMAX;
     bool any = false;
-#pragma unroll
-    for (int k = 0; k < GMAX; ++k) {
-        tile[k] = fl->tile[k];
-        any |= tile[k] >= 0;
-    }
+    for (int k = 0; k < NG; ++k) any |= fl->tile[k] >= 0;
     if (!any) return;                                   // uniform
     // tables for the agreed tile pair of every fusion of the workgroup
-    build_tables(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
-        int key = -1;
-#pragma unroll
-        for (int k = 0; k < GMAX; ++k)
-            if (k == gi) key = tile[k];
+    build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
+        const int key = fl->tile[gi];
         q0 = q1 = REF_PAD16;                 // no tile agreed: nobody reads this group's table
         if (key >= 0) {
             const int c0 = key >> 8, c1 = key & 0xFF;
@@ -816,7 +826,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
     int my_key = 256, my_rank = 0;
     {
         const LaneInfo mine = fl->info[threadIdx.x];
-        if (mine.last_row & TASK_FAST) my_key = min((int)(mine.first_a_group & 0x1FFF), 255);
+        if (mine.last_row & TASK_FAST) my_key = mine.key_group & 0xFF;
         my_rank = atomicAdd(&fl->hist[my_key], 1);
     }
     __syncthreads();
@@ -845,7 +855,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
     if (Rw == 0) return;                                  // wave-uniform; no barriers below
     const bool has0 = has && li.c0 != NO_CHUNK, has1 = has && li.c1 != NO_CHUNK;
     const int c0 = has0 ? li.c0 : 0, c1 = has1 ? li.c1 : 0;
-    const uint32_t* tb = T + (li.first_a_group >> 13) * TGROUP;
+    const uint32_t* tb = T + (li.key_group >> 8) * (SPLIT ? TGROUP_SPLIT : TGROUP);
     const int64_t wr = w < g.n_waves ? w : (int64_t)blockIdx.x * WG_WAVES;   // idle lanes read a valid plane
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + wr * g.lq1 * WAVE) + lane;
     const uint4* bi0 = reinterpret_cast<const uint4*>(bnd + (wr * g.nch + (c0 - 1)) * g.lq1 * WAVE) + lane;
@@ -883,14 +893,23 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
             const int j = 4 * gq + sidx;
             const uint32_t bcur = bv[sidx];
             if (j >= 1 && j <= Rw) {                     // wave-uniform
-                const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
-                uint4 v = trow[0];
+                const uint4* trow = reinterpret_cast<const uint4*>(tb + (SPLIT ? (rcv[sidx] >> 16) & 0xFu : rcv[sidx] & 0xFFu) * TROW);
+                const uint4* trow_hi = reinterpret_cast<const uint4*>(tb + (NCLS + ((rcv[sidx] >> 20) & 0xFu)) * TROW);   // SPLIT only
+                auto table4 = [&](int q) -> uint4 {
+                    uint4 t = trow[q];
+                    if (SPLIT) {
+                        const uint4 h = trow_hi[q];
+                        t.x += h.x; t.y += h.y; t.z += h.z; t.w += h.w;
+                    }
+                    return t;
+                };
+                uint4 v = table4(0);
                 uint32_t a = bprev + v.x;
                 uint32_t up = bcur - TWO2;
 #pragma unroll
                 for (int q = 0; q < W / 4; ++q) {
                     uint4 vn = v;
-                    if (q + 1 < W / 4) vn = trow[q + 1];
+                    if (q + 1 < W / 4) vn = table4(q + 1);
                     uint32_t an;
                     an = X[4 * q + 0] + v.y;
                     X[4 * q + 0] = max3(a, X[4 * q + 0], up);
@@ -1094,6 +1113,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 // A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column; four rows share one
 // dwordx4 load of row codes / boundary and one dwordx4 store of tile maxima / boundary.
 // ---------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            const WaveInfo* __restrict__ winfo,
                                                            const WgInfo* __restrict__ wginfo,
@@ -1111,10 +1131,11 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
+    const WgInfo wgi = wginfo[blockIdx.x];
+    if ((wgi.n_groups > GMAX) != SPLIT) return;  // the other instantiation owns it (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
     const int lane = threadIdx.x & 63;
-    const WgInfo wgi = wginfo[blockIdx.x];
     WaveInfo wi = {0, 0};
     int f = 0;
     // Exact pruning: a cell with V(i,j) < 4j - slack, slack = 2*Lq - minScore, can never
@@ -1155,9 +1176,9 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 
     int gsel = 0;
 #pragma unroll
-    for (int k = 0; k < GMAX; ++k)
+    for (int k = 0; k < (SPLIT ? GSPLIT : GMAX); ++k)
         if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
-    const uint32_t* tb = T + gsel * TGROUP;
+    const uint32_t* tb = T + gsel * (SPLIT ? TGROUP_SPLIT : TGROUP);
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
     int stop_prev = 0;                   // stored row groups of the tile to the left
     TileStops stops = {};
@@ -1179,7 +1200,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 #if defined(DSA_EXP_NOTABLE) || defined(DSA_EXP_NOBARRIER)
         if (c == 0)
 #endif
-        build_tables(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
+        build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
             const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
             q0 = code & 0xFFFFu;
             q1 = code >> 16;
@@ -1223,6 +1244,34 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                 if (j >= 1 && j <= wi.lq_max) {             // wave-uniform
                     // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
                     // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
+                    if constexpr (SPLIT) {
+                        const uint4* tlo = reinterpret_cast<const uint4*>(tb + ((rcv[sidx] >> 16) & 0xFu) * TROW);
+                        const uint4* thi = reinterpret_cast<const uint4*>(tb + (NCLS + ((rcv[sidx] >> 20) & 0xFu)) * TROW);
+                        uint4 lo = tlo[0], hi = thi[0];
+                        uint32_t a = bprev + lo.x + hi.x;
+                        uint32_t up = bcur - TWO2;
+#pragma unroll
+                        for (int q = 0; q < W / 4; ++q) {
+                            uint4 lo1 = lo, hi1 = hi;             // one table read of either kind in flight
+                            if (q + 1 < W / 4) { lo1 = tlo[q + 1]; hi1 = thi[q + 1]; }
+                            uint32_t an;
+                            an = X[4 * q + 0] + lo.y + hi.y;
+                            X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                            a = an;
+                            an = X[4 * q + 1] + lo.z + hi.z;
+                            X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                            a = an;
+                            an = X[4 * q + 2] + lo.w + hi.w;
+                            X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                            a = an;
+                            an = X[4 * q + 3] + lo1.x + hi1.x;
+                            X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                            a = an;
+                            up = X[4 * q + 3];
+                            lo = lo1;
+                            hi = hi1;
+                        }
+                    } else {
                     const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
                     uint4 vq[FILL_PF + 1];                  // table reads in flight
 #ifdef DSA_ABLATE_LDS
@@ -1255,6 +1304,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                         X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
                         a = an;
                         up = X[4 * q + 3];
+                    }
                     }
                     cmv[sidx] = tile_row_max<false>(X, W, W);
                     bov[sidx] = X[W - 1] - drift2(W - 1);
@@ -1304,7 +1354,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, &fl, fb, g);
     STAT_T(t_rep);
 #ifndef DSA_ABLATE_REPLAY
-    replay_fast_wg(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
+    replay_fast_wg<SPLIT>(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
 #endif
 #endif
 #ifdef DSA_PRUNE_STATS

@@ -69,6 +69,27 @@ def test_parity_single_fusion_fast_path(gpu_ctx, ora):
     assert len(got) > 300
 
 
+def test_parity_split_table_tier(gpu_ctx, ora):
+    """Workgroups of five to ten fusions (30 reads each, reads over {A,C,G,T,N}) take the fill kernel with two
+    small LDS tables per fusion; twelve reads per fusion push workgroups past ten fusions onto the generic one."""
+    import numpy as np
+    rng = np.random.default_rng(79)
+    for reads_per_fusion, n_fusions in ((30, 40), (12, 60)):
+        bb = cases.BatchBuilder()
+        for k in range(n_fusions):
+            ref0, ref1 = cases.rnd(rng, int(rng.integers(200, 420))), cases.rnd(rng, int(rng.integers(200, 420)), b"ACGTN")
+            f = bb.add_fusion(ref0, ref1)
+            for r in range(reads_per_fusion):
+                read = cases.mutate(rng, cases.split_read(rng, ref0, ref1, int(rng.integers(40, 77))), 0.02)
+                if r % 9 == 0:
+                    b = bytearray(read)
+                    b[int(rng.integers(0, len(b)))] = ord("N")
+                    read = bytes(b)
+                bb.add_read(f, read)
+        got = check_batch(gpu_ctx, ora, bb.arrays())
+        assert len(got) > 200
+
+
 def test_parity_exotic_reads_hand_workgroups_over(gpu_ctx, ora):
     """Several workgroups of two fusions; a lowercase read every 300 pairs makes the fast kernel hand just
     those workgroups to the generic one (decided on the device while packing the rows)."""
