@@ -943,10 +943,15 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
 //   cmax[((w*nch + c)*lq1 + j)*64 + lane] = max over the tile's valid columns of V(.,j)   (2 x u16, biased)
 //   bnd [((w*nch + c)*lq1 + j)*64 + lane] = V(last column of tile c, j)
 // ---------------------------------------------------------------------------------------------
+// Pruning as in k_fill_fast (exact): lq_lane / slack are the lane's read length and
+// 2*Lq - minScore, l_in the last row at which a live value can still enter from the left, stop_prev the
+// stored row groups of the tile to the left.  Returns the row groups stored for this tile; last_bnd is
+// the last row whose outgoing boundary is alive for this lane.
 template <bool MASKED>
-__device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const uint4* __restrict__ rows4,
-                                                   const uint4* __restrict__ bi4, uint4* __restrict__ cm4,
-                                                   uint4* __restrict__ bo4, int lq, bool first, int nv0, int nv1)
+__device__ __forceinline__ int sweep_tile_generic(const uint32_t (&r)[W], const uint4* __restrict__ rows4,
+                                                  const uint4* __restrict__ bi4, uint4* __restrict__ cm4,
+                                                  uint4* __restrict__ bo4, int lq, bool first, int nv0, int nv1,
+                                                  int lq_lane, int slack, int l_in, int stop_prev, int& last_bnd)
 {
     uint32_t X[W];
 #pragma unroll
@@ -955,14 +960,17 @@ __device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const
     uint32_t bprev = BIAS2;
     const int ngq = (lq >> 2) + 1;
     uint4 rc_n = rows4[0];
-    uint4 b_n = first ? bias4 : bi4[0];
-    for (int gq = 0; gq < ngq; ++gq) {
+    uint4 b_n = first ? bias4 : bi4[0];                     // every tile stores at least its first row group
+    last_bnd = 0;
+    int gq = 0;
+    for (; gq < ngq; ++gq) {
         const uint4 rc = rc_n, b = b_n;
         const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
         rc_n = rows4[(int64_t)gn * WAVE];
-        b_n = first ? bias4 : bi4[(int64_t)gn * WAVE];
+        b_n = (!first && gn < stop_prev) ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
         const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
         uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+        bool alive = false;
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
             const int j = 4 * gq + sidx;
@@ -970,12 +978,20 @@ __device__ __forceinline__ void sweep_tile_generic(const uint32_t (&r)[W], const
                 row_step(X, r, rcv[sidx], bprev, bv[sidx]);
                 cmv[sidx] = tile_row_max<MASKED>(X, nv0, nv1);
                 bov[sidx] = X[W - 1] - drift2(W - 1);
+                const int thr = 4 * j - slack + (int)BIAS16;
+                const bool in_read = j <= lq_lane;
+                alive |= in_read && ((int)(cmv[sidx] & 0xFFFFu) >= thr || (int)(cmv[sidx] >> 16) >= thr);
+                if (in_read && ((int)(bov[sidx] & 0xFFFFu) >= thr || (int)(bov[sidx] >> 16) >= thr)) last_bnd = j;
             }
             bprev = bv[sidx];
         }
         cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
         bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+#ifndef DSA_NO_PRUNE
+        if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
+#endif
     }
+    return gq;
 }
 
 // After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
@@ -1078,6 +1094,19 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         const dsa_fusion fu = fusions[f];
         const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
         const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+        int lq_lane = 0, slack = 0;
+        if ((int64_t)w * WAVE + lane < g.n_pairs) {
+            lq_lane = pairs[p].read_len;
+            slack = 2 * lq_lane - min_score_tab[lq_lane];
+        }
+        auto wave_max = [](int v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+            return v;
+        };
+        int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
+        int stop_prev = 0;
+        TileStops stops = {};
 
         for (int c = 0; c < wi.nch_max; ++c) {
             uint32_t r[W];
@@ -1087,17 +1116,20 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
             uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
             uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
             const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
+            int last_bnd, stop;
             if (__builtin_amdgcn_ballot_w64(nv0 < W || nv1 < W) == 0)
-                sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
+                stop = sweep_tile_generic<false>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1, lq_lane, slack, l_in, stop_prev, last_bnd);
             else
-                sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1);
-            if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = (wi.lq_max >> 2) + 1;    // no pruning here: every row group is stored
+                stop = sweep_tile_generic<true>(r, rows4, bi4, cm4, bo4, wi.lq_max, c == 0, nv0, nv1, lq_lane, slack, l_in, stop_prev, last_bnd);
+            if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = stop;
+            stop_prev = stop;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k == c) stops.v[k] = stop;
+            l_in = wave_max(last_bnd);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        TileStops all;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) all.v[k] = (wi.lq_max >> 2) + 1;
-        reduce_row_max(cmax, rmax, tmask, fb.tstop, all, g, w, lane, wi.nch_max, wi.lq_max);
+        reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
     const WgInfo wgi = wginfo[blockIdx.x];
     combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
