@@ -30,9 +30,11 @@
 //     a per-(fusion,tile) score table in LDS with one ds_read_b128 per 4 columns.  Generic path (any
 //     bytes): d(i) from xor + pk_min.
 //   * per (tile,row) the kernel stores the tile's row maximum and the tile's last column (the
-//     boundary the next tile starts from).  The finish kernels pick the winning rows and replay only
-//     the winning tiles from the stored boundaries to enumerate tied columns — exact, at a few
-//     percent of the fill work instead of a second full pass.
+//     boundary the next tile starts from).  In its tail the same workgroup picks the winning rows
+//     (combine_wg) and replays only the winning tile pair from the stored boundaries to enumerate tied
+//     columns (replay_fast_wg) — exact, at a fraction of the fill work instead of a second full pass,
+//     and in the shadow of the other resident workgroups' sweeps.  k_replay takes the left-over tiles,
+//     k_emit writes the records.
 //
 // Everything here is integer; results are bit-exact with the reference by construction.
 #pragma once
@@ -994,9 +996,9 @@ __device__ __forceinline__ int sweep_tile_generic(const uint32_t (&r)[W], const 
     return gq;
 }
 
-// After the last tile: rmax = max over tiles of cmax (both fields), so the combine kernel reads one
+// After the last tile: rmax = max over tiles of cmax (both fields), so the combine step reads one
 // dword per row instead of one per tile; tmask = which tiles attain it (bit c: M1 tile c, bit 16+c:
-// M2 tile c; only meaningful while a reference has at most 16 tiles, the combine kernel falls back to
+// M2 tile c; only meaningful while a reference has at most 16 tiles, the combine step falls back to
 // cmax otherwise).  cmax of this wave is L2-hot.
 __device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
 {

@@ -84,9 +84,9 @@ typedef struct dsa_limits {
 
 /* Timings of the most recent dsa_run / dsa_align_batch, measured with HIP events on the ctx stream. */
 typedef struct dsa_timing {
-    float   pack_ms;              /* byte -> code packing kernels                                */
-    float   fill_ms;              /* the DP fill kernel(s) — the dominant kernel                 */
-    float   finish_ms;            /* combine + tile replay + emit kernels                        */
+    float   pack_ms;              /* reference bytes -> codes (rows are packed inside the fill)  */
+    float   fill_ms;              /* the DP fill kernel(s), with combine and table replay in their tail */
+    float   finish_ms;            /* left-over tile replay + emit kernels                        */
     float   total_ms;             /* elapsed host time of dsa_run (stage times overlap between slices) */
     int32_t fill_launches;        /* number of DP fill launches in fill_ms                       */
     int32_t n_generic_tasks;      /* of n_replay_tasks: tiles re-run by the generic replay kernel   */

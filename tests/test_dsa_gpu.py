@@ -43,7 +43,7 @@ def test_parity_long_reads_many_tiles(gpu_ctx, ora):
 
 
 def test_parity_many_tiles_paths(gpu_ctx, ora):
-    """References of 17-20 tiles (beyond the 16-tile winning-tile masks: the combine kernel falls back to
+    """References of 17-20 tiles (beyond the 16-tile winning-tile masks: the combine step falls back to
     the per-tile maxima) and of more than 64 tiles (every tile of a kept pair is replayed)."""
     got = check_batch(gpu_ctx, ora, cases.mixed_batch(31, n_fusions=3, reads_per_fusion=24, lq=60, lr=(1050, 1250)))
     assert len(got) > 10
