@@ -25,6 +25,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;   // elements
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
@@ -250,7 +254,8 @@ int grow_records(dsa_ctx* ctx, size_t need)
     if (ctx->n_records)
         HIPC(hipMemcpy(bigger.p, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice));
     ctx->d_records.release();
-    ctx->d_records = bigger;
+    std::swap(ctx->d_records.p, bigger.p);
+    std::swap(ctx->d_records.cap, bigger.cap);
     return DSA_OK;
 }
 

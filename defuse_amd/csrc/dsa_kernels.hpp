@@ -1226,23 +1226,14 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
 #endif
     for (int c = 0; c < nch_wg; ++c) {
         STAT_T(ts0);
-#ifdef DSA_EXP_NOBARRIER
-        if (c == 0)
-#endif
         __syncthreads();                          // previous tile's tables no longer in use
         STAT_T(ts1);
-#if defined(DSA_EXP_NOTABLE) || defined(DSA_EXP_NOBARRIER)
-        if (c == 0)
-#endif
         build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
             const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
             q0 = code & 0xFFFFu;
             q1 = code >> 16;
         });
         STAT_T(ts2);
-#ifdef DSA_EXP_NOBARRIER
-        if (c == 0)
-#endif
         __syncthreads();
 #ifdef DSA_PRUNE_STATS
         t_bar += (ts1 - ts0) + (__builtin_readcyclecounter() - ts2);
@@ -1522,12 +1513,8 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                 const int j = 4 * gq + sidx;
                 const uint32_t bcur = bv[sidx];
                 if (j >= 1 && j <= R) {
-#ifndef DSA_EXP_REPLAY_NOSTEP
                     row_step(X, r, rcv[sidx], bprev, bcur);
-#endif
-#ifndef DSA_EXP_REPLAY_NOHITS
                     record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
-#endif
                 }
                 bprev = bcur;
             }
