@@ -107,6 +107,7 @@ struct dsa_ctx {
     int32_t n_fusions = 0;
     DevBuf<uint8_t> d_ref, d_reads;
     DevBuf<dsa_fusion> d_fusions;
+    DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig), when pairs were reordered
     DevBuf<dsa_pair> d_pairs;
     DevBuf<int32_t> d_min_score;
     std::vector<Slice> slices;
@@ -161,6 +162,76 @@ size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 
 // Slices bound the scratch footprint; inside a slice pair p lives in wave p/64, lane p%64.
 // Per wave the loop bounds, per workgroup (256 pairs) the distinct fusions for the fast path.
+int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs);
+
+// Sweep order (speed only; records always come out in the caller's pair order).  Workgroups are 256
+// consecutive pairs, waves 64: fusions with many reads go first (table-driven tiers), and inside a size
+// class fusions whose alignments end in the same tiles (device probe) sit next to each other, so the lanes
+// of a wave that straddles two fusions are alive in the same tiles.  Only for batches of one slice: the
+// record offsets of a reordered batch come from one scan over all pairs.  DEFUSE_DSA_NO_REORDER=1 keeps
+// the caller's order.
+int reorder_for_pruning(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
+{
+    const int nf = ctx->n_fusions;
+    const char* off = getenv("DEFUSE_DSA_NO_REORDER");
+    if (nf < 2 || n_pairs < 2 * WG_LANES || ctx->slices.size() != 1 || (off && atoi(off) != 0)) return DSA_OK;
+    hipStream_t st = ctx->stream;
+    std::vector<uint8_t> tiles((size_t)2 * nf);
+    {
+        DevBuf<int32_t> d_taken, d_votes;
+        DevBuf<uint8_t> d_tiles;
+        HIPC(d_taken.reserve((size_t)nf));
+        HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
+        HIPC(d_tiles.reserve((size_t)nf * 2));
+        HIPC(hipMemsetAsync(d_taken.p, 0, (size_t)nf * sizeof(int32_t), st));
+        HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_probe_votes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
+                           ctx->d_reads.p, ctx->d_pairs.p, n_pairs, d_taken.p, d_votes.p);
+        hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
+        HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
+        HIPC(hipStreamSynchronize(st));
+        HIPC(hipGetLastError());
+    }
+    std::vector<int64_t> count((size_t)nf, 0);
+    for (int64_t p = 0; p < n_pairs; ++p) ++count[pairs[p].fusion_idx];
+    auto size_class = [&](int f) { return count[f] >= WAVE ? 0 : count[f] >= WG_LANES / GSPLIT ? 1 : 2; };
+    std::vector<int32_t> forder((size_t)nf);
+    for (int f = 0; f < nf; ++f) forder[f] = f;
+    std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
+        const int ca = size_class(a), cb = size_class(b);
+        if (ca != cb) return ca < cb;
+        const int ka = tiles[2 * a] * 256 + tiles[2 * a + 1], kb = tiles[2 * b] * 256 + tiles[2 * b + 1];
+        return ka < kb;
+    });
+    std::vector<int64_t> start((size_t)nf + 1, 0);           // first sweep position of every fusion
+    for (int r = 0; r < nf; ++r) start[forder[r]] = count[forder[r]];
+    {
+        int64_t run = 0;
+        for (int r = 0; r < nf; ++r) { const int f = forder[r]; const int64_t c = start[f]; start[f] = run; run += c; }
+    }
+    std::vector<int32_t> orig((size_t)n_pairs);
+    std::vector<dsa_pair> sweep((size_t)n_pairs);
+    bool identity = true;
+    for (int64_t p = 0; p < n_pairs; ++p) {                  // stable inside a fusion
+        const int64_t q = start[pairs[p].fusion_idx]++;
+        orig[q] = (int32_t)p;
+        sweep[q] = pairs[p];
+        identity = identity && q == p;
+    }
+    if (identity) return DSA_OK;
+    HIPC(ctx->d_orig.reserve((size_t)n_pairs));
+    HIPC(hipMemcpyAsync(ctx->d_orig.p, orig.data(), (size_t)n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ctx->d_pairs.p, sweep.data(), (size_t)n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    if (int rc = build_slices(ctx, fusions, sweep.data(), n_pairs)) return rc;
+    if (ctx->slices.size() != 1) {                           // cannot happen (same pairs), but never sweep a split batch reordered
+        HIPC(hipMemcpy(ctx->d_pairs.p, pairs, (size_t)n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice));
+        return build_slices(ctx, fusions, pairs, n_pairs);
+    }
+    ctx->slices[0].g.orig = ctx->d_orig.p;
+    return DSA_OK;
+}
+
 int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
 {
     ctx->slices.clear();
@@ -224,6 +295,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
         cur.g.lrp = nch * W;
         cur.g.n_fusions = ctx->n_fusions;
         cur.g.n_pairs = cur.pair_end - cur.pair_begin;
+        cur.g.orig = nullptr;
         ctx->slices.push_back(std::move(cur));
     }
     return DSA_OK;
@@ -463,7 +535,7 @@ void dsa_destroy(dsa_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release();
+    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release();
     (void)hipDeviceSynchronize();
     ctx->d_min_score.release(); ctx->d_records.release();
     for (PipeLane& L : ctx->lane) {
@@ -553,7 +625,8 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     HIPC(ctx->d_min_score.reserve(tab.size()));
     HIPC(hipMemcpyAsync(ctx->d_min_score.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPC(hipStreamSynchronize(st));
-    return build_slices(ctx, fusions, pairs, n_pairs);
+    if (int rc = build_slices(ctx, fusions, pairs, n_pairs)) return rc;
+    return reorder_for_pruning(ctx, fusions, pairs, n_pairs);
 }
 
 int dsa_run(dsa_ctx* ctx, int64_t* out_n)

@@ -118,6 +118,7 @@ struct Geom {
     int32_t lrp;           // refcodes stride = nch * W
     int32_t n_fusions;
     int64_t n_pairs;
+    const int32_t* orig;   // pair order of the sweep -> the caller's pair index (nullptr: the same order)
 #ifdef DSA_PRUNE_STATS
     unsigned long long* stats;   // diagnostic builds only
 #endif
@@ -183,6 +184,71 @@ __global__ void k_pack_refs(const uint8_t* __restrict__ ref_bytes, const dsa_fus
     if (i < f.ref0_len) lo = (uint32_t)ref_bytes[(int64_t)f.ref0_off + i] << 8;
     if (i < f.ref1_len) hi = (uint32_t)ref_bytes[(int64_t)f.ref1_off + (f.ref1_len - 1 - i)] << 8;
     refcodes[t] = lo | (hi << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Probe for the sweep order (speed heuristic only: any order gives the same records).  Up to
+// PROBE_READS reads per fusion vote for the tile in which their M1 / M2 alignment ends: the first 16
+// bases of the read are looked up in window 0 and extended along the diagonal, the last 16 bases in
+// window 1 and extended backwards (X-drop).  k_probe_pick takes the majority per window.  Fusions
+// with the same tiles are then swept next to each other, so that a wave that straddles two fusions is
+// alive in the same tiles for both and the exact pruning stops the other tiles early.
+// ---------------------------------------------------------------------------------------------
+constexpr int PROBE_READS = 8, PROBE_SEED = 16, PROBE_TILES = 16;
+__global__ void k_probe_votes(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
+                              const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs, int64_t n_pairs,
+                              int32_t* __restrict__ taken, int32_t* __restrict__ votes)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const dsa_pair pr = pairs[p];
+    const int lq = pr.read_len;
+    if (lq < PROBE_SEED + 8) return;
+    if (atomicAdd(&taken[pr.fusion_idx], 1) >= PROBE_READS) return;
+    const dsa_fusion fu = fusions[pr.fusion_idx];
+    const uint8_t* rd = read_bytes + pr.read_off;
+    const uint8_t* r0 = ref_bytes + fu.ref0_off;
+    const uint8_t* r1 = ref_bytes + fu.ref1_off;
+    for (int x = 0; x + PROBE_SEED <= fu.ref0_len; ++x) {          // M1: prefix seed, extend forwards
+        int k = 0;
+        while (k < PROBE_SEED && r0[x + k] == rd[k]) ++k;
+        if (k < PROBE_SEED) continue;
+        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;
+        for (k = PROBE_SEED; k < lq && x + k < fu.ref0_len && score > best - 6; ++k) {
+            score += r0[x + k] == rd[k] ? 1 : -2;
+            if (score > best) { best = score; best_k = k; }
+        }
+        const int tile = (x + best_k) / W;                          // matrix column x + best_k + 1
+        atomicAdd(&votes[((int64_t)pr.fusion_idx * 2 + 0) * PROBE_TILES + min(tile, PROBE_TILES - 1)], 1);
+        break;
+    }
+    for (int y = 0; y + PROBE_SEED <= fu.ref1_len; ++y) {          // M2: suffix seed, extend backwards
+        int k = 0;
+        while (k < PROBE_SEED && r1[y + k] == rd[lq - PROBE_SEED + k]) ++k;
+        if (k < PROBE_SEED) continue;
+        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;   // k counts bases from the read's end
+        for (k = PROBE_SEED; k < lq && y + PROBE_SEED - 1 - k >= 0 && score > best - 6; ++k) {
+            score += r1[y + PROBE_SEED - 1 - k] == rd[lq - 1 - k] ? 1 : -2;
+            if (score > best) { best = score; best_k = k; }
+        }
+        const int s1 = y + PROBE_SEED - 1 - best_k;                 // first window-1 base of the aligned suffix
+        const int tile = (fu.ref1_len - s1 - 1) / W;                // its column in the reversed window is len1 - s1
+        atomicAdd(&votes[((int64_t)pr.fusion_idx * 2 + 1) * PROBE_TILES + min(max(tile, 0), PROBE_TILES - 1)], 1);
+        break;
+    }
+}
+
+// tiles[2f + s] = majority tile of window s of fusion f, 255 without votes
+__global__ void k_probe_pick(const int32_t* __restrict__ votes, int n_windows, uint8_t* __restrict__ tiles)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_windows) return;
+    int best = 0, tile = 255;
+    for (int t = 0; t < PROBE_TILES; ++t) {
+        const int n = votes[(int64_t)q * PROBE_TILES + t];
+        if (n > best) { best = n; tile = t; }
+    }
+    tiles[q] = (uint8_t)tile;
 }
 
 __device__ __forceinline__ bool is_fast_base(uint32_t b)
@@ -1558,14 +1624,15 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= g.n_pairs) return;
+    const int64_t o = g.orig ? g.orig[p] : p;      // records are counted and written in the caller's pair order
     const PairState st = state[p];
     int64_t n = 0;
     if (st.n_kept > 0) {
         const dsa_pair pr = pairs[p];
         const dsa_fusion fu = fusions[pr.fusion_idx];
         const uint32_t tb = st.task_begin, te = tb + st.n_tasks;
-        int64_t wr = WRITE ? rec_offset[p] : 0;
-        if (WRITE && (uint64_t)rec_offset[p + 1] > out_cap) return;   // host grows the buffer and reruns emit
+        int64_t wr = WRITE ? rec_offset[o] : 0;
+        if (WRITE && (uint64_t)rec_offset[o + 1] > out_cap) return;   // host grows the buffer and reruns emit
         for (int k = 0; k < st.n_kept; ++k) {
             const KeptRow kr = kept[st.kept_begin + k];
             for (uint32_t q1 = tb; q1 < te; ++q1) {        // tasks hold M1 tiles in ascending order
@@ -1595,7 +1662,7 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
                                 rec.read_first = kr.a;
                                 rec.read_second = pr.read_len - kr.a;
                                 rec.score = kr.m1 < kr.m2 ? kr.m1 : kr.m2;
-                                rec.pair_idx = (int32_t)(pair_base + p);
+                                rec.pair_idx = (int32_t)(pair_base + o);
                                 out[wr] = rec;
                             }
                             ++wr;
@@ -1606,7 +1673,7 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
             }
         }
     }
-    if (!WRITE) rec_count[p] = n;
+    if (!WRITE) rec_count[o] = n;
 }
 
 }  // namespace dsa
