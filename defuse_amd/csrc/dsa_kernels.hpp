@@ -1056,7 +1056,7 @@ __device__ __forceinline__ int sweep_tile_generic(const uint32_t (&r)[W], const 
         cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
         bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
 #ifndef DSA_NO_PRUNE
-        if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
+        if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
 #endif
     }
     return gq;
@@ -1415,7 +1415,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             }
 #endif
 #ifndef DSA_NO_PRUNE
-            if (4 * gq + 3 >= l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform
+            if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
 #endif
         }
 #ifdef DSA_PRUNE_STATS

@@ -69,6 +69,30 @@ def test_parity_single_fusion_fast_path(gpu_ctx, ora):
     assert len(got) > 300
 
 
+def test_parity_pruning_diagonal_entry(gpu_ctx, ora):
+    """A borderline alignment (one mismatch + one inserted read base: exactly minScore) that leaves tile 0 through
+    its last column at row 27 and enters tile 1 diagonally at row 28, alone in its wave: everything of tile 1 up
+    to row 27 is dead, so the pruning may only stop after the row that the live boundary value still feeds."""
+    import numpy as np
+    hits = 0
+    for seed in range(6):
+        rng = np.random.default_rng(500 + seed)
+        ref0, ref1 = bytearray(cases.rnd(rng, 130)), cases.rnd(rng, 90)
+        seg = bytearray(ref0[38:66])                     # columns 39..66: rows 27 / 28 sit on columns 64 / 65
+        seg[9] = ord("A") if seg[9] != ord("A") else ord("C")          # one mismatch
+        other = ord("G") if seg[5] != ord("G") else ord("T")
+        prefix = bytes(seg[:5]) + bytes([other]) + bytes(seg[5:])      # one inserted read base: 29 rows, 28 columns
+        read = prefix + ref1[:4]                                        # Lq = 33, minScore 59 = 51 + 8
+        bb = cases.BatchBuilder()
+        f = bb.add_fusion(bytes(ref0), ref1)
+        bb.add_read(f, read)
+        batch = bb.arrays()
+        exp = ora.align_batch(*batch)
+        hits += int(any(int(r["read_first"]) == 29 for r in exp))
+        check_batch(gpu_ctx, ora, batch)
+    assert hits >= 3          # the constructed split is really what wins in most draws
+
+
 def test_parity_split_table_tier(gpu_ctx, ora):
     """Workgroups of five to ten fusions (30 reads each, reads over {A,C,G,T,N}) take the fill kernel with two
     small LDS tables per fusion; twelve reads per fusion push workgroups past ten fusions onto the generic one."""
