@@ -204,6 +204,7 @@ __global__ void k_probe_votes(const uint8_t* __restrict__ ref_bytes, const dsa_f
     const dsa_pair pr = pairs[p];
     const int lq = pr.read_len;
     if (lq < PROBE_SEED + 8) return;
+    if (__hip_atomic_load(&taken[pr.fusion_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= PROBE_READS) return;   // cheap early out
     if (atomicAdd(&taken[pr.fusion_idx], 1) >= PROBE_READS) return;
     const dsa_fusion fu = fusions[pr.fusion_idx];
     const uint8_t* rd = read_bytes + pr.read_off;
