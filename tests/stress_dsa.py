@@ -12,6 +12,28 @@ from oracle import dosplitalign_oracle as ora
 from tests import cases
 
 
+def borderline(rng, read):
+    """Edits whose penalties add up to about the budget 2*Lq - minScore (mismatch 3, inserted base 4, deleted
+    base 2 + the lost match): alignments that sit exactly on the pruning threshold, or just beyond it."""
+    b = bytearray(read)
+    if len(b) < 12:
+        return bytes(b)
+    budget = 2 * len(b) - int(np.float32(len(b)) * np.float32(2) * 0.90) + int(rng.integers(-1, 2))
+    while budget >= 3 and len(b) > 10:
+        pos = int(rng.integers(1, len(b) - 1))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            b[pos] = ord("ACGT"[("ACGT".find(chr(b[pos])) + 1) % 4]) if chr(b[pos]) in "ACGT" else ord("A")
+            budget -= 3
+        elif kind == 1 and budget >= 4:
+            b.insert(pos, int(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8))))
+            budget -= 4
+        else:
+            del b[pos]
+            budget -= 4
+    return bytes(b)
+
+
 def random_batch(rng):
     bb = cases.BatchBuilder()
     clean = rng.random() < 0.7                        # reads over {A,C,G,T,N} only
@@ -26,7 +48,9 @@ def random_batch(rng):
         for _ in range(int(rng.integers(1, rpf_hi + 1))):
             lq = int(rng.integers(8, lq_hi + 1))
             kind = rng.random()
-            if kind < 0.7 and len(ref0) > 8 and len(ref1) > 8:
+            if kind < 0.25 and len(ref0) > 8 and len(ref1) > 8:
+                read = borderline(rng, cases.split_read(rng, ref0, ref1, lq))
+            elif kind < 0.7 and len(ref0) > 8 and len(ref1) > 8:
                 read = cases.mutate(rng, cases.split_read(rng, ref0, ref1, lq), float(rng.choice([0.0, 0.01, 0.05])))
             elif kind < 0.85:
                 read = cases.rnd(rng, lq)
