@@ -820,6 +820,7 @@ __device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr,
 __device__ __forceinline__ void equal_columns(const uint32_t (&X)[W], uint32_t target2, uint64_t& m0, uint64_t& m1)
 {
     uint32_t miss[W / 16];
+    const uint32_t one2 = 0x00010001u;
 #pragma unroll
     for (int q = 0; q < W / 16; ++q) {
         uint32_t acc = 0;
@@ -827,8 +828,8 @@ __device__ __forceinline__ void equal_columns(const uint32_t (&X)[W], uint32_t t
         for (int k = 0; k < 16; ++k) {
             const int i = 16 * q + k;
             const uint32_t e = (X[i] - drift2(i)) ^ target2;
-            const v2u one = {1, 1};
-            const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u, e), one));
+            uint32_t y;            // min(e, 1) per field; spelled out: the compiler would expand the C form
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(e), "v"(one2));   // into two compares and two selects
             acc |= y << k;         // bit k: lo field differs, bit 16+k: hi field differs
         }
         miss[q] = acc;
