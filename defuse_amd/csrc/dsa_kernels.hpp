@@ -1070,8 +1070,12 @@ __device__ __forceinline__ int sweep_tile_generic(const uint32_t (&r)[W], const 
 // cmax otherwise).  cmax of this wave is L2-hot.
 __device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
 {
-    const uint32_t x = v ^ m;
-    return ((x & 0xFFFFu) == 0u ? (1u << c) : 0u) | ((x >> 16) == 0u ? (1u << (16 + c)) : 0u);
+    // bit c if the lo fields are equal, bit 16+c if the hi fields are: min(v ^ m, 1) per field is the
+    // "differs" flag of both fields at once (one packed instruction instead of two compares and selects)
+    uint32_t differs;
+    const uint32_t one2 = 0x00010001u;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(differs) : "v"(v ^ m), "v"(one2));
+    return (differs ^ one2) << c;
 }
 struct TileStops { int v[8]; };    // stored row groups of a wave's first tiles (wave-uniform)
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
