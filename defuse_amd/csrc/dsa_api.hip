@@ -178,15 +178,13 @@ int reorder_for_pruning(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair*
     hipStream_t st = ctx->stream;
     std::vector<uint8_t> tiles((size_t)2 * nf);
     {
-        DevBuf<int32_t> d_taken, d_votes;
+        DevBuf<int32_t> d_votes;
         DevBuf<uint8_t> d_tiles;
-        HIPC(d_taken.reserve((size_t)nf));
         HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
         HIPC(d_tiles.reserve((size_t)nf * 2));
-        HIPC(hipMemsetAsync(d_taken.p, 0, (size_t)nf * sizeof(int32_t), st));
         HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
         hipLaunchKernelGGL(k_probe_votes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
-                           ctx->d_reads.p, ctx->d_pairs.p, n_pairs, d_taken.p, d_votes.p);
+                           ctx->d_reads.p, ctx->d_pairs.p, n_pairs, d_votes.p);
         hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
         HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));

@@ -197,15 +197,15 @@ __global__ void k_pack_refs(const uint8_t* __restrict__ ref_bytes, const dsa_fus
 constexpr int PROBE_READS = 8, PROBE_SEED = 16, PROBE_TILES = 16;
 __global__ void k_probe_votes(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
                               const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs, int64_t n_pairs,
-                              int32_t* __restrict__ taken, int32_t* __restrict__ votes)
+                              int32_t* __restrict__ votes)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const dsa_pair pr = pairs[p];
     const int lq = pr.read_len;
     if (lq < PROBE_SEED + 8) return;
-    if (__hip_atomic_load(&taken[pr.fusion_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= PROBE_READS) return;   // cheap early out
-    if (atomicAdd(&taken[pr.fusion_idx], 1) >= PROBE_READS) return;
+    // voters: the first PROBE_READS pairs of every run of one fusion (callers group pairs by fusion)
+    if (p >= PROBE_READS && pairs[p - PROBE_READS].fusion_idx == pr.fusion_idx) return;
     const dsa_fusion fu = fusions[pr.fusion_idx];
     const uint8_t* rd = read_bytes + pr.read_off;
     const uint8_t* r0 = ref_bytes + fu.ref0_off;
