@@ -49,12 +49,13 @@ def test_cli(built):
     assert "Mate Pair Clustering Tool" in r.stdout
 
 
-def run_tool(lines, tmp_path, m=5, stdin=False):
+def run_tool(lines, tmp_path, m=5, stdin=False, env=None):
     p = tmp_path / "spanning.txt"
     p.write_text("".join(lines))
     out = tmp_path / "clusters.txt"
     args = [TOOL, "-a", "-" if stdin else str(p), "-c", str(out), "-u", "300", "-s", "30", "-p", "0.95", "-m", str(m)]
-    r = subprocess.run(args, capture_output=True, text=True, input="".join(lines) if stdin else None)
+    r = subprocess.run(args, capture_output=True, text=True, input="".join(lines) if stdin else None,
+                       env=dict(os.environ, **env) if env else None)
     return r, out.read_text() if out.exists() else None
 
 
@@ -83,6 +84,10 @@ def test_tool_matches_oracle(built, tmp_path, seed):
     assert r.returncode == 0, r.stderr
     exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
     assert n >= 8
+    assert txt == exp
+    # the same run with the EM workspaces cut into many chunks
+    r, txt = run_tool(lines, tmp_path, env={"DEFUSE_MPE_SCRATCH_MB": "1"})
+    assert r.returncode == 0, r.stderr
     assert txt == exp
 
 
