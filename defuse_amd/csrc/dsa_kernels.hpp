@@ -139,7 +139,7 @@ struct ReplayTask {
     uint16_t last_row;     // largest row either matrix needs; bit 15 = replayed by the table-driven kernel
     uint8_t  chunk0;       // NO_CHUNK = nothing to replay on that side
     uint8_t  chunk1;
-    uint16_t first_a;      // first kept read split of the pair: the generic replay sorts its lanes by it
+    uint16_t first_a;      // min(a, lq - a) of the first kept read split: the generic replay sorts its lanes by it
     uint16_t pad_;
 };
 constexpr uint16_t TASK_FAST = 0x8000u;
@@ -456,7 +456,7 @@ struct LaneInfo {
     uint16_t n_kept;
     uint16_t last_row;        // bit 15 (TASK_FAST): the pair's first task is replayed by the workgroup
     uint8_t  c0, c1;          // its tile pair (NO_CHUNK: side not replayed)
-    uint16_t key_group;       // sort key min(first kept a, 255) | fusion group of the pair << 8
+    uint16_t key_group;       // sort key min(a, lq - a, 255) of the first kept a | fusion group of the pair << 8
     uint16_t lq;
     uint8_t  nv0, nv1;        // valid columns of the two tiles
 };
@@ -691,6 +691,9 @@ __device__ __forceinline__ void combine_wg(
     bool fast = key >= 0 && fl->tile[gsel] == key;
     const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
 
+    // Sort key of the replays: a pair meets its kept rows at row a in M1 and at row lq - a in M2, so lanes
+    // sorted by min(a, lq - a) share both hit rows with their neighbours (a and lq - a just swap sides).
+    const int fold_a = first_a < lq - first_a ? first_a : lq - first_a;
     const unsigned want[4] = {(unsigned)n_kept, n_tasks, n_tasks * (unsigned)n_kept, n_gen};
     unsigned long long base[4];
     wave_alloc4(fb.ctr, want, base);
@@ -710,7 +713,7 @@ __device__ __forceinline__ void combine_wg(
         li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST) : (uint16_t)0;
         li.c0 = here ? (uint8_t)c0 : NO_CHUNK;
         li.c1 = here ? (uint8_t)c1 : NO_CHUNK;
-        li.key_group = (uint16_t)((first_a < 255 ? first_a : 255) | ((gsel >= 0 ? gsel : 0) << 8));
+        li.key_group = (uint16_t)((fold_a < 255 ? fold_a : 255) | ((gsel >= 0 ? gsel : 0) << 8));
         li.lq = (uint16_t)lq;
         const int v0 = len0 - c0 * W, v1 = len1 - c1 * W;
         li.nv0 = (uint8_t)(here && c0 != NO_CHUNK ? (v0 < W ? (v0 > 0 ? v0 : 0) : W) : 0);
@@ -758,7 +761,7 @@ __device__ __forceinline__ void combine_wg(
         rt.last_row = (uint16_t)(r0 > r1 ? r0 : r1);
         rt.chunk0 = c0 >= 0 ? (uint8_t)c0 : NO_CHUNK;
         rt.chunk1 = c1 >= 0 ? (uint8_t)c1 : NO_CHUNK;
-        rt.first_a = (uint16_t)first_a;
+        rt.first_a = (uint16_t)fold_a;
         rt.pad_ = 0;
         if (t == 0 && fast)
             rt.last_row |= TASK_FAST;
