@@ -85,6 +85,10 @@ __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b)));
 }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)   // per-field unsigned maximum
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b)));
+}
 __device__ __forceinline__ uint32_t max3(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_bit_cast(uint32_t,
@@ -1336,7 +1340,7 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
             b_n = gn < stop_prev ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
             const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
             uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
-            bool alive = false;
+            uint32_t alive_bits = 0;
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
                 const int j = 4 * gq + sidx;
@@ -1408,13 +1412,16 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                     }
                     cmv[sidx] = tile_row_max<false>(X, W, W);
                     bov[sidx] = X[W - 1] - drift2(W - 1);
-                    const int thr = 4 * j - slack + (int)BIAS16;
-                    const bool in_read = j <= lq_lane;
-                    alive |= in_read && ((int)(cmv[sidx] & 0xFFFFu) >= thr || (int)(cmv[sidx] >> 16) >= thr);
-                    if (in_read && ((int)(bov[sidx] & 0xFFFFu) >= thr || (int)(bov[sidx] >> 16) >= thr)) last_bnd = j;
+                    // alive: a field >= thr = 4j - slack (biased).  Both fields at once: x >= thr <=> max(x, thr-1) != thr-1;
+                    // rows past the lane's read compare against 0xFFFF, which nothing exceeds.
+                    const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
+                    const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
+                    alive_bits |= pk_max_u16(cmv[sidx], tm2) ^ tm2;
+                    if ((pk_max_u16(bov[sidx], tm2) ^ tm2) != 0u) last_bnd = j;
                 }
                 bprev = bcur;
             }
+            const bool alive = alive_bits != 0u;
 #ifdef DSA_ABLATE_STORES
             if (gq == ngq - 1) {
 #endif
