@@ -159,7 +159,8 @@ def main():
                          "kernel": "k_fill_fast", "kernel_ms": launch_ms,
                          "algorithmic_bytes_per_align": round(bytes_per_align, 2),
                          "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
-                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)); "
+                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)): "
+                                 "profiles/r01/pmc_sq.json has the kernel at 0.81 of the VALU issue slots of a nominal 2.4 GHz clock; "
                                  "traffic >> algorithmic bytes because tile checkpoints and tile maxima "
                                  "(needed for exact tie enumeration) stream through HBM, see DESIGN.md 5"},
             "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)) * max(1, t.fill_launches),
