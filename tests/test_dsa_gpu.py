@@ -69,6 +69,20 @@ def test_parity_single_fusion_fast_path(gpu_ctx, ora):
     assert len(got) > 300
 
 
+@pytest.mark.parametrize("lq,lr,n_reads", [(7600, 9000, 1), (300, 16320, 2), (1000, 3000, 4), (5, 40, 8), (8, 64, 8), (9, 65, 8)])
+def test_parity_limits(gpu_ctx, ora, lq, lr, n_reads):
+    """The documented limits (reads of 7600 bases, windows of 255 tiles) and the smallest inputs that can still
+    produce an alignment (the anchor is 8: a read of 9 can split 8 + 1... none of these may differ from the oracle)."""
+    import numpy as np
+    rng = np.random.default_rng(lq + lr)
+    bb = cases.BatchBuilder()
+    ref0, ref1 = cases.rnd(rng, lr), cases.rnd(rng, lr)
+    f = bb.add_fusion(ref0, ref1)
+    for _ in range(n_reads):
+        bb.add_read(f, cases.mutate(rng, cases.split_read(rng, ref0, ref1, lq), 0.01))
+    check_batch(gpu_ctx, ora, bb.arrays())
+
+
 def test_parity_pruning_diagonal_entry(gpu_ctx, ora):
     """A borderline alignment (one mismatch + one inserted read base: exactly minScore) that leaves tile 0 through
     its last column at row 27 and enters tile 1 diagonally at row 28, alone in its wave: everything of tile 1 up
