@@ -63,12 +63,23 @@ constexpr int TROW = W + 4;           // table row stride in dwords: table row t
 #endif
 constexpr int GMAX = 4;               // max distinct fusions per workgroup with one 25-row table per fusion
 constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
-// Workgroups of 5..GSPLIT fusions keep two 5-row tables per fusion in the same LDS instead (M1 terms by
-// M1 class, M2 terms by M2 class): a cell then adds two table terms (v_add3_u32 instead of v_add_u32)
-// from two ds_read_b128 per four columns.
-constexpr int GSPLIT = 10;
-constexpr int TGROUP_SPLIT = 2 * NCLS * TROW;
+// Workgroups of 5..GSPLIT fusions keep two 5-row tables of 16-bit terms per fusion in the same LDS instead
+// (M1 terms by M1 class, M2 terms by M2 class): four columns come from two ds_read_b64 and one v_perm_b32
+// per column joins the two fields (one instruction more per cell pair than the 25-row tables).
+constexpr int GSPLIT = 20;
+constexpr int TROW_S = TROW / 2;                  // split table row stride in dwords (TROW 16-bit terms)
+constexpr int TGROUP_SPLIT = 2 * NCLS * TROW_S;   // dwords per fusion
 static_assert(GSPLIT * TGROUP_SPLIT <= GMAX * TGROUP, "split tables must fit the LDS of the combined ones");
+static_assert((TROW_S % 2) == 0, "split table rows are read with ds_read_b64");
+
+// terms of columns 4q..4q+3 for M1 class k1 / M2 class k2 of one fusion's split tables
+__device__ __forceinline__ uint4 split_terms(const uint32_t* tb, uint32_t k1, uint32_t k2, int q)
+{
+    const uint2 L = reinterpret_cast<const uint2*>(tb + k1 * TROW_S)[q];
+    const uint2 H = reinterpret_cast<const uint2*>(tb + (NCLS + k2) * TROW_S)[q];
+    return make_uint4(__builtin_amdgcn_perm(H.x, L.x, 0x05040100u), __builtin_amdgcn_perm(H.x, L.x, 0x07060302u),
+                      __builtin_amdgcn_perm(H.y, L.y, 0x05040100u), __builtin_amdgcn_perm(H.y, L.y, 0x07060302u));
+}
 // Stored values are V + 1024 per int16 field: always a positive normal fp16 bit pattern.
 constexpr uint32_t BIAS16 = 0x0400u;
 constexpr uint32_t BIAS2 = 0x04000400u;
@@ -299,12 +310,12 @@ __device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_gro
         }
         // +2 per field for i > 0: the diagonal move from column i-1 to i picks up the drift
         const uint32_t drift = i > 0 ? TWO2 : 0u;
-        if (SPLIT) {                   // rows 0..4: M1 term by M1 class (lo field), rows 5..9: M2 term (hi field)
-            uint32_t* col = T + gi * TGROUP_SPLIT + i;
+        if (SPLIT) {                   // rows 0..4: M1 term by M1 class, rows 5..9: M2 term by M2 class, 16 bits each
+            unsigned short* col = reinterpret_cast<unsigned short*>(T + gi * TGROUP_SPLIT) + i;
 #pragma unroll
             for (int k = 0; k < NCLS; ++k) {
-                col[k * TROW] = lo[k] + (drift & 0xFFFFu);
-                col[(NCLS + k) * TROW] = hi[k] + (drift & 0xFFFF0000u);
+                col[k * TROW] = (unsigned short)(lo[k] + (drift & 0xFFFFu));
+                col[(NCLS + k) * TROW] = (unsigned short)((hi[k] + (drift & 0xFFFF0000u)) >> 16);
             }
         } else {
             uint32_t* col = T + gi * TGROUP + i;
@@ -970,15 +981,10 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
             const int j = 4 * gq + sidx;
             const uint32_t bcur = bv[sidx];
             if (j >= 1 && j <= Rw) {                     // wave-uniform
-                const uint4* trow = reinterpret_cast<const uint4*>(tb + (SPLIT ? (rcv[sidx] >> 16) & 0xFu : rcv[sidx] & 0xFFu) * TROW);
-                const uint4* trow_hi = reinterpret_cast<const uint4*>(tb + (NCLS + ((rcv[sidx] >> 20) & 0xFu)) * TROW);   // SPLIT only
+                const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);       // combined tables
                 auto table4 = [&](int q) -> uint4 {
-                    uint4 t = trow[q];
-                    if (SPLIT) {
-                        const uint4 h = trow_hi[q];
-                        t.x += h.x; t.y += h.y; t.z += h.z; t.w += h.w;
-                    }
-                    return t;
+                    if (SPLIT) return split_terms(tb, (rcv[sidx] >> 16) & 0xFu, (rcv[sidx] >> 20) & 0xFu, q);
+                    return trow[q];
                 };
                 uint4 v = table4(0);
                 uint32_t a = bprev + v.x;
@@ -1349,31 +1355,29 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                     // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
                     // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
                     if constexpr (SPLIT) {
-                        const uint4* tlo = reinterpret_cast<const uint4*>(tb + ((rcv[sidx] >> 16) & 0xFu) * TROW);
-                        const uint4* thi = reinterpret_cast<const uint4*>(tb + (NCLS + ((rcv[sidx] >> 20) & 0xFu)) * TROW);
-                        uint4 lo = tlo[0], hi = thi[0];
-                        uint32_t a = bprev + lo.x + hi.x;
+                        const uint32_t k1 = (rcv[sidx] >> 16) & 0xFu, k2 = (rcv[sidx] >> 20) & 0xFu;
+                        uint4 v = split_terms(tb, k1, k2, 0);
+                        uint32_t a = bprev + v.x;
                         uint32_t up = bcur - TWO2;
 #pragma unroll
                         for (int q = 0; q < W / 4; ++q) {
-                            uint4 lo1 = lo, hi1 = hi;             // one table read of either kind in flight
-                            if (q + 1 < W / 4) { lo1 = tlo[q + 1]; hi1 = thi[q + 1]; }
+                            uint4 vn = v;                         // one pair of table reads in flight
+                            if (q + 1 < W / 4) vn = split_terms(tb, k1, k2, q + 1);
                             uint32_t an;
-                            an = X[4 * q + 0] + lo.y + hi.y;
+                            an = X[4 * q + 0] + v.y;
                             X[4 * q + 0] = max3(a, X[4 * q + 0], up);
                             a = an;
-                            an = X[4 * q + 1] + lo.z + hi.z;
+                            an = X[4 * q + 1] + v.z;
                             X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
                             a = an;
-                            an = X[4 * q + 2] + lo.w + hi.w;
+                            an = X[4 * q + 2] + v.w;
                             X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
                             a = an;
-                            an = X[4 * q + 3] + lo1.x + hi1.x;
+                            an = X[4 * q + 3] + vn.x;
                             X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
                             a = an;
                             up = X[4 * q + 3];
-                            lo = lo1;
-                            hi = hi1;
+                            v = vn;
                         }
                     } else {
                     const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
