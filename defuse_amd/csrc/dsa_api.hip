@@ -89,7 +89,7 @@ struct Slice {
     int64_t pair_begin = 0, pair_end = 0;
     std::vector<WaveInfo> waves;     // one per 64 pairs
     std::vector<WgInfo> wgs;         // one per 256 pairs
-    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GSPLIT fusions)
+    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GSPLIT2 fusions)
     Geom g{};
 };
 
@@ -192,7 +192,9 @@ int reorder_for_pruning(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair*
     }
     std::vector<int64_t> count((size_t)nf, 0);
     for (int64_t p = 0; p < n_pairs; ++p) ++count[pairs[p].fusion_idx];
-    auto size_class = [&](int f) { return count[f] >= WAVE ? 0 : count[f] >= WG_LANES / GSPLIT ? 1 : 2; };
+    auto size_class = [&](int f) {
+        return count[f] >= WAVE ? 0 : count[f] >= WG_LANES / GSPLIT ? 1 : count[f] >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
+    };
     std::vector<int32_t> forder((size_t)nf);
     for (int f = 0; f < nf; ++f) forder[f] = f;
     std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
@@ -272,7 +274,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
                     bool found = false;
                     for (int k = 0; k < wg.n_groups; ++k) found |= wg.group_f[k] == f;
                     if (!found) {
-                        if (wg.n_groups < GSPLIT)
+                        if (wg.n_groups < GSPLIT2)
                             wg.group_f[wg.n_groups++] = f;
                         else
                             too_many = true;
@@ -364,10 +366,13 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
     HIPC(hipEventRecord(L.ev[1], st));
     // every workgroup is run by exactly one of the two fill kernels
-    hipLaunchKernelGGL(k_fill_fast<false>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+    hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
                        L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
-    hipLaunchKernelGGL(k_fill_fast<true>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+    hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_tmask.p, fb, g);
+    hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
                        L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,

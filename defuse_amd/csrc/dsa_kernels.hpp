@@ -66,7 +66,8 @@ constexpr int TGROUP = NCOMBO * TROW; // dwords per fusion table
 // Workgroups of 5..GSPLIT fusions keep two 5-row tables of 16-bit terms per fusion in the same LDS instead
 // (M1 terms by M1 class, M2 terms by M2 class): four columns come from two ds_read_b64 and one v_perm_b32
 // per column joins the two fields (one instruction more per cell pair than the 25-row tables).
-constexpr int GSPLIT = 20;
+constexpr int GSPLIT = 20;                       // at four workgroups per CU
+constexpr int GSPLIT2 = 40;                      // at two workgroups per CU (twice the LDS): still ahead of the generic kernel
 constexpr int TROW_S = TROW / 2;                  // split table row stride in dwords (TROW 16-bit terms)
 constexpr int TGROUP_SPLIT = 2 * NCLS * TROW_S;   // dwords per fusion
 static_assert(GSPLIT * TGROUP_SPLIT <= GMAX * TGROUP, "split tables must fit the LDS of the combined ones");
@@ -121,7 +122,7 @@ struct WaveInfo {
 // Per workgroup (WG_WAVES waves = WG_LANES pairs): the distinct fusions of its pairs, for the fast path.
 struct WgInfo {
     int32_t n_groups;              // 0 => generic kernel (more than GSPLIT fusions); > GMAX => split tables
-    int32_t group_f[GSPLIT];       // fusion_idx
+    int32_t group_f[GSPLIT2];      // fusion_idx
 };
 
 // Geometry shared by all kernels of one run (one slice).  Pair p <-> wave p>>6, lane p&63.
@@ -477,7 +478,7 @@ struct LaneInfo {
 };
 constexpr int KCACHE = 3;     // kept rows per pair that travel through LDS as well
 struct FinishLds {
-    int tile[GSPLIT];
+    int tile[GSPLIT2];
     int hist[258];
     unsigned short order[WG_LANES];
     LaneInfo info[WG_LANES];
@@ -527,7 +528,7 @@ __device__ __forceinline__ void combine_wg(
     const bool active = p < g.n_pairs;
     const int64_t w = p >> 6;
     const int lane = (int)(p & 63);
-    if (tid < GSPLIT) fl->tile[tid] = -1;
+    if (tid < GSPLIT2) fl->tile[tid] = -1;
     const uint32_t* rm = rmax + w * g.lq1 * WAVE;
     const uint4* rm4 = reinterpret_cast<const uint4*>(rm) + lane;
     const uint4* tm4 = reinterpret_cast<const uint4*>(tmask + w * g.lq1 * WAVE) + lane;
@@ -661,9 +662,8 @@ __device__ __forceinline__ void combine_wg(
     const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
     // offer the first tile pair to the table-driven replay
     int gsel = -1;
-#pragma unroll
-    for (int k = 0; k < GSPLIT; ++k)
-        if (k < wgi.n_groups && wgi.group_f[k] == fidx) gsel = k;
+    for (int k = 0; k < wgi.n_groups; ++k)
+        if (wgi.group_f[k] == fidx) gsel = k;
     int key = -1;
     if (n_tasks > 0 && small && fast_wg && gsel >= 0) {
         const int c0 = nth_set_bit(tiles0, 0), c1 = nth_set_bit(tiles1, 0);
@@ -891,9 +891,8 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
 {
     const KeptRow* __restrict__ kept = fb.kept;
     uint64_t* __restrict__ masks = fb.masks;
-    constexpr int NG = SPLIT ? GSPLIT : GMAX;
     bool any = false;
-    for (int k = 0; k < NG; ++k) any |= fl->tile[k] >= 0;
+    for (int k = 0; k < wgi.n_groups; ++k) any |= fl->tile[k] >= 0;
     if (!any) return;                                   // uniform
     // tables for the agreed tile pair of every fusion of the workgroup
     build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
@@ -1232,8 +1231,11 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 // A row costs one ds_read_b128 per 4 columns and 2 adds + 1.5 max3 per column; four rows share one
 // dwordx4 load of row codes / boundary and one dwordx4 store of tile maxima / boundary.
 // ---------------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
+// TIER 0: one 25-row table per fusion, at most GMAX fusions; 1: split tables, at most GSPLIT; 2: split tables in
+// twice the LDS (two workgroups per CU), at most GSPLIT2.
+__host__ __device__ constexpr int tier_of(int n_groups) { return n_groups <= GMAX ? 0 : n_groups <= GSPLIT ? 1 : 2; }
+template <int TIER>
+__global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            const WaveInfo* __restrict__ winfo,
                                                            const WgInfo* __restrict__ wginfo,
                                                            uint32_t* __restrict__ wg_generic,
@@ -1246,12 +1248,13 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
                                                            uint32_t* __restrict__ rmax, uint32_t* __restrict__ tmask,
                                                            FinishBufs fb, Geom g)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t T[GMAX * TGROUP];
+    constexpr bool SPLIT = TIER > 0;
+    __shared__ __attribute__((aligned(16))) uint32_t T[TIER == 2 ? GSPLIT2 * TGROUP_SPLIT : GMAX * TGROUP];
     __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
     const WgInfo wgi = wginfo[blockIdx.x];
-    if ((wgi.n_groups > GMAX) != SPLIT) return;  // the other instantiation owns it (uniform)
+    if (tier_of(wgi.n_groups) != TIER) return;   // another instantiation owns it (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
     const int lane = threadIdx.x & 63;
@@ -1294,9 +1297,8 @@ __global__ __launch_bounds__(WG_LANES, 4) void k_fill_fast(const dsa_pair* __res
     const int nch_wg = s_nch;
 
     int gsel = 0;
-#pragma unroll
-    for (int k = 0; k < (SPLIT ? GSPLIT : GMAX); ++k)
-        if (k < wgi.n_groups && wgi.group_f[k] == f) gsel = k;
+    for (int k = 0; k < wgi.n_groups; ++k)
+        if (wgi.group_f[k] == f) gsel = k;
     const uint32_t* tb = T + gsel * (SPLIT ? TGROUP_SPLIT : TGROUP);
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
     int stop_prev = 0;                   // stored row groups of the tile to the left
