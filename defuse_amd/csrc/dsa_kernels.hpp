@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
         reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
-    const WgInfo& wgi = wginfo[blockIdx.x];   // read in place (uniform, scalar loads): 164 bytes are too many to copy
+    const WgInfo wgi = wginfo[blockIdx.x];
     combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
 }
 
@@ -1253,7 +1253,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const
     __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
-    const WgInfo& wgi = wginfo[blockIdx.x];   // read in place (uniform, scalar loads): 164 bytes are too many to copy
+    const WgInfo wgi = wginfo[blockIdx.x];
     if (tier_of(wgi.n_groups) != TIER) return;   // another instantiation owns it (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
