@@ -125,6 +125,46 @@ struct WgInfo {
     int32_t group_f[GSPLIT2];      // fusion_idx
 };
 
+// What a kernel keeps of its workgroup's descriptor: the first GMAX fusions in registers (all there are for
+// the 25-row-table tier) and a pointer to the full list for the split-table tiers.  Copying the whole
+// WgInfo into a kernel costs scratch and 1-2 % of the common case.
+struct WgView {
+    int32_t n_groups;
+    int32_t f4[GMAX];
+    const int32_t* list;
+};
+__device__ __forceinline__ WgView view_of(const WgInfo* w)
+{
+    WgView v;
+    v.n_groups = w->n_groups;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k) v.f4[k] = w->group_f[k];
+    v.list = w->group_f;
+    return v;
+}
+__device__ __forceinline__ int group_fusion(const WgView& v, int k)      // fusion_idx of group k < n_groups
+{
+    if (v.n_groups > GMAX) return v.list[k];                          // uniform
+    int f = v.f4[0];
+#pragma unroll
+    for (int j = 1; j < GMAX; ++j)
+        if (k == j) f = v.f4[j];
+    return f;
+}
+__device__ __forceinline__ int group_of(const WgView& v, int fusion_idx)  // group of a fusion of the workgroup, -1 if none
+{
+    int gsel = -1;
+    if (v.n_groups > GMAX) {
+        for (int k = 0; k < v.n_groups; ++k)
+            if (v.list[k] == fusion_idx) gsel = k;
+    } else {
+#pragma unroll
+        for (int k = 0; k < GMAX; ++k)
+            if (k < v.n_groups && v.f4[k] == fusion_idx) gsel = k;
+    }
+    return gsel;
+}
+
 // Geometry shared by all kernels of one run (one slice).  Pair p <-> wave p>>6, lane p&63.
 struct Geom {
     int32_t n_waves;
@@ -516,7 +556,7 @@ template <bool HANDOFF>
 __device__ __forceinline__ void combine_wg(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
     const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
-    const WgInfo& wgi, bool fast_wg, FinishLds* fl, const FinishBufs& fb, const Geom& g)
+    const WgView& wgi, bool fast_wg, FinishLds* fl, const FinishBufs& fb, const Geom& g)
 {
     PairState* __restrict__ state = fb.state;
     KeptRow* __restrict__ kept = fb.kept;
@@ -661,9 +701,7 @@ __device__ __forceinline__ void combine_wg(
     }
     const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
     // offer the first tile pair to the table-driven replay
-    int gsel = -1;
-    for (int k = 0; k < wgi.n_groups; ++k)
-        if (wgi.group_f[k] == fidx) gsel = k;
+    const int gsel = group_of(wgi, fidx);
     int key = -1;
     if (n_tasks > 0 && small && fast_wg && gsel >= 0) {
         const int c0 = nth_set_bit(tiles0, 0), c1 = nth_set_bit(tiles1, 0);
@@ -885,7 +923,7 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
 // threads of the workgroup after combine_wg<true>, whose LDS hand-off (fl) says what to replay; T is
 // free by then (barriers inside combine_wg).
 template <bool SPLIT>
-__device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const WgInfo& wgi, const FinishBufs& fb,
+__device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const WgView& wgi, const FinishBufs& fb,
                                                const uint32_t* __restrict__ refcodes, const uint32_t* __restrict__ rowcodes,
                                                const uint32_t* __restrict__ bnd, const Geom& g)
 {
@@ -900,7 +938,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
         q0 = q1 = REF_PAD16;                 // no tile agreed: nobody reads this group's table
         if (key >= 0) {
             const int c0 = key >> 8, c1 = key & 0xFF;
-            const uint32_t* rc = refcodes + (int64_t)wgi.group_f[gi] * g.lrp;
+            const uint32_t* rc = refcodes + (int64_t)group_fusion(wgi, gi) * g.lrp;
             if (c0 != NO_CHUNK) q0 = rc[c0 * W + i] & 0xFFFFu;
             if (c1 != NO_CHUNK) q1 = rc[c1 * W + i] >> 16;
         }
@@ -1217,7 +1255,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
         reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
-    const WgInfo wgi = wginfo[blockIdx.x];
+    const WgView wgi = view_of(wginfo + blockIdx.x);
     combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
 }
 
@@ -1253,7 +1291,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const
     __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
     if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
-    const WgInfo wgi = wginfo[blockIdx.x];
+    const WgView wgi = view_of(wginfo + blockIdx.x);
     if (tier_of(wgi.n_groups) != TIER) return;   // another instantiation owns it (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
@@ -1296,9 +1334,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const
     }
     const int nch_wg = s_nch;
 
-    int gsel = 0;
-    for (int k = 0; k < wgi.n_groups; ++k)
-        if (wgi.group_f[k] == f) gsel = k;
+    const int gsel = max(group_of(wgi, f), 0);
     const uint32_t* tb = T + gsel * (SPLIT ? TGROUP_SPLIT : TGROUP);
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
     int stop_prev = 0;                   // stored row groups of the tile to the left
@@ -1316,7 +1352,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const
         __syncthreads();                          // previous tile's tables no longer in use
         STAT_T(ts1);
         build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
-            const uint32_t code = refcodes[(int64_t)wgi.group_f[gi] * g.lrp + c * W + i];
+            const uint32_t code = refcodes[(int64_t)group_fusion(wgi, gi) * g.lrp + c * W + i];
             q0 = code & 0xFFFFu;
             q1 = code >> 16;
         });
