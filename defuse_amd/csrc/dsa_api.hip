@@ -108,6 +108,7 @@ struct dsa_ctx {
     DevBuf<uint8_t> d_ref, d_reads;
     DevBuf<dsa_fusion> d_fusions;
     DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig), when pairs were reordered
+    DevBuf<dsa_pair> d_pairs_sweep;  // second pair buffer: the permutation is written here, then the two are swapped
     DevBuf<dsa_pair> d_pairs;
     DevBuf<int32_t> d_min_score;
     std::vector<Slice> slices;
@@ -164,72 +165,119 @@ size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 // Per wave the loop bounds, per workgroup (256 pairs) the distinct fusions for the fast path.
 int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs);
 
-// Sweep order (speed only; records always come out in the caller's pair order).  Workgroups are 256
-// consecutive pairs, waves 64: fusions with many reads go first (table-driven tiers), and inside a size
-// class fusions whose alignments end in the same tiles (device probe) sit next to each other, so the lanes
-// of a wave that straddles two fusions are alive in the same tiles.  Only for batches of one slice: the
-// record offsets of a reordered batch come from one scan over all pairs.  DEFUSE_DSA_NO_REORDER=1 keeps
-// the caller's order.
-int reorder_for_pruning(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
+// Sweep plan (speed only; records always come out in the caller's pair order).  Workgroups are 256
+// consecutive pairs, waves 64: fusions with many reads go first (table tiers), and inside a size class
+// fusions whose alignments end in the same tiles (device probe) sit next to each other, so the lanes of a
+// wave that straddles two fusions are alive in the same tiles.  Everything that touches pairs runs on the
+// device (statistics per fusion, probe, permutation); the host sorts the fusions and derives the wave and
+// workgroup descriptors from the runs.  Needs the pairs of every fusion to be one run and the batch to fit
+// one slice (the record offsets of a reordered batch come from one scan over all pairs); otherwise, and
+// with DEFUSE_DSA_NO_REORDER=1, the caller's order is swept.  Returns 1 if the plan was made, 0 if not.
+int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqmax)
 {
     const int nf = ctx->n_fusions;
     const char* off = getenv("DEFUSE_DSA_NO_REORDER");
-    if (nf < 2 || n_pairs < 2 * WG_LANES || ctx->slices.size() != 1 || (off && atoi(off) != 0)) return DSA_OK;
+    if (nf < 2 || n_pairs < 2 * WG_LANES || (off && atoi(off) != 0) || getenv("DEFUSE_DSA_SLICE_PAIRS")) return 0;
     hipStream_t st = ctx->stream;
+    std::vector<FusionStat> stat((size_t)nf);
     std::vector<uint8_t> tiles((size_t)2 * nf);
+    DevBuf<FusionStat> d_stat;
     {
         DevBuf<int32_t> d_votes;
         DevBuf<uint8_t> d_tiles;
+        HIPC(d_stat.reserve((size_t)nf));
         HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
         HIPC(d_tiles.reserve((size_t)nf * 2));
         HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_probe_votes, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
-                           ctx->d_reads.p, ctx->d_pairs.p, n_pairs, d_votes.p);
+        hipLaunchKernelGGL(k_fusion_stats_init, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d_stat.p, nf);
+        hipLaunchKernelGGL(k_fusion_stats, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs, d_stat.p);
+        hipLaunchKernelGGL(k_probe_wave, dim3((unsigned)nf * PROBE_READS), dim3(WAVE), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
+                           ctx->d_pairs.p, d_stat.p, d_votes.p);
         hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
+        HIPC(hipMemcpyAsync(stat.data(), d_stat.p, (size_t)nf * sizeof(FusionStat), hipMemcpyDeviceToHost, st));
         HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
         HIPC(hipStreamSynchronize(st));
         HIPC(hipGetLastError());
     }
-    std::vector<int64_t> count((size_t)nf, 0);
-    for (int64_t p = 0; p < n_pairs; ++p) ++count[pairs[p].fusion_idx];
+    for (int f = 0; f < nf; ++f)
+        if (stat[f].count > 0 && stat[f].last - stat[f].first + 1 != stat[f].count) return 0;     // not one run per fusion
+
+    auto window_tiles = [&](int f) { return std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)); };
     auto size_class = [&](int f) {
-        return count[f] >= WAVE ? 0 : count[f] >= WG_LANES / GSPLIT ? 1 : count[f] >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
+        const int c = stat[f].count;
+        return c >= WAVE ? 0 : c >= WG_LANES / GSPLIT ? 1 : c >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
     };
     std::vector<int32_t> forder((size_t)nf);
     for (int f = 0; f < nf; ++f) forder[f] = f;
     std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
         const int ca = size_class(a), cb = size_class(b);
         if (ca != cb) return ca < cb;
-        const int ka = tiles[2 * a] * 256 + tiles[2 * a + 1], kb = tiles[2 * b] * 256 + tiles[2 * b + 1];
-        return ka < kb;
+        return tiles[2 * a] * 256 + tiles[2 * a + 1] < tiles[2 * b] * 256 + tiles[2 * b + 1];
     });
-    std::vector<int64_t> start((size_t)nf + 1, 0);           // first sweep position of every fusion
-    for (int r = 0; r < nf; ++r) start[forder[r]] = count[forder[r]];
-    {
-        int64_t run = 0;
-        for (int r = 0; r < nf; ++r) { const int f = forder[r]; const int64_t c = start[f]; start[f] = run; run += c; }
+
+    // geometry and descriptors from the runs
+    Slice cur;
+    cur.pair_begin = 0;
+    cur.pair_end = n_pairs;
+    int nch = 1;
+    for (int f = 0; f < nf; ++f)
+        if (stat[f].count > 0) nch = std::max(nch, window_tiles(f));
+    const int lq1 = (lqmax + 1 + 3) & ~3;
+    const int64_t n_waves = (n_pairs + WAVE - 1) / WAVE, n_wgs = (n_pairs + WG_LANES - 1) / WG_LANES;
+    if (slice_scratch_bytes(n_waves, lq1, nch) > ctx->scratch_budget) return 0;              // would need several slices
+    cur.waves.assign((size_t)n_waves, WaveInfo{0, 0});
+    cur.wgs.assign((size_t)n_wgs, WgInfo{});
+    cur.wg_flags.assign((size_t)n_wgs, 0u);
+    std::vector<int32_t> new_start((size_t)nf, 0);
+    ctx->total_cells = 0;
+    int64_t pos = 0;
+    for (int r = 0; r < nf; ++r) {
+        const int f = forder[r];
+        const int64_t c = stat[f].count;
+        new_start[f] = (int32_t)pos;
+        if (c == 0) continue;
+        const int tl = window_tiles(f);
+        for (int64_t w = pos / WAVE; w <= (pos + c - 1) / WAVE; ++w) {
+            cur.waves[w].lq_max = std::max(cur.waves[w].lq_max, stat[f].max_lq);    // upper bound of the wave's reads
+            cur.waves[w].nch_max = std::max(cur.waves[w].nch_max, tl);
+        }
+        for (int64_t g = pos / WG_LANES; g <= (pos + c - 1) / WG_LANES; ++g) {
+            WgInfo& wg = cur.wgs[g];
+            if (cur.wg_flags[g]) continue;
+            if (wg.n_groups < GSPLIT2)
+                wg.group_f[wg.n_groups++] = f;
+            else {
+                wg.n_groups = 0;
+                cur.wg_flags[g] = 1u;
+            }
+        }
+        ctx->total_cells += (int64_t)(fusions[f].ref0_len + 1 + fusions[f].ref1_len + 1) * (stat[f].sum_lq + c);
+        pos += c;
     }
-    std::vector<int32_t> orig((size_t)n_pairs);
-    std::vector<dsa_pair> sweep((size_t)n_pairs);
-    bool identity = true;
-    for (int64_t p = 0; p < n_pairs; ++p) {                  // stable inside a fusion
-        const int64_t q = start[pairs[p].fusion_idx]++;
-        orig[q] = (int32_t)p;
-        sweep[q] = pairs[p];
-        identity = identity && q == p;
-    }
-    if (identity) return DSA_OK;
+    cur.g.n_waves = (int32_t)n_waves;
+    cur.g.n_wgs = (int32_t)n_wgs;
+    cur.g.lq1 = lq1;
+    cur.g.nch = nch;
+    cur.g.lrp = nch * W;
+    cur.g.n_fusions = nf;
+    cur.g.n_pairs = n_pairs;
+
+    // pairs into sweep order on the device
+    DevBuf<int32_t> d_start;
+    HIPC(d_start.reserve((size_t)nf));
     HIPC(ctx->d_orig.reserve((size_t)n_pairs));
-    HIPC(hipMemcpyAsync(ctx->d_orig.p, orig.data(), (size_t)n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(ctx->d_pairs.p, sweep.data(), (size_t)n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+    HIPC(ctx->d_pairs_sweep.reserve((size_t)n_pairs + 1));
+    HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs, d_stat.p, d_start.p,
+                       ctx->d_pairs_sweep.p, ctx->d_orig.p);
     HIPC(hipStreamSynchronize(st));
-    if (int rc = build_slices(ctx, fusions, sweep.data(), n_pairs)) return rc;
-    if (ctx->slices.size() != 1) {                           // cannot happen (same pairs), but never sweep a split batch reordered
-        HIPC(hipMemcpy(ctx->d_pairs.p, pairs, (size_t)n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice));
-        return build_slices(ctx, fusions, pairs, n_pairs);
-    }
-    ctx->slices[0].g.orig = ctx->d_orig.p;
-    return DSA_OK;
+    HIPC(hipGetLastError());
+    std::swap(ctx->d_pairs.p, ctx->d_pairs_sweep.p);
+    std::swap(ctx->d_pairs.cap, ctx->d_pairs_sweep.cap);
+    cur.g.orig = ctx->d_orig.p;
+    ctx->slices.clear();
+    ctx->slices.push_back(std::move(cur));
+    return 1;
 }
 
 int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
@@ -538,7 +586,7 @@ void dsa_destroy(dsa_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release();
+    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_sweep.release();
     (void)hipDeviceSynchronize();
     ctx->d_min_score.release(); ctx->d_records.release();
     for (PipeLane& L : ctx->lane) {
@@ -628,8 +676,10 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     HIPC(ctx->d_min_score.reserve(tab.size()));
     HIPC(hipMemcpyAsync(ctx->d_min_score.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPC(hipStreamSynchronize(st));
-    if (int rc = build_slices(ctx, fusions, pairs, n_pairs)) return rc;
-    return reorder_for_pruning(ctx, fusions, pairs, n_pairs);
+    const int planned = plan_sweep(ctx, fusions, n_pairs, lqmax);
+    if (planned < 0) return planned;
+    if (planned == 1) return DSA_OK;
+    return build_slices(ctx, fusions, pairs, n_pairs);
 }
 
 int dsa_run(dsa_ctx* ctx, int64_t* out_n)

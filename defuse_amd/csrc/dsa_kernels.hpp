@@ -243,56 +243,116 @@ __global__ void k_pack_refs(const uint8_t* __restrict__ ref_bytes, const dsa_fus
 }
 
 // ---------------------------------------------------------------------------------------------
-// Probe for the sweep order (speed heuristic only: any order gives the same records).  Up to
-// PROBE_READS reads per fusion vote for the tile in which their M1 / M2 alignment ends: the first 16
-// bases of the read are looked up in window 0 and extended along the diagonal, the last 16 bases in
-// window 1 and extended backwards (X-drop).  k_probe_pick takes the majority per window.  Fusions
-// with the same tiles are then swept next to each other, so that a wave that straddles two fusions is
-// alive in the same tiles for both and the exact pruning stops the other tiles early.
+// Sweep planning on the device (speed heuristic only: any order gives the same records).
+//   k_fusion_stats: per fusion the number of pairs, the first and last pair index (callers group pairs by
+//                   fusion; a fusion whose pairs are not one run switches planning off), read length max / sum.
+//   k_probe_wave:   one wave per (fusion, voter): the first PROBE_READS reads of a fusion vote for the tile in
+//                   which their M1 / M2 alignment ends.  The first 16 bases of the read are looked up in window 0
+//                   (64 positions per step, one per lane) and extended along the diagonal, the last 16 bases in
+//                   window 1 and extended backwards (X-drop).  k_probe_pick takes the majority per window.
+//   k_permute_pairs: pairs into sweep order.
+// Fusions whose alignments end in the same tiles are swept next to each other, so that a wave that straddles
+// two fusions is alive in the same tiles for both and the exact pruning stops the others early.
 // ---------------------------------------------------------------------------------------------
-constexpr int PROBE_READS = 8, PROBE_SEED = 16, PROBE_TILES = 16;
-__global__ void k_probe_votes(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
-                              const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs, int64_t n_pairs,
-                              int32_t* __restrict__ votes)
+constexpr int PROBE_READS = 4, PROBE_SEED = 16, PROBE_TILES = 16;
+struct FusionStat {
+    int32_t count, first, last, max_lq;
+    long long sum_lq;
+};
+__global__ void k_fusion_stats_init(FusionStat* __restrict__ st, int n_fusions)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_fusions) return;
+    FusionStat s;
+    s.count = 0;
+    s.first = 0x7FFFFFFF;
+    s.last = -1;
+    s.max_lq = 0;
+    s.sum_lq = 0;
+    st[f] = s;
+}
+__global__ void k_fusion_stats(const dsa_pair* __restrict__ pairs, int64_t n_pairs, FusionStat* __restrict__ st)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const dsa_pair pr = pairs[p];
+    FusionStat* s = st + pr.fusion_idx;
+    // runs of one fusion: only the ends of a run touch first / last, one lane per run adds the count
+    const bool run_begin = p == 0 || pairs[p - 1].fusion_idx != pr.fusion_idx;
+    const bool run_end = p + 1 == n_pairs || pairs[p + 1].fusion_idx != pr.fusion_idx;
+    if (run_begin) atomicMin(&s->first, (int32_t)p);
+    if (run_end) atomicMax(&s->last, (int32_t)p);
+    atomicAdd(&s->count, 1);
+    atomicMax(&s->max_lq, pr.read_len);
+    atomicAdd((unsigned long long*)&s->sum_lq, (unsigned long long)pr.read_len);
+}
+
+__global__ __launch_bounds__(64) void k_probe_wave(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
+                                                   const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
+                                                   const FusionStat* __restrict__ st, int32_t* __restrict__ votes)
+{
+    const int f = blockIdx.x / PROBE_READS, v = blockIdx.x % PROBE_READS;
+    const int lane = threadIdx.x;
+    const FusionStat s = st[f];
+    if (v >= s.count) return;
+    const dsa_pair pr = pairs[s.first + v];
+    if (pr.fusion_idx != f) return;                                // not one run: no vote
     const int lq = pr.read_len;
     if (lq < PROBE_SEED + 8) return;
-    // voters: the first PROBE_READS pairs of every run of one fusion (callers group pairs by fusion)
-    if (p >= PROBE_READS && pairs[p - PROBE_READS].fusion_idx == pr.fusion_idx) return;
-    const dsa_fusion fu = fusions[pr.fusion_idx];
+    const dsa_fusion fu = fusions[f];
     const uint8_t* rd = read_bytes + pr.read_off;
     const uint8_t* r0 = ref_bytes + fu.ref0_off;
     const uint8_t* r1 = ref_bytes + fu.ref1_off;
-    for (int x = 0; x + PROBE_SEED <= fu.ref0_len; ++x) {          // M1: prefix seed, extend forwards
-        int k = 0;
-        while (k < PROBE_SEED && r0[x + k] == rd[k]) ++k;
-        if (k < PROBE_SEED) continue;
+    // M1: first window position at which the read's first PROBE_SEED bases match
+    int x0 = -1;
+    for (int base = 0; base + PROBE_SEED <= fu.ref0_len && x0 < 0; base += WAVE) {
+        const int x = base + lane;
+        bool ok = x + PROBE_SEED <= fu.ref0_len;
+        for (int k = 0; k < PROBE_SEED && ok; ++k) ok = r0[x + k] == rd[k];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        if (m) x0 = base + __builtin_ctzll(m);
+    }
+    // M2: first window position at which its last PROBE_SEED bases match
+    int y0 = -1;
+    for (int base = 0; base + PROBE_SEED <= fu.ref1_len && y0 < 0; base += WAVE) {
+        const int y = base + lane;
+        bool ok = y + PROBE_SEED <= fu.ref1_len;
+        for (int k = 0; k < PROBE_SEED && ok; ++k) ok = r1[y + k] == rd[lq - PROBE_SEED + k];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        if (m) y0 = base + __builtin_ctzll(m);
+    }
+    if (lane != 0) return;
+    if (x0 >= 0) {                                                 // extend forwards (X-drop)
         int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;
-        for (k = PROBE_SEED; k < lq && x + k < fu.ref0_len && score > best - 6; ++k) {
-            score += r0[x + k] == rd[k] ? 1 : -2;
+        for (int k = PROBE_SEED; k < lq && x0 + k < fu.ref0_len && score > best - 6; ++k) {
+            score += r0[x0 + k] == rd[k] ? 1 : -2;
             if (score > best) { best = score; best_k = k; }
         }
-        const int tile = (x + best_k) / W;                          // matrix column x + best_k + 1
-        atomicAdd(&votes[((int64_t)pr.fusion_idx * 2 + 0) * PROBE_TILES + min(tile, PROBE_TILES - 1)], 1);
-        break;
+        const int tile = (x0 + best_k) / W;                         // matrix column x0 + best_k + 1
+        atomicAdd(&votes[((int64_t)f * 2 + 0) * PROBE_TILES + min(tile, PROBE_TILES - 1)], 1);
     }
-    for (int y = 0; y + PROBE_SEED <= fu.ref1_len; ++y) {          // M2: suffix seed, extend backwards
-        int k = 0;
-        while (k < PROBE_SEED && r1[y + k] == rd[lq - PROBE_SEED + k]) ++k;
-        if (k < PROBE_SEED) continue;
-        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;   // k counts bases from the read's end
-        for (k = PROBE_SEED; k < lq && y + PROBE_SEED - 1 - k >= 0 && score > best - 6; ++k) {
-            score += r1[y + PROBE_SEED - 1 - k] == rd[lq - 1 - k] ? 1 : -2;
+    if (y0 >= 0) {                                                 // extend backwards; k counts bases from the read's end
+        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;
+        for (int k = PROBE_SEED; k < lq && y0 + PROBE_SEED - 1 - k >= 0 && score > best - 6; ++k) {
+            score += r1[y0 + PROBE_SEED - 1 - k] == rd[lq - 1 - k] ? 1 : -2;
             if (score > best) { best = score; best_k = k; }
         }
-        const int s1 = y + PROBE_SEED - 1 - best_k;                 // first window-1 base of the aligned suffix
+        const int s1 = y0 + PROBE_SEED - 1 - best_k;                // first window-1 base of the aligned suffix
         const int tile = (fu.ref1_len - s1 - 1) / W;                // its column in the reversed window is len1 - s1
-        atomicAdd(&votes[((int64_t)pr.fusion_idx * 2 + 1) * PROBE_TILES + min(max(tile, 0), PROBE_TILES - 1)], 1);
-        break;
+        atomicAdd(&votes[((int64_t)f * 2 + 1) * PROBE_TILES + min(max(tile, 0), PROBE_TILES - 1)], 1);
     }
+}
+
+// pair p of fusion f (one run starting at first[f]) goes to sweep position new_start[f] + (p - first[f])
+__global__ void k_permute_pairs(const dsa_pair* __restrict__ pairs, int64_t n_pairs, const FusionStat* __restrict__ st,
+                                const int32_t* __restrict__ new_start, dsa_pair* __restrict__ sweep, int32_t* __restrict__ orig)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const dsa_pair pr = pairs[p];
+    const int64_t q = (int64_t)new_start[pr.fusion_idx] + (p - st[pr.fusion_idx].first);
+    sweep[q] = pr;
+    orig[q] = (int32_t)p;
 }
 
 // tiles[2f + s] = majority tile of window s of fusion f, 255 without votes
