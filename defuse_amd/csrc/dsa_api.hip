@@ -449,7 +449,6 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     Geom g = s.g;
     hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
-    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     if (g.lq1 > ((7600 + 1 + 3) & ~3)) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");   // lq1 is padded to a multiple of 4
     const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
     HIPC(L.d_waves.reserve(s.waves.size()));
