@@ -107,6 +107,23 @@ def test_parity_pruning_diagonal_entry(gpu_ctx, ora):
     assert hits >= 3          # the constructed split is really what wins in most draws
 
 
+def test_parity_sweep_plans(gpu_ctx, ora, monkeypatch):
+    """The sweep plan is a speed heuristic: the same records come out with the device-side plan (pairs grouped by
+    fusion), with the caller's order kept (DEFUSE_DSA_NO_REORDER) and for pairs that are not grouped by fusion at
+    all (no plan possible), always in the caller's pair order."""
+    import numpy as np
+    ref, fus, reads, pairs = cases.mixed_batch(41, n_fusions=30, reads_per_fusion=35, lq=76, lr=(300, 420))
+    base = check_batch(gpu_ctx, ora, (ref, fus, reads, pairs))
+    monkeypatch.setenv("DEFUSE_DSA_NO_REORDER", "1")
+    same = check_batch(gpu_ctx, ora, (ref, fus, reads, pairs))
+    assert same.tobytes() == base.tobytes()
+    monkeypatch.delenv("DEFUSE_DSA_NO_REORDER")
+    rng = np.random.default_rng(3)
+    shuffled = pairs[rng.permutation(len(pairs))].copy()              # fusions interleaved: several runs per fusion
+    check_batch(gpu_ctx, ora, (ref, fus, reads, shuffled))
+    assert len(base) > 500
+
+
 def test_parity_split_table_tier(gpu_ctx, ora):
     """Workgroups of five to ten fusions (30 reads each, reads over {A,C,G,T,N}) take the fill kernel with two
     small LDS tables per fusion; twelve reads per fusion push workgroups past ten fusions onto the generic one."""
