@@ -11,6 +11,9 @@
 //               Y(i,j) = max3(Y(i-1,j-1) + s - gap, Y(i,j-1), Y(i-1,j) + gap)
 //           per column: xor + pk_min + pk_mad (score term), add (diagonal), sub (left), max3, and half a
 //           max3 for the row maximum.  Needs gap <= mismatch <= 0 and a bounded value range.
+//           With a minimum score per pair (the tool's -t threshold) it prunes exactly, as the split-read fill
+//           does: a cell with H + max(match,0)*(rows left) < need cannot lie on the path to a score >= need, so
+//           once a whole row group of a tile and the boundary entering it are dead the tile is left.
 //   k_la32: one pair per lane in int32, any scores, padded columns masked out of the maximum.
 //
 // Pairs are sorted by (sequence length, reference length) so that the lanes of a wave sweep about the
@@ -50,10 +53,17 @@ __device__ __forceinline__ uint32_t max3(uint32_t a, uint32_t b, uint32_t c)
                                             __builtin_bit_cast(v2h, c)));
 }
 
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)   // per-field unsigned maximum
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b)));
+}
+
 struct Lane {              // what one lane aligns: ITEMS pairs (second one unused by the int32 kernel)
     int32_t lr[2], ls[2];
     int32_t out[2];        // index into scores, -1 = padding
+    int32_t need[2];       // scores below this need not be exact (NO_NEED: always exact)
 };
+constexpr int32_t NO_NEED = -0x40000000;
 struct Wave {
     int64_t ref_off;       // dwords into refcodes: [nch*W columns][64 lanes]
     int64_t row_off;       // dwords into rowcodes: [rows4][64 lanes], rowidx layout
@@ -63,6 +73,7 @@ struct Wave {
 struct Params {
     int32_t match, mismatch, gap;      // as given (int32 kernel)
     int32_t dm, dx, gd;                // packed kernel: match - gap, mismatch - gap (after the 2*gap clamp), -gap
+    int32_t mp;                        // max(match, 0): the most a further row can add to a score
 };
 
 __host__ __device__ __forceinline__ int64_t rowidx(int j, int lane) { return ((int64_t)(j >> 2) * WAVE + lane) * 4 + (j & 3); }
@@ -102,7 +113,7 @@ __global__ void k_pack(const uint8_t* __restrict__ pool, const la_item* __restri
 // ---------------------------------------------------------------------------------------------
 // packed kernel: two pairs per lane
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_WAVES * WAVE, 3) void k_la16(const Lane* __restrict__ lanes, const Wave* __restrict__ waves, int n_waves,
+__global__ __launch_bounds__(WG_WAVES * WAVE, 2) void k_la16(const Lane* __restrict__ lanes, const Wave* __restrict__ waves, int n_waves,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ bnd,
                                                            Params prm, int32_t* __restrict__ scores)
@@ -130,6 +141,22 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 3) void k_la16(const Lane* __restr
     const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
     const int ngq = (wv.ls_max >> 2) + 1;
     int best0 = 0, best1 = 0;
+    // pruning: field f is alive at row j while Y (biased) >= need_f - mp*ls_f + (mp + gd)*j + BIAS
+    const int slope = prm.mp + prm.gd;
+    const int base0 = ln.need[0] - prm.mp * ln.ls[0] + (int)BIAS16, base1 = ln.need[1] - prm.mp * ln.ls[1] + (int)BIAS16;
+    auto wave_max = [](int v) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+        return v;
+    };
+    auto rows_alive_at_zero = [&](int base, int ls) {          // rows at which Y = 0 (column 0, fresh starts) is alive
+        if (ls <= 0) return 0;
+        if (base - (int)BIAS16 <= 0 && slope <= 0) return ls;
+        if (base - (int)BIAS16 > 0) return 0;
+        return min(ls, ((int)BIAS16 - base) / slope);
+    };
+    int l_in = wave_max(max(rows_alive_at_zero(base0, ln.ls[0]), rows_alive_at_zero(base1, ln.ls[1])));
+    int stop_prev = 0;
 
     for (int c = 0; c < wv.nch; ++c) {
         uint32_t r[W];
@@ -143,14 +170,17 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 3) void k_la16(const Lane* __restr
         uint4* out4 = reinterpret_cast<uint4*>(bnd + wv.bnd_off + (c & 1) * plane) + lane;
         uint32_t bprev = BIAS2;
         uint4 rc_n = rows4[0];
-        uint4 b_n = c == 0 ? bias4 : in4[0];
-        for (int gq = 0; gq < ngq; ++gq) {
+        uint4 b_n = c == 0 ? bias4 : in4[0];                    // every tile stores at least its first row group
+        int last_bnd = 0;
+        int gq = 0;
+        for (; gq < ngq; ++gq) {
             const uint4 rcq = rc_n, b = b_n;
             const int gn = gq + 1 < ngq ? gq + 1 : gq;
             rc_n = rows4[(int64_t)gn * WAVE];
-            b_n = c == 0 ? bias4 : in4[(int64_t)gn * WAVE];
+            b_n = (c > 0 && gn < stop_prev) ? in4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, Y = 0
             const uint32_t rcv[4] = {rcq.x, rcq.y, rcq.z, rcq.w}, bv[4] = {b.x, b.y, b.z, b.w};
             uint32_t bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+            uint32_t alive_bits = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int j = 4 * gq + s;
@@ -180,11 +210,21 @@ __global__ __launch_bounds__(WG_WAVES * WAVE, 3) void k_la16(const Lane* __restr
                     if (j <= ln.ls[0]) best0 = max(best0, h0);
                     if (j <= ln.ls[1]) best1 = max(best1, h1);
                     bov[s] = X[W - 1];
+                    // alive fields: x >= thr <=> max(x, thr - 1) != thr - 1; rows past a field's sequence compare with 0xFFFF
+                    const uint32_t t0 = j <= ln.ls[0] ? (uint32_t)min(max(base0 + slope * j - 1, 0), 0xFFFE) : 0xFFFFu;
+                    const uint32_t t1 = j <= ln.ls[1] ? (uint32_t)min(max(base1 + slope * j - 1, 0), 0xFFFE) : 0xFFFFu;
+                    const uint32_t tm2 = t0 | (t1 << 16);
+                    alive_bits |= pk_max_u16(m, tm2) ^ tm2;
+                    if ((pk_max_u16(bov[s], tm2) ^ tm2) != 0u) last_bnd = j;
                 }
                 bprev = bcur;
             }
             if (c + 1 < wv.nch) out4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+            // a live boundary value at row l_in also enters row l_in + 1 (diagonal move): sweep past it
+            if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive_bits != 0u) == 0) { ++gq; break; }   // wave-uniform
         }
+        stop_prev = gq;
+        l_in = wave_max(last_bnd);
     }
     if (ln.out[0] >= 0) scores[ln.out[0]] = best0;
     if (ln.out[1] >= 0) scores[ln.out[1]] = best1;
@@ -277,7 +317,7 @@ struct Group {
     int64_t ref_dwords = 0, row_dwords = 0, bnd_dwords = 0;
 };
 
-void add_wave(Group& g, const la_item* items, const int64_t* order, int64_t n, int items_per_lane)
+void add_wave(Group& g, const la_item* items, const int32_t* min_score, const int64_t* order, int64_t n, int items_per_lane)
 {
     Wave wv{};
     wv.ref_off = g.ref_dwords;
@@ -288,12 +328,14 @@ void add_wave(Group& g, const la_item* items, const int64_t* order, int64_t n, i
         Lane ln{};
         for (int f = 0; f < 2; ++f) {
             ln.out[f] = -1;
+            ln.need[f] = NO_NEED;
             const int64_t k = (int64_t)lane * items_per_lane + f;
             if (f < items_per_lane && k < n) {
                 const la_item& it = items[order[k]];
                 ln.out[f] = (int32_t)order[k];
                 ln.lr[f] = it.ref_len;
                 ln.ls[f] = it.seq_len;
+                if (min_score) ln.need[f] = std::max(min_score[order[k]], NO_NEED);
                 lr_max = std::max(lr_max, it.ref_len);
                 ls_max = std::max(ls_max, it.seq_len);
             }
@@ -317,6 +359,12 @@ const char* la_last_error(void) { return g_err.c_str(); }
 
 int la_align_batch(int device, int32_t match, int32_t mismatch, int32_t gap, const uint8_t* pool, int64_t pool_len,
                    const la_item* items, int64_t n_items, int32_t* scores, la_timing* timing)
+{
+    return la_align_batch_min(device, match, mismatch, gap, pool, pool_len, items, n_items, nullptr, scores, timing);
+}
+
+int la_align_batch_min(int device, int32_t match, int32_t mismatch, int32_t gap, const uint8_t* pool, int64_t pool_len,
+                       const la_item* items, int64_t n_items, const int32_t* min_score, int32_t* scores, la_timing* timing)
 {
     const auto t_begin = std::chrono::steady_clock::now();
     la_timing tm{};
@@ -344,6 +392,7 @@ int la_align_batch(int device, int32_t match, int32_t mismatch, int32_t gap, con
     prm.gd = -gap;
     prm.dm = std::max(match, 2 * gap) - gap;
     prm.dx = std::max(mismatch, 2 * gap) - gap;
+    prm.mp = std::max(match, 0);
 
     // longest sequences first; a wave takes consecutive pairs
     std::vector<int64_t> order((size_t)n_items);
@@ -385,7 +434,7 @@ int la_align_batch(int device, int32_t match, int32_t mismatch, int32_t gap, con
             Group g;
             while (k < end) {
                 const int64_t n = std::min(per_wave, end - k);
-                add_wave(g, items, order.data() + k, n, items_per_lane);
+                add_wave(g, items, min_score, order.data() + k, n, items_per_lane);
                 k += n;
                 if ((size_t)(g.ref_dwords + g.row_dwords + g.bnd_dwords) >= budget_dwords) break;
             }

@@ -14,11 +14,12 @@ class LaTiming(ctypes.Structure):
                 ("cells", ctypes.c_int64)]
 
 
-def align_batch(pairs, match, mismatch, gap, device=0):
-    """pairs: list of (reference bytes, sequence bytes).  Returns (int32 scores, timing)."""
+def align_batch(pairs, match, mismatch, gap, device=0, min_score=None):
+    """pairs: list of (reference bytes, sequence bytes).  Returns (int32 scores, timing).  With min_score (one
+    int per pair) a score below its minimum is only guaranteed to be below it (la_align_batch_min)."""
     lib = load_library()
-    lib.la_align_batch.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
-                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(LaTiming)]
+    lib.la_align_batch_min.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(LaTiming)]
     lib.la_last_error.restype = ctypes.c_char_p
     items = np.zeros(len(pairs), dtype=LA_ITEM)
     chunks, off = [], 0
@@ -29,8 +30,10 @@ def align_batch(pairs, match, mismatch, gap, device=0):
     pool = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8)
     scores = np.zeros(len(pairs), dtype=np.int32)
     t = LaTiming()
-    rc = lib.la_align_batch(device, match, mismatch, gap, pool.ctypes.data, off, items.ctypes.data if len(pairs) else None,
-                            len(pairs), scores.ctypes.data if len(pairs) else None, ctypes.byref(t))
+    need = None if min_score is None else np.ascontiguousarray(min_score, dtype=np.int32)
+    rc = lib.la_align_batch_min(device, match, mismatch, gap, pool.ctypes.data, off, items.ctypes.data if len(pairs) else None,
+                                len(pairs), need.ctypes.data if need is not None and len(pairs) else None,
+                                scores.ctypes.data if len(pairs) else None, ctypes.byref(t))
     if rc != 0:
-        raise RuntimeError("la_align_batch failed (%d): %s" % (rc, lib.la_last_error().decode()))
+        raise RuntimeError("la_align_batch_min failed (%d): %s" % (rc, lib.la_last_error().decode()))
     return scores, t

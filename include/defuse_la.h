@@ -45,6 +45,12 @@ typedef struct la_timing {
  * (tools/localalign.cpp:84: `aligner.Align(reference, sequence)`). */
 int la_align_batch(int device, int32_t match, int32_t mismatch, int32_t gap, const uint8_t* pool, int64_t pool_len,
                    const la_item* items, int64_t n_items, int32_t* scores, la_timing* timing);
+/* The same with a minimum score per pair (NULL: none): scores[k] is exact when it is >= min_score[k]; a pair
+ * that scores less only gets some value below min_score[k] (and >= 0).  This is what the tool's threshold
+ * needs (tools/localalign.cpp:89-92 drops the lines below it), and it lets the device leave every tile as
+ * soon as nothing in it can still reach the minimum. */
+int la_align_batch_min(int device, int32_t match, int32_t mismatch, int32_t gap, const uint8_t* pool, int64_t pool_len,
+                       const la_item* items, int64_t n_items, const int32_t* min_score, int32_t* scores, la_timing* timing);
 const char* la_last_error(void);
 
 #ifdef __cplusplus

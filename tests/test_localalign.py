@@ -69,7 +69,7 @@ def test_library_exports_la():
     import ctypes
     from defuse_amd.dsa import LIB_PATH
     lib = ctypes.CDLL(LIB_PATH)
-    for sym in ("la_align_batch", "la_last_error"):
+    for sym in ("la_align_batch", "la_align_batch_min", "la_last_error"):
         assert hasattr(lib, sym)
 
 
@@ -117,6 +117,25 @@ def test_gpu_long_sequences_use_int32(built):
     pairs = [(ref, ref[100:100 + n]) for n in (1800, 1900, 2300)] + random_pairs(4, 50)
     t = _check(pairs, PIPELINE)
     assert t.n_int32 == 2 and t.n_packed16 == len(pairs) - 2
+
+
+@pytest.mark.gpu
+def test_gpu_minimum_scores(built):
+    """With a minimum per pair (the tool's threshold) the device prunes: scores that reach the minimum are exact,
+    the others only have to stay below it."""
+    from defuse_amd import la
+    from oracle import localalign_oracle as o
+    pairs = random_pairs(51, 3000, lr=(50, 700), ls=(20, 260), related=0.5)
+    want = np.array([o.simple_align(*PIPELINE, r, s) for r, s in pairs], dtype=np.int64)
+    for frac in (0.8, 0.5, 1.0):
+        need = np.array([int(np.ceil(frac * 10 * len(s))) for _, s in pairs], dtype=np.int32)
+        got, _ = la.align_batch(pairs, *PIPELINE, min_score=need)
+        hit = want >= need
+        assert hit.sum() > 20 and (~hit).sum() > 100
+        assert np.array_equal(got[hit], want[hit])
+        assert np.all(got[~hit] < need[~hit]) and np.all(got >= 0)
+    got, _ = la.align_batch(pairs, *PIPELINE, min_score=np.full(len(pairs), -5, dtype=np.int32))
+    assert np.array_equal(got, want)                          # a minimum every score reaches: all exact
 
 
 @pytest.mark.gpu

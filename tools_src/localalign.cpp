@@ -6,6 +6,8 @@
 #include "../include/defuse_la.h"
 #include "defuse_host.hpp"
 
+#include <limits>
+
 using namespace defuse;
 
 namespace {
@@ -22,10 +24,22 @@ void flush(Batch& b, int matchScore, int misMatchScore, int gapScore, double thr
 {
     if (b.items.empty()) return;
     std::vector<int32_t> scores(b.items.size());
+    // the smallest score a line needs to be printed at all: below it the device may stop early
+    std::vector<int32_t> need(b.items.size());
+    for (size_t k = 0; k < b.items.size(); ++k) {
+        const int maxScore = (size_t)b.items[k].seq_len * matchScore;
+        int32_t s = std::numeric_limits<int32_t>::min();
+        if (maxScore > 0 && threshold > 0.0) {
+            s = (int32_t)std::min<double>(std::ceil(threshold * (double)maxScore), 2147483000.0);
+            while (s > 0 && !((double)(s - 1) / (double)maxScore < threshold)) --s;     // exactly the test of :89
+            while ((double)s / (double)maxScore < threshold) ++s;
+        }
+        need[k] = s;
+    }
     const char* dev = std::getenv("DEFUSE_GPU");          // as the other tools: device ordinal, default 0
     const int device = dev ? std::atoi(dev) : 0;
-    if (la_align_batch(device, matchScore, misMatchScore, gapScore, b.pool.data(), (int64_t)b.pool.size(), b.items.data(),
-                       (int64_t)b.items.size(), scores.data(), nullptr) != 0)
+    if (la_align_batch_min(device, matchScore, misMatchScore, gapScore, b.pool.data(), (int64_t)b.pool.size(), b.items.data(),
+                           (int64_t)b.items.size(), need.data(), scores.data(), nullptr) != 0)
         die(std::string("Error: GPU alignment failed: ") + la_last_error());
     for (size_t k = 0; k < b.items.size(); ++k) {
         const int score = scores[k];
