@@ -59,6 +59,8 @@ struct PipeLane {
     hipEvent_t ev[7] = {};      // 0 pack start, 4 pack end, 1 fill start, 2 fill end, 3 phase-1 end, 5 emit start, 6 emit end
     HostResult* host = nullptr;
     int slice = -1;             // slice whose phase 1 is in flight
+    int64_t resident_upload = -1;   // the descriptors of (resident_upload, resident_slice) are on the device
+    int resident_slice = -1;
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
@@ -107,6 +109,7 @@ struct dsa_ctx {
     int32_t n_fusions = 0;
     DevBuf<uint8_t> d_ref, d_reads;
     DevBuf<dsa_fusion> d_fusions;
+    int64_t upload_serial = 0;       // counts dsa_upload calls
     DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig), when pairs were reordered
     DevBuf<dsa_pair> d_pairs_sweep;  // second pair buffer: the permutation is written here, then the two are swapped
     DevBuf<dsa_pair> d_pairs;
@@ -469,12 +472,19 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_tasks.reserve((size_t)np * 4 + 1024));
     HIPC(L.d_masks.reserve((size_t)np * 8 + 1024));
     HIPC(L.d_gtasks.reserve((size_t)np * 2 + 1024));
-    HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIPC(hipEventRecord(L.ev[0], st));
+    // The wave / workgroup descriptors are inputs of the batch like the pairs themselves: a batch that is run
+    // again finds them on the device (the generic flags the fill kernel may have set for it stay valid too).
+    // All packing (reference codes here, row codes inside the fill) is redone by every run.
+    if (L.resident_upload != ctx->upload_serial || L.resident_slice != slice_idx) {
+        HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
+        HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        L.resident_upload = ctx->upload_serial;
+        L.resident_slice = slice_idx;
+    }
     {
-        int64_t total = (int64_t)g.n_fusions * g.lrp;
+        const int64_t total = (int64_t)g.n_fusions * g.lrp;
         hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
                            L.d_refcodes.p, g);
     }
@@ -657,6 +667,7 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     HIPC(hipSetDevice(ctx->device));
     ctx->have_results = false;
     ctx->n_records = 0;
+    ++ctx->upload_serial;
     ctx->n_pairs = n_pairs;
     ctx->n_fusions = n_fusions;
     ctx->ref_bytes_len = ref_bytes_len;
