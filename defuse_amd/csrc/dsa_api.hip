@@ -173,35 +173,31 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
 // fusions whose alignments end in the same tiles (device probe) sit next to each other, so the lanes of a
 // wave that straddles two fusions are alive in the same tiles.  Everything that touches pairs runs on the
 // device (statistics per fusion, probe, permutation); the host sorts the fusions and derives the wave and
-// workgroup descriptors from the runs.  Needs the pairs of every fusion to be one run and the batch to fit
-// one slice (the record offsets of a reordered batch come from one scan over all pairs); otherwise, and
-// with DEFUSE_DSA_NO_REORDER=1, the caller's order is swept.  Returns 1 if the plan was made, 0 if not.
-int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqmax)
+// workgroup descriptors from the runs.  A batch larger than the scratch budget is cut into contiguous ranges
+// of the caller's order, each planned on its own (records of a slice follow those of the slices before it, so
+// the offsets of a reordered slice only need the scan over that slice).  Needs the pairs of every fusion to
+// be one run inside a slice; otherwise, and with DEFUSE_DSA_NO_REORDER=1, the caller's order is swept.
+// Returns 1 if the plan was made, 0 if not.
+// plans pairs [begin, end) of the caller's order as one slice; 0 = some fusion is not one run in it
+int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t end, int lq1, DevBuf<FusionStat>& d_stat,
+               DevBuf<int32_t>& d_votes, DevBuf<uint8_t>& d_tiles, DevBuf<int32_t>& d_start, Slice& cur)
 {
     const int nf = ctx->n_fusions;
-    const char* off = getenv("DEFUSE_DSA_NO_REORDER");
-    if (nf < 2 || n_pairs < 2 * WG_LANES || (off && atoi(off) != 0) || getenv("DEFUSE_DSA_SLICE_PAIRS")) return 0;
+    const int64_t n = end - begin;
     hipStream_t st = ctx->stream;
+    const dsa_pair* pairs = ctx->d_pairs.p + begin;
     std::vector<FusionStat> stat((size_t)nf);
     std::vector<uint8_t> tiles((size_t)2 * nf);
-    DevBuf<FusionStat> d_stat;
-    {
-        DevBuf<int32_t> d_votes;
-        DevBuf<uint8_t> d_tiles;
-        HIPC(d_stat.reserve((size_t)nf));
-        HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
-        HIPC(d_tiles.reserve((size_t)nf * 2));
-        HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_fusion_stats_init, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d_stat.p, nf);
-        hipLaunchKernelGGL(k_fusion_stats, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs, d_stat.p);
-        hipLaunchKernelGGL(k_probe_wave, dim3((unsigned)nf * PROBE_READS), dim3(WAVE), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
-                           ctx->d_pairs.p, d_stat.p, d_votes.p);
-        hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
-        HIPC(hipMemcpyAsync(stat.data(), d_stat.p, (size_t)nf * sizeof(FusionStat), hipMemcpyDeviceToHost, st));
-        HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
-        HIPC(hipStreamSynchronize(st));
-        HIPC(hipGetLastError());
-    }
+    HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_fusion_stats_init, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d_stat.p, nf);
+    hipLaunchKernelGGL(k_fusion_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p);
+    hipLaunchKernelGGL(k_probe_wave, dim3((unsigned)nf * PROBE_READS), dim3(WAVE), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
+                       pairs, d_stat.p, d_votes.p);
+    hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
+    HIPC(hipMemcpyAsync(stat.data(), d_stat.p, (size_t)nf * sizeof(FusionStat), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    HIPC(hipGetLastError());
     for (int f = 0; f < nf; ++f)
         if (stat[f].count > 0 && stat[f].last - stat[f].first + 1 != stat[f].count) return 0;     // not one run per fusion
 
@@ -210,8 +206,9 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
         const int c = stat[f].count;
         return c >= WAVE ? 0 : c >= WG_LANES / GSPLIT ? 1 : c >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
     };
-    std::vector<int32_t> forder((size_t)nf);
-    for (int f = 0; f < nf; ++f) forder[f] = f;
+    std::vector<int32_t> forder;
+    for (int f = 0; f < nf; ++f)
+        if (stat[f].count > 0) forder.push_back(f);
     std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
         const int ca = size_class(a), cb = size_class(b);
         if (ca != cb) return ca < cb;
@@ -219,26 +216,19 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     });
 
     // geometry and descriptors from the runs
-    Slice cur;
-    cur.pair_begin = 0;
-    cur.pair_end = n_pairs;
+    cur.pair_begin = begin;
+    cur.pair_end = end;
     int nch = 1;
-    for (int f = 0; f < nf; ++f)
-        if (stat[f].count > 0) nch = std::max(nch, window_tiles(f));
-    const int lq1 = (lqmax + 1 + 3) & ~3;
-    const int64_t n_waves = (n_pairs + WAVE - 1) / WAVE, n_wgs = (n_pairs + WG_LANES - 1) / WG_LANES;
-    if (slice_scratch_bytes(n_waves, lq1, nch) > ctx->scratch_budget) return 0;              // would need several slices
+    for (int f : forder) nch = std::max(nch, window_tiles(f));
+    const int64_t n_waves = (n + WAVE - 1) / WAVE, n_wgs = (n + WG_LANES - 1) / WG_LANES;
     cur.waves.assign((size_t)n_waves, WaveInfo{0, 0});
     cur.wgs.assign((size_t)n_wgs, WgInfo{});
     cur.wg_flags.assign((size_t)n_wgs, 0u);
     std::vector<int32_t> new_start((size_t)nf, 0);
-    ctx->total_cells = 0;
     int64_t pos = 0;
-    for (int r = 0; r < nf; ++r) {
-        const int f = forder[r];
+    for (int f : forder) {
         const int64_t c = stat[f].count;
         new_start[f] = (int32_t)pos;
-        if (c == 0) continue;
         const int tl = window_tiles(f);
         for (int64_t w = pos / WAVE; w <= (pos + c - 1) / WAVE; ++w) {
             cur.waves[w].lq_max = std::max(cur.waves[w].lq_max, stat[f].max_lq);    // upper bound of the wave's reads
@@ -263,23 +253,53 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     cur.g.nch = nch;
     cur.g.lrp = nch * W;
     cur.g.n_fusions = nf;
-    cur.g.n_pairs = n_pairs;
+    cur.g.n_pairs = n;
+    cur.g.orig = ctx->d_orig.p + begin;        // slice-relative indices of the caller's order
 
     // pairs into sweep order on the device
-    DevBuf<int32_t> d_start;
+    HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p,
+                       ctx->d_pairs_sweep.p + begin, ctx->d_orig.p + begin);
+    HIPC(hipStreamSynchronize(st));             // new_start is reused by the next chunk
+    HIPC(hipGetLastError());
+    return 1;
+}
+
+int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqmax)
+{
+    const int nf = ctx->n_fusions;
+    const char* off = getenv("DEFUSE_DSA_NO_REORDER");
+    if (nf < 2 || n_pairs < 2 * WG_LANES || (off && atoi(off) != 0)) return 0;
+    // slices: contiguous ranges of the caller's order that fit the scratch budget (and DEFUSE_DSA_SLICE_PAIRS)
+    int nch_all = 1;
+    for (int f = 0; f < nf; ++f) nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
+    const int lq1 = (lqmax + 1 + 3) & ~3;
+    const size_t per_wg = slice_scratch_bytes(WG_WAVES, lq1, nch_all);
+    int64_t chunk = (int64_t)std::min<size_t>((size_t)1 << 40, ctx->scratch_budget / std::max<size_t>(per_wg, 1)) * WG_LANES;
+    // (cutting a batch that fits into two slices, so that the finish kernels of the first overlap the fill of the
+    // second, measured between -0.4 % and -2 % per step: not done, one fill launch per batch is easier to reason about)
+    if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
+    if (chunk < 2 * WG_LANES) return 0;
+    DevBuf<FusionStat> d_stat;
+    DevBuf<int32_t> d_votes, d_start;
+    DevBuf<uint8_t> d_tiles;
+    HIPC(d_stat.reserve((size_t)nf));
+    HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
+    HIPC(d_tiles.reserve((size_t)nf * 2));
     HIPC(d_start.reserve((size_t)nf));
     HIPC(ctx->d_orig.reserve((size_t)n_pairs));
     HIPC(ctx->d_pairs_sweep.reserve((size_t)n_pairs + 1));
-    HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs, d_stat.p, d_start.p,
-                       ctx->d_pairs_sweep.p, ctx->d_orig.p);
-    HIPC(hipStreamSynchronize(st));
-    HIPC(hipGetLastError());
+    std::vector<Slice> slices;
+    ctx->total_cells = 0;
+    for (int64_t b = 0; b < n_pairs; b += chunk) {
+        Slice cur;
+        const int rc = plan_chunk(ctx, fusions, b, std::min(n_pairs, b + chunk), lq1, d_stat, d_votes, d_tiles, d_start, cur);
+        if (rc != 1) return rc;                 // the caller's pairs are untouched: the unplanned path takes over
+        slices.push_back(std::move(cur));
+    }
     std::swap(ctx->d_pairs.p, ctx->d_pairs_sweep.p);
     std::swap(ctx->d_pairs.cap, ctx->d_pairs_sweep.cap);
-    cur.g.orig = ctx->d_orig.p;
-    ctx->slices.clear();
-    ctx->slices.push_back(std::move(cur));
+    ctx->slices = std::move(slices);
     return 1;
 }
 
