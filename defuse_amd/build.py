@@ -31,11 +31,11 @@ def _run(cmd):
 
 def build_lib(force=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h")]
+           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h")]
     if force or _newer(LIB, srcs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
               "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip"),
-              os.path.join(CSRC, "la_api.hip")])
+              os.path.join(CSRC, "la_api.hip"), os.path.join(CSRC, "hc_api.hip")])
     return LIB
 
 

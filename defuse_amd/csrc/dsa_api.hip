@@ -758,6 +758,19 @@ int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n)
     return DSA_OK;
 }
 
+int dsa_copy_records_device(dsa_ctx* ctx, void* out_device, int64_t out_cap, int64_t* out_n)
+{
+    if (!ctx || !ctx->have_results) return fail(ctx, DSA_E_ARG, "dsa_copy_records_device before dsa_run");
+    if (out_n) *out_n = ctx->n_records;
+    if (ctx->n_records > out_cap) return fail(ctx, DSA_E_CAPACITY, "need room for %lld records", (long long)ctx->n_records);
+    if (ctx->n_records) {
+        if (!out_device) return fail(ctx, DSA_E_ARG, "null output");
+        HIPC(hipMemcpyAsync(out_device, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+    }
+    return DSA_OK;
+}
+
 int dsa_get_timing(const dsa_ctx* ctx, dsa_timing* out)
 {
     if (!ctx || !out) return DSA_E_ARG;

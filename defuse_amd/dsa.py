@@ -20,7 +20,7 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
 EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_align_batch",
-           "dsa_upload", "dsa_run", "dsa_download", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
+           "dsa_upload", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
 
 DSA_E_CAPACITY = -1
 
@@ -64,6 +64,7 @@ def load_library():
         lib.dsa_upload.argtypes = batch
         lib.dsa_run.argtypes = [vp, ctypes.POINTER(i64)]
         lib.dsa_download.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
+        lib.dsa_copy_records_device.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
         lib.dsa_get_timing.argtypes = [vp, ctypes.POINTER(Timing)]
         lib.dsa_set_stream.argtypes = [vp, vp]
         lib.dsa_synchronize.argtypes = [vp]
@@ -137,6 +138,15 @@ class Context:
             if rc != 0:
                 self._err(rc)
         return out
+
+    def records_to_device(self, device_ptr, capacity):
+        """Copies the records of the last run into device memory the caller owns (e.g. a torch tensor's
+        data_ptr()); returns the record count.  Raises DsaError(DSA_E_CAPACITY) if it does not fit."""
+        n = ctypes.c_int64(0)
+        rc = self.lib.dsa_copy_records_device(self.h, ctypes.c_void_p(device_ptr), int(capacity), ctypes.byref(n))
+        if rc != 0:
+            self._err(rc)
+        return n.value
 
     def timing(self):
         t = Timing()

@@ -40,3 +40,38 @@ def merge_records(parts):
         out.append(r)
     allr = np.concatenate(out) if out else np.zeros(0, dtype=RECORD_DTYPE)
     return allr[np.argsort(allr["pair_idx"], kind="stable")]
+
+
+RECORD_WORDS = RECORD_DTYPE.itemsize // 4
+
+
+def gather_records(recs, pair_base=0, dst=0, group=None):
+    """recs: this rank's records as an int32 tensor [n, RECORD_WORDS] (on the GPU with RCCL, on the CPU with gloo);
+    pair_base is added to its pair_idx column so that the gathered records carry job-wide pair numbers.
+    Returns (on dst) the records of all ranks in rank order as one tensor plus the per-rank counts, else (None, counts).
+    Collectives: one all_gather of the counts, then one group of isend/irecv with exact sizes (no padding)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert recs.dtype == torch.int32 and recs.dim() == 2 and recs.shape[1] == RECORD_WORDS
+    if pair_base:
+        recs = recs.clone()
+        recs[:, RECORD_WORDS - 1] += int(pair_base)
+    recs = recs.contiguous()
+    mine = torch.tensor([recs.shape[0]], dtype=torch.int64, device=recs.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=recs.device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    if rank != dst:
+        if counts[rank]:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, recs, dst, group)]):
+                w.wait()
+        return None, counts
+    out = torch.empty((sum(counts), RECORD_WORDS), dtype=torch.int32, device=recs.device)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    out[starts[rank]:starts[rank + 1]] = recs
+    ops = [dist.P2POp(dist.irecv, out[starts[r]:starts[r + 1]], r, group) for r in range(world) if r != dst and counts[r]]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out, counts

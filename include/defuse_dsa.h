@@ -122,6 +122,9 @@ int dsa_upload(dsa_ctx* ctx,
                const dsa_pair* pairs, int64_t n_pairs);
 int dsa_run(dsa_ctx* ctx, int64_t* out_n);                       /* all kernels, records stay on device */
 int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n);
+/* Same as dsa_download, but `out_device` is device memory of the ctx's GPU (room for out_cap records): the
+ * records never visit the host.  This is what the multi-GPU gather sends over RCCL. */
+int dsa_copy_records_device(dsa_ctx* ctx, void* out_device, int64_t out_cap, int64_t* out_n);
 int dsa_get_timing(const dsa_ctx* ctx, dsa_timing* out);
 /* Use an existing HIP stream (e.g. torch's current stream) instead of the ctx's own; pass the
  * hipStream_t as an opaque pointer, NULL restores the private stream. */

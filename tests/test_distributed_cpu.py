@@ -30,10 +30,23 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # bench.py's max-over-ranks timing
     gathered = [None] * world
     dist.all_gather_object(gathered, (recs, orig))
+    # the tensor gather bench.py and a multi-GPU caller use (RCCL there, gloo here): records as int32 rows,
+    # pair_idx renumbered to the job-wide candidate list before sending
+    r = recs.copy()
+    if len(r):
+        r["pair_idx"] = orig[r["pair_idx"]]
+    rows = torch.from_numpy(np.ascontiguousarray(r).view(np.int32).reshape(-1, shard.RECORD_WORDS))
+    allrows, counts = shard.gather_records(rows, dst=0)
     if rank == 0:
         merged = shard.merge_records(gathered)
         exp = ora.align_batch(*batch)
-        q.put((float(t.item()), merged.tobytes() == exp.tobytes(), len(exp), [len(g[0]) for g in gathered]))
+        from defuse_amd.dsa import RECORD_DTYPE
+        viat = allrows.numpy().view(RECORD_DTYPE).reshape(-1)
+        viat = viat[np.argsort(viat["pair_idx"], kind="stable")]
+        same = merged.tobytes() == exp.tobytes() and viat.tobytes() == exp.tobytes() and counts == [len(g[0]) for g in gathered]
+        q.put((float(t.item()), same, len(exp), [len(g[0]) for g in gathered]))
+    else:
+        assert allrows is None
     dist.barrier()
     dist.destroy_process_group()
 
