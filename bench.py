@@ -5,7 +5,9 @@ A "step" is one pass of the hot path (pack -> DP fill -> combine/replay/emit) ov
 synthetic candidates that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
 (10k synthetic fusions x 100 reads, 2x76 bp => Lref 389, 1M aligns).  With N>1 ranks every rank
 holds its own batch of the same shape (fusions are independent, no data-path collective: weak
-scaling); the only collective is the barrier/max-reduction of the timing.
+scaling); the timed region has no collective beyond the barrier/max-reduction of the timing.  After it,
+with N>1, the final gather of the result records on rank 0 (the path's one exchange step) is
+run and timed on its own over RCCL: HBM -> xGMI -> rank 0's HBM, reported as "gather" in the JSON line.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -65,6 +67,41 @@ def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
     return {"value": total / dt, "unit": "aligns/s", "cores": len(chunks), "kind": "port",
             "sample": "first %d aligns of the same batch in %d shares, oracle/dsa_oracle.c, one thread per share, %.1f s "
                       "(one thread alone: %.0f aligns/s)" % (total, len(chunks), dt, 1.0 / per)}
+
+
+def gather_leg(ctx, n_rec, n_pairs, rank, world, backend, barrier, reps=5):
+    """The final gather of one step's records on rank 0 (defuse_amd/shard.py:gather_records), timed by itself:
+    records go device -> device; max over ranks by construction (rank 0 waits for every peer)."""
+    import torch
+    from defuse_amd import shard
+    try:
+        buf = torch.empty((max(n_rec, 1), shard.RECORD_WORDS), dtype=torch.int32, device="cuda")
+        got = ctx.records_to_device(buf.data_ptr(), buf.shape[0])
+        rows = buf[:got] if backend == "nccl" else buf[:got].cpu()      # gloo rehearsal: host tensors
+        base = rank * n_pairs
+        out, counts = shard.gather_records(rows, pair_base=base)       # untimed first call (communicator set-up)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out, counts = shard.gather_records(rows, pair_base=base)
+        barrier()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        if rank != 0:
+            return None
+        total = sum(counts)
+        ok = out.shape[0] == total
+        lo = 0
+        for r, c in enumerate(counts):             # every rank's records arrived in its slot, renumbered job-wide
+            if c:
+                col = out[lo:lo + c, shard.RECORD_WORDS - 1]
+                ok = ok and int(col.min()) >= r * n_pairs and int(col.max()) < (r + 1) * n_pairs
+            lo += c
+        nbytes = (total - counts[0]) * shard.RECORD_WORDS * 4
+        return {"ms": ms, "records": total, "bytes_moved": nbytes, "GB/s": nbytes / (ms * 1e-3) / 1e9, "verified": bool(ok),
+                "backend": "rccl" if backend == "nccl" else backend, "included_in_value": False,
+                "pattern": "all_gather of counts + grouped isend/irecv, exact sizes, peers -> rank 0"}
+    except Exception as e:                          # the throughput line must survive a failed gather
+        return {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
 
 
 def main():
@@ -136,6 +173,10 @@ def main():
     else:
         total_aligns = len(pairs) * args.steps
 
+    gather = None
+    if world > 1 and os.environ.get("DEFUSE_BENCH_GATHER", "1") != "0":
+        gather = gather_leg(ctx, n_rec, len(pairs), rank, world, backend, barrier)
+
     if rank == 0:
         t = ctx.timing()
         rec_per_align = n_rec / len(pairs)
@@ -168,6 +209,8 @@ def main():
             "replay_tiles_per_align": round(t.n_replay_tasks / len(pairs), 4),
             "generic_replay_tiles_per_align": round(t.n_generic_tasks / len(pairs), 4),
         }
+        if gather is not None:
+            out["gather"] = gather
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, fus, reads, pairs)
         print(json.dumps(out), flush=True)
