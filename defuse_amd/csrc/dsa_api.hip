@@ -4,6 +4,7 @@
 // reference) for whole batches.  There is deliberately no CPU fallback in this file: without a HIP
 // device dsa_create fails and every other entry point needs a ctx.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -576,6 +577,19 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
 extern "C" {
 
 const char* dsa_version(void) { return "defuse_amd dsa 0.1 (gfx950)"; }
+
+int dsa_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int dsa_pick_device(void)
+{
+    if (const char* e = getenv("DEFUSE_GPU")) return atoi(e);
+    const int n = dsa_device_count();
+    return n > 1 ? (int)((unsigned long)getpid() % (unsigned long)n) : 0;
+}
 
 int dsa_create(dsa_ctx** out, int device)
 {

@@ -19,7 +19,7 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
                                              "ref_second", "read_first", "read_second", "score", "pair_idx")])
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
-EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_align_batch",
+EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_align_batch",
            "dsa_upload", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
 
 DSA_E_CAPACITY = -1

@@ -101,6 +101,11 @@ void dsa_destroy(dsa_ctx* ctx);
 int  dsa_get_limits(const dsa_ctx* ctx, dsa_limits* out);
 const char* dsa_last_error(const dsa_ctx* ctx); /* human-readable text for the last failure      */
 const char* dsa_version(void);
+/* HIP devices this process sees (0 without a GPU), and the ordinal a tool should use: DEFUSE_GPU if set, else
+ * pid mod device count — the pipeline starts up to --parallel independent tool processes (scripts/defuse_run.pl:33,285;
+ * SURVEY 8(b)), which spreads them over the GPUs of a node without any of them assuming it owns one. */
+int dsa_device_count(void);
+int dsa_pick_device(void);
 
 /* ---- one-shot: host buffers in, host records out ----------------------------------------- */
 /* Records are ordered by pair index, then in the reference's emission order (read split a

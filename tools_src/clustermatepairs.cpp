@@ -7,6 +7,7 @@
 // orders of SURVEY.md 8(c).
 #include <numeric>
 
+#include "../include/defuse_dsa.h"
 #include "../include/defuse_mpe.h"
 #include "defuse_host.hpp"
 
@@ -281,9 +282,8 @@ int main(int argc, char* argv[])
     std::vector<int32_t> nClusters(problems.size(), 0), status(problems.size(), 0);
     std::vector<uint16_t> member(X.size(), 0);
     if (!problems.empty()) {
-        const char* dev = std::getenv("DEFUSE_GPU");
         mpe_timing t;
-        const int rc = mpe_cluster_batch(dev ? std::atoi(dev) : 0, &prm, probOff.data(), (int32_t)problems.size(), X.data(), Y.data(),
+        const int rc = mpe_cluster_batch(dsa_pick_device(), &prm, probOff.data(), (int32_t)problems.size(), X.data(), Y.data(),
                                          U.data(), toXO.data(), toYO.data(), nClusters.data(), member.data(), status.data(), &t);
         if (rc != 0) die(std::string("Error: mate pair clustering on the GPU failed: ") + mpe_last_error());
         if (std::getenv("DEFUSE_TIMING"))

@@ -7,7 +7,8 @@
 // — the canonical order of SURVEY.md 8(c) for the reference's unordered_set iteration (the pipeline
 // sorts the file by fusion id afterwards, scripts/defuse_run.pl:528).
 //
-// Environment: DEFUSE_GPU=<ordinal> selects the device (default 0; with HIP_VISIBLE_DEVICES the
+// Environment: DEFUSE_GPU=<ordinal> selects the device (default: pid mod device count, so the processes the
+// pipeline runs side by side spread over a node's GPUs; with HIP_VISIBLE_DEVICES the
 // ordinal is relative to the visible set).
 #include <numeric>
 
@@ -82,8 +83,7 @@ int main(int argc, char* argv[])
         for (size_t k = 0; k < order.size(); ++k) pairs[k] = cand[order[k]];
 
         if (!ctx) {
-            const char* dev = std::getenv("DEFUSE_GPU");
-            if (dsa_create(&ctx, dev ? std::atoi(dev) : 0) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
+            if (dsa_create(&ctx, dsa_pick_device()) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
         }
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
         int64_t n = 0;

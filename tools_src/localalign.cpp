@@ -3,6 +3,7 @@
 // stdout lines `id \t score \t percent` for the pairs whose percent reaches the threshold.  The scores
 // (SimpleAligner::Align, tools/SimpleAligner.cpp:24-64) come from the GPU through include/defuse_la.h;
 // there is no CPU fallback: without a HIP device the tool exits 1.
+#include "../include/defuse_dsa.h"
 #include "../include/defuse_la.h"
 #include "defuse_host.hpp"
 
@@ -36,8 +37,7 @@ void flush(Batch& b, int matchScore, int misMatchScore, int gapScore, double thr
         }
         need[k] = s;
     }
-    const char* dev = std::getenv("DEFUSE_GPU");          // as the other tools: device ordinal, default 0
-    const int device = dev ? std::atoi(dev) : 0;
+    const int device = dsa_pick_device();                  // as the other tools: DEFUSE_GPU, else pid mod device count
     if (la_align_batch_min(device, matchScore, misMatchScore, gapScore, b.pool.data(), (int64_t)b.pool.size(), b.items.data(),
                            (int64_t)b.items.size(), need.data(), scores.data(), nullptr) != 0)
         die(std::string("Error: GPU alignment failed: ") + la_last_error());

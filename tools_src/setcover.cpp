@@ -2,6 +2,7 @@
 // line, same cluster file format in and out, same progress lines on stdout.  ReadClusters /
 // WriteClusters follow tools/Parsers.cpp:23-170; SetCover itself runs on the GPU through
 // include/defuse_sc.h (no CPU fallback: without a HIP device the tool exits 1).
+#include "../include/defuse_dsa.h"
 #include "../include/defuse_sc.h"
 #include "defuse_host.hpp"
 
@@ -67,9 +68,8 @@ int main(int argc, char* argv[])
     }
     std::vector<int32_t> owner((size_t)maxElement + 1, -1);
     if (!elements.empty()) {
-        const char* dev = std::getenv("DEFUSE_GPU");
         sc_timing t;
-        const int rc = sc_cover(dev ? std::atoi(dev) : 0, off.data(), elements.data(), (int32_t)clusters.size(), maxElement,
+        const int rc = sc_cover(dsa_pick_device(), off.data(), elements.data(), (int32_t)clusters.size(), maxElement,
                                 owner.data(), &t);
         if (rc != 0) die(std::string("Error: set cover on the GPU failed: ") + sc_last_error());
         if (std::getenv("DEFUSE_TIMING"))
