@@ -418,9 +418,240 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Wave-per-fit version for the larger problems.  A lane that works through a whole fit by itself spends
+// N*K exp/log/divide sequences per EM iteration one after the other and reads its private arrays with 64
+// different addresses per wave instruction; the few largest bin pairs of a run then decide the kernel time.
+// Here one wave owns one fit:
+//   * everything elementwise over the mate pairs (exponents, exp, log, responsibilities, KKZ distances,
+//     memberships) runs lane-strided over i, coalesced;
+//   * every sum the reference takes serially stays one serial chain of the same additions in the same order,
+//     but independent chains run side by side: lane j owns component j (its NK, RXYU and the breakpoint
+//     walk of MaxLikelihood), lane 0 owns the log-likelihood chain;
+//   * the AS 136 k-means is sequential by construction (every transfer changes the centres the next point
+//     sees) and runs on lane 0.
+// Results are those of the lane version operation for operation: same expressions, same order, same ocml calls.
+struct WaveShared {
+    double W[MPE_KMAX], A[MPE_KMAX], B[MPE_KMAX];
+    double px[MPE_KMAX], py[MPE_KMAX], c[2 * MPE_KMAX];
+    double like;
+    int ifault, flag;
+};
+
+constexpr int WV = 64;
+
+// MaxLikelihood (:192-325) for one component in one lane, streaming: the two prefix sums advance with the
+// walk (SX[i] = SX[i-1] + RXO[i]) and the first breakpoint with a positive derivative ends it, so neither the
+// prefix arrays nor the breakpoint list are stored.  nk receives the component's sum of responsibilities
+// (UpdateMixWeights :183-190 takes the same sum in the same order).  Return codes as max_likelihood.
+__device__ int max_likelihood_stream(const Work& w, const double* R, const double* RXO, const double* RYO, double& a, double& b,
+                                     double& nk)
+{
+    const int N = w.N;
+    double NK = 0.0, RXYU = 0.0;
+    for (int t = 0; t < N; ++t) {
+        const double r = R[t];
+        NK += r;
+        RXYU += r * (w.X[t] + w.Y[t] + w.U[t]);
+    }
+    nk = NK;
+    if (NK == 0.0) return 0;
+    const double var = w.sd * w.sd;
+    double pcx = 0.0, pcy = 0.0, pcs = 0.0, ccx = 0.0, ccy = 0.0, ccs = 0.0;
+    int mi = 0;
+    bool found = false;
+    auto push = [&](double cx, double cy, double cs) {
+        if (found) return;
+        if ((RXYU - NK * (cx + cy)) / var + LAMBDA * cs > 0) { found = true; ccx = cx; ccy = cy; ccs = cs; }
+        else { pcx = cx; pcy = cy; pcs = cs; ++mi; }
+    };
+    int i = 0, j = 0;
+    double sx = RXO[0], sy = RYO[0];
+    push(w.XO[0], w.YO[0], 0.0);
+    while (!found && i < N && j < N) {
+        if (i + 1 < N && w.XO[i] == w.XO[i + 1]) { ++i; sx = sx + RXO[i]; continue; }
+        if (j + 1 < N && w.YO[j] == w.YO[j + 1]) { ++j; sy = sy + RYO[j]; continue; }
+        if (sx == sy) {
+            push(w.XO[i], w.YO[j], sx);
+            if (i + 1 < N && j + 1 < N) push(w.XO[i + 1], w.YO[j + 1], sx);
+            ++i;
+            ++j;
+            if (i < N) sx = sx + RXO[i];
+            if (j < N) sy = sy + RYO[j];
+        } else if (sx < sy) {
+            push(w.XO[i], w.YO[j], sx);
+            if (i + 1 < N) push(w.XO[i + 1], w.YO[j], sx);
+            ++i;
+            if (i < N) sx = sx + RXO[i];
+        } else {
+            push(w.XO[i], w.YO[j], sy);
+            if (j + 1 < N) push(w.XO[i], w.YO[j + 1], sy);
+            ++j;
+            if (j < N) sy = sy + RYO[j];
+        }
+    }
+    if (!found) return -1;
+    const double aplusb = (RXYU + var * LAMBDA * ccs) / NK;
+    if (mi == 0) {
+        const double min_a = ccx, max_a = aplusb - ccy;
+        a = 0.5 * (min_a + max_a);
+        b = aplusb - a;
+    } else if (ccs != pcs) {
+        a = ccx;
+        b = ccy;
+    } else {
+        const double min_a = fmax(ccx, aplusb - pcy);
+        const double max_a = fmin(pcx, aplusb - ccy);
+        a = 0.5 * (min_a + max_a);
+        b = aplusb - a;
+    }
+    return 1;
+}
+
+// index of the first maximum of v over the wave's candidates (the serial scans keep the first with strict '>')
+__device__ int wave_first_argmax(double v, int idx, double& vmax)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    vmax = v;
+    return idx;
+}
+
+__device__ bool select_kkz_wave(Work& w, WaveShared& s, int k, int lane)   // :327-386
+{
+    const int N = w.N;
+    double best = 0.0;
+    int bi = -1;
+    for (int i = lane; i < N; i += WV) {
+        const double l2 = w.X[i] * w.Y[i];
+        if (bi < 0 || l2 > best) { best = l2; bi = i; }
+    }
+    double vm;
+    const int imax = wave_first_argmax(best, bi, vm);
+    if (lane == 0) { s.px[0] = w.X[imax]; s.py[0] = w.Y[imax]; }
+    __syncthreads();
+    for (int na = 1; na < k; ++na) {
+        best = 0.0;
+        bi = -1;
+        for (int i = lane; i < N; i += WV) {
+            double md = (w.X[i] - s.px[0]) * (w.X[i] - s.px[0]) + (w.Y[i] - s.py[0]) * (w.Y[i] - s.py[0]);
+            for (int j = 1; j < na; ++j) {
+                const double dj = (w.X[i] - s.px[j]) * (w.X[i] - s.px[j]) + (w.Y[i] - s.py[j]) * (w.Y[i] - s.py[j]);
+                md = fmin(md, dj);
+            }
+            if (bi < 0 || md > best) { best = md; bi = i; }
+        }
+        const int idx = wave_first_argmax(best, bi, vm);
+        if (vm == 0.0) return false;
+        __syncthreads();
+        if (lane == 0) { s.px[na] = w.X[idx]; s.py[na] = w.Y[idx]; }
+        __syncthreads();
+    }
+    return true;
+}
+
+// ExpectationMaximization (:388-494), one wave; every lane returns the same values
+__device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int lane, double& ll)
+{
+    const int N = w.N;
+    if (K == 1 || K == N) {
+        const double v = 1.0 / K;
+        for (size_t t = lane; t < (size_t)K * N; t += WV) { w.R[t] = v; w.RXO[t] = v; w.RYO[t] = v; }
+    } else {
+        if (!select_kkz_wave(w, s, K, lane)) return false;
+        for (int i = lane; i < N; i += WV) { w.ka[i] = w.Y[i]; w.ka[N + i] = w.X[i]; }
+        if (lane < K) { s.c[lane] = s.py[lane]; s.c[K + lane] = s.px[lane]; }
+        __syncthreads();
+        if (lane == 0) s.ifault = kmns(w.ka, N, s.c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER);
+        __syncthreads();
+        if (s.ifault == 1 || s.ifault == 3) { w.fail = 1; return false; }
+        for (int i = lane; i < N; i += WV) {
+            const int own = w.ic1[i] - 1, ixo = w.ToXO[i], iyo = w.ToYO[i];
+            for (int j = 0; j < K; ++j) {
+                const double v = (j == own) ? 1.0 : 0.0;
+                w.R[(size_t)j * N + i] = v;
+                w.RXO[(size_t)j * N + ixo] = v;
+                w.RYO[(size_t)j * N + iyo] = v;
+            }
+        }
+    }
+    __syncthreads();
+    double last = 0.0;
+    bool valid = false;
+    for (;;) {
+        // M step: component j in lane j
+        int rc = 0;
+        if (lane < K) {
+            double a = 0.0, b = 0.0, nk = 0.0;
+            rc = max_likelihood_stream(w, w.R + (size_t)lane * N, w.RXO + (size_t)lane * N, w.RYO + (size_t)lane * N, a, b, nk);
+            if (rc > 0) { s.A[lane] = a; s.B[lane] = b; }
+            s.W[lane] = nk / N;
+        }
+        if (__any(rc < 0)) { w.fail = 1; return false; }
+        if (lane == 0) s.flag = 0;
+        __syncthreads();
+        // E step, elementwise part: exponents, exp, mixture sum, log.  EX keeps exp(EX - maxexp), kd the mixture
+        // sum, SX / SY the two terms of the log-likelihood chain.
+        bool zero = false;
+        for (int i = lane; i < N; i += WV) {
+            for (int j = 0; j < K; ++j) {
+                const double t = (s.A[j] + s.B[j] - w.X[i] - w.Y[i] - w.U[i]) / w.sd;
+                w.EX[(size_t)j * N + i] = -0.5 * (t * t) - LAMBDA * fmax(0.0, w.X[i] - s.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[j]);
+            }
+            double maxexp = w.EX[i];
+            for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, w.EX[(size_t)j * N + i]);
+            double sum = 0.0;
+            for (int j = 0; j < K; ++j) {
+                const double e = exp(w.EX[(size_t)j * N + i] - maxexp);
+                w.EX[(size_t)j * N + i] = e;
+                sum += s.W[j] * e;
+            }
+            if (sum == 0.0) zero = true;
+            w.kd[i] = sum;
+            w.SX[i] = log(sum);
+            w.SY[i] = maxexp;
+        }
+        if (zero) s.flag = 1;
+        __syncthreads();
+        if (lane == 0) {                       // LogLikelihood :96-137, the serial chain
+            double LL = 0.0;
+            if (s.flag) LL = -DBL_MAX_;
+            else
+                for (int i = 0; i < N; ++i) LL = LL + w.SX[i] + w.SY[i];
+            s.like = LL;
+        }
+        __syncthreads();
+        const double like = s.like;
+        const bool any_zero = s.flag != 0;
+        w.iters += 1;
+        if (valid && fabs(like - last) < TOLERANCE) break;
+        if (valid && like == -DBL_MAX_) return false;
+        if (valid && !(like / last < 1.0000001)) { w.fail = 1; return false; }   // DebugCheck
+        last = like;
+        valid = true;
+        if (any_zero) { w.fail = 1; return false; }                              // DebugCheck(norm != 0.0), :172
+        for (int i = lane; i < N; i += WV) {                                     // UpdateResponsibilities :139-181
+            const int ixo = w.ToXO[i], iyo = w.ToYO[i];
+            const double norm = w.kd[i];
+            for (int j = 0; j < K; ++j) {
+                const double r = s.W[j] * w.EX[(size_t)j * N + i] / norm;
+                w.R[(size_t)j * N + i] = r;
+                w.RXO[(size_t)j * N + ixo] = r;
+                w.RYO[(size_t)j * N + iyo] = r;
+            }
+        }
+        __syncthreads();
+    }
+    ll = last;
+    return true;
+}
+
 // carve the workspace of a fit with up to K components and set up the sorted copies
 __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, const double* y, const double* u, const int32_t* to_xo,
-                          const int32_t* to_yo, double* d, int* ip, double sd)
+                          const int32_t* to_yo, double* d, int* ip, double sd, int first = 0, int step = 1)
 {
     w.N = N;
     w.X = x + b; w.Y = y + b; w.U = u + b;
@@ -445,7 +676,7 @@ __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, con
     w.iters = 0;
     w.fail = 0;
     for (int j = 0; j < MPE_KMAX; ++j) w.W[j] = w.A[j] = w.B[j] = 0.0;
-    for (int i = 0; i < N; ++i) {
+    for (int i = first; i < N; i += step) {
         w.XO[w.ToXO[i]] = w.X[i];
         w.YO[w.ToYO[i]] = w.Y[i];
     }
@@ -453,7 +684,7 @@ __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, con
 
 // fit_state[(p - p0) * MPE_KMAX + K - 1]: 0 = the fit gave no likelihood (the reference `continue`s),
 // 1 = bic valid, 2 = the reference would have exited through a DebugCheck
-__global__ void k_mpe_fit(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int n_chunk,
+__global__ void k_mpe_fit(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int first, int n_chunk,
                           const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
                           const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
                           const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
@@ -463,7 +694,7 @@ __global__ void k_mpe_fit(mpe_params prm, const int64_t* __restrict__ prob_off, 
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)n_chunk * MPE_KMAX) return;
     const int K = (int)(t / n_chunk) + 1;                 // K-major: a wave fits one K
-    const int q = order[t % n_chunk];                     // chunk-relative problem, largest first
+    const int q = order[first + t % n_chunk];             // chunk-relative problem, largest first
     const int p = p0 + q;
     const int64_t b = prob_off[p];
     const int N = (int)(prob_off[p + 1] - b);
@@ -482,16 +713,17 @@ __global__ void k_mpe_fit(mpe_params prm, const int64_t* __restrict__ prob_off, 
     atomicAdd(iters, (unsigned long long)w.iters);
 }
 
-__global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int n_chunk,
-                            const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ u,
+__global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, int first, int n_chunk,
+                            const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ u,
                             const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
                             const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
                             int* __restrict__ wints, const double* __restrict__ bic, const int32_t* __restrict__ fit_state,
                             int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status,
                             unsigned long long* __restrict__ iters)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_chunk) return;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_chunk) return;
+    const int q = order[first + qi];
     const int p = p0 + q;
     const int64_t b = prob_off[p];
     const int N = (int)(prob_off[p + 1] - b);
@@ -542,6 +774,105 @@ __global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off
     atomicAdd(iters, (unsigned long long)w.iters);
 }
 
+// one wave per (problem, K) fit of the chunk's n_large largest problems; heaviest fits first
+__global__ __launch_bounds__(WV) void k_mpe_fit_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
+                          const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
+                          const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
+                          const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
+                          int* __restrict__ wints, double* __restrict__ bic, int32_t* __restrict__ fit_state,
+                          unsigned long long* __restrict__ iters)
+{
+    __shared__ WaveShared s;
+    const int lane = threadIdx.x;
+    const int q = order[blockIdx.x / MPE_KMAX];
+    const int K = MPE_KMAX - (int)(blockIdx.x % MPE_KMAX);
+    const int p = p0 + q;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    const int slot = q * MPE_KMAX + K - 1;
+    if (lane == 0) fit_state[slot] = 0;
+    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
+    if (K > (N < MPE_KMAX ? N : MPE_KMAX)) return;
+    Work w;
+    init_work(w, N, K, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev, lane, WV);
+    if (lane < MPE_KMAX) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
+    __syncthreads();
+    double ll;
+    const bool ok = expectation_maximization_wave(w, s, K, lane, ll);
+    if (lane == 0) {
+        if (ok) {
+            bic[slot] = -2.0 * ll + K * 2.0 * log((double)N);
+            fit_state[slot] = 1;
+        }
+        if (w.fail) fit_state[slot] = 2;
+        atomicAdd(iters, (unsigned long long)w.iters);
+    }
+}
+
+// model selection, refit and memberships of one large problem per wave
+__global__ __launch_bounds__(WV) void k_mpe_final_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
+                            const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
+                            const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
+                            const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
+                            int* __restrict__ wints, const double* __restrict__ bic, const int32_t* __restrict__ fit_state,
+                            int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status,
+                            unsigned long long* __restrict__ iters)
+{
+    __shared__ WaveShared s;
+    const int lane = threadIdx.x;
+    const int q = order[blockIdx.x];
+    const int p = p0 + q;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    if (lane == 0) { n_clusters[p] = 0; status[p] = 0; }
+    for (int i = lane; i < N; i += WV) member[b + i] = 0;
+    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
+    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
+    double min_bic = 0.0;                                                  // :599-606, every lane the same
+    bool have = false, failed = false;
+    int k_min = 1;
+    for (int K = 1; K <= kmax; ++K) {
+        const int st = fit_state[q * MPE_KMAX + K - 1];
+        if (st == 2) { failed = true; break; }
+        if (st != 1) continue;
+        const double v = bic[q * MPE_KMAX + K - 1];
+        if (!have || v < min_bic) { min_bic = v; k_min = K; have = true; }
+    }
+    if (failed) { if (lane == 0) status[p] = 1; return; }
+    const int slot = q * MPE_KMAX + kmax - 1;
+    Work w;
+    init_work(w, N, kmax, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev, lane, WV);
+    if (lane < MPE_KMAX) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
+    __syncthreads();
+    double ll;
+    if (expectation_maximization_wave(w, s, k_min, lane, ll)) {
+        const double coeff = 1.0 / (w.sd * sqrt(2 * M_PI));                // normalpdf, tools/Common.cpp:61-69
+        int emitted = 0;
+        for (int j = 0; j < k_min; ++j) {
+            int count = 0;
+            for (int i = lane; i < N; i += WV) {
+                const double dist = ((s.A[j] + s.B[j] - w.X[i] - w.Y[i]) - w.U[i]) / w.sd;
+                const double prob = coeff * exp(-0.5 * dist * dist) *
+                                    exp(-LAMBDA * fmax(0.0, w.X[i] - s.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[j]));
+                const bool in = prob > prm.min_probability;
+                w.ic1[i] = in ? 1 : 0;
+                count += in ? 1 : 0;
+            }
+            for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+            if ((double)count >= (double)prm.min_cluster_size) {
+                for (int i = lane; i < N; i += WV)
+                    if (w.ic1[i]) member[b + i] |= (uint16_t)(1u << emitted);
+                ++emitted;
+            }
+        }
+        if (lane == 0) n_clusters[p] = emitted;
+    }
+    if (lane == 0) {
+        status[p] = w.fail;
+        atomicAdd(iters, (unsigned long long)w.iters);
+    }
+}
+
 template <typename T>
 struct DBuf {
     T* p = nullptr;
@@ -588,9 +919,15 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         MPE_HIP(hipMemcpy(d_tyo.p, to_yo, n_mp * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     MPE_HIP(hipMemset(d_iters.p, 0, sizeof(unsigned long long)));
-    hipEvent_t e0, e1;
+    hipEvent_t e0, e1, e2;
     MPE_HIP(hipEventCreate(&e0));
     MPE_HIP(hipEventCreate(&e1));
+    MPE_HIP(hipEventCreate(&e2));
+    hipStream_t s_wave;
+    MPE_HIP(hipStreamCreateWithFlags(&s_wave, hipStreamNonBlocking));
+    // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none)
+    int64_t wave_min = 40;
+    if (const char* e = getenv("DEFUSE_MPE_WAVE_MIN")) wave_min = atoll(e);
 
     // problems are taken in chunks whose fit workspaces (one per problem and K) fit the budget
     size_t budget = (size_t)8 << 30;
@@ -635,14 +972,33 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         MPE_HIP(hipMemcpy(d_wd.p, wd.data(), wd.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         MPE_HIP(hipMemcpy(d_wi.p, wi.data(), wi.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         MPE_HIP(hipMemcpy(d_order.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        MPE_HIP(hipEventRecord(e0));
-        const int64_t n_fit = (int64_t)n_chunk * MPE_KMAX;
-        hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_chunk, d_order.p, d_x.p,
-                           d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
-        hipLaunchKernelGGL(k_mpe_final, dim3((unsigned)((n_chunk + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_chunk, d_x.p, d_y.p,
-                           d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p, d_member.p,
-                           d_status.p, d_iters.p);
-        MPE_HIP(hipEventRecord(e1));
+        // the largest problems get a wave per fit, the rest a lane per fit; the two groups are independent and
+        // run side by side on two streams
+        int n_large = 0;
+        while (n_large < n_chunk && prob_off[p0 + order[n_large] + 1] - prob_off[p0 + order[n_large]] >= wave_min) ++n_large;
+        const int n_small = n_chunk - n_large;
+        t.n_wave_problems += n_large;
+        MPE_HIP(hipEventRecord(e0, 0));
+        MPE_HIP(hipStreamWaitEvent(s_wave, e0, 0));
+        if (n_large) {
+            hipLaunchKernelGGL(k_mpe_fit_wave, dim3((unsigned)n_large * MPE_KMAX), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p,
+                               d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
+            hipLaunchKernelGGL(k_mpe_final_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
+                               d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p,
+                               d_member.p, d_status.p, d_iters.p);
+        }
+        if (n_small) {
+            const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
+            hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_large, n_small,
+                               d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p,
+                               d_iters.p);
+            hipLaunchKernelGGL(k_mpe_final, dim3((unsigned)((n_small + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_large, n_small,
+                               d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p,
+                               d_nc.p, d_member.p, d_status.p, d_iters.p);
+        }
+        MPE_HIP(hipEventRecord(e2, s_wave));
+        MPE_HIP(hipStreamWaitEvent(0, e2, 0));
+        MPE_HIP(hipEventRecord(e1, 0));
         MPE_HIP(hipDeviceSynchronize());
         MPE_HIP(hipGetLastError());
         float ms = 0;
@@ -657,6 +1013,8 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    (void)hipStreamDestroy(s_wave);
     t.em_iterations = (int64_t)it;
     for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;
     if (timing) *timing = t;

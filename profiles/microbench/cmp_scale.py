@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--fragments", type=int, default=5_000_000)
     ap.add_argument("--out", default="gpurun_out/cmp_scale")
     ap.add_argument("--generate-only", action="store_true")
+    ap.add_argument("--compare-lane", action="store_true", help="run again with a lane per fit for every problem and compare the cluster files")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     span = os.path.join(args.out, "spanning.txt")
@@ -90,6 +91,16 @@ def main():
     res["clustermatepairs_stdout_tail"] = r.stdout.strip().splitlines()[-1:] if r.stdout.strip() else []
     res["clustermatepairs_timing"] = r.stderr.strip().splitlines()[-3:]
     res["fragments_per_s"] = round(n_frag / max(res["clustermatepairs_s"], 1e-9))
+    if r.returncode == 0 and args.compare_lane:
+        cl2 = cl + ".lane"
+        t0 = time.time()
+        r2 = subprocess.run([ROOT + "/bin/clustermatepairs", "-a", span, "-c", cl2, "-u", "300", "-s", "30", "-p", "0.95", "-m", "5"],
+                            capture_output=True, text=True, env=dict(env, DEFUSE_MPE_WAVE_MIN="1000000000"))
+        res["lane_only_s"] = round(time.time() - t0, 2)
+        res["lane_only_timing"] = r2.stderr.strip().splitlines()[-1:]
+        res["lane_only_identical"] = r2.returncode == 0 and subprocess.run(["cmp", "-s", cl, cl2]).returncode == 0
+        if os.path.exists(cl2):
+            os.remove(cl2)
     if r.returncode == 0:
         t0 = time.time()
         r = subprocess.run([ROOT + "/bin/setcover", "-c", cl, "-m", "5", "-o", sc], capture_output=True, text=True, env=env)
