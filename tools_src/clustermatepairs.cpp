@@ -5,6 +5,7 @@
 // all bin pairs runs on the GPU in one batch through include/defuse_mpe.h (no CPU fallback).
 // Iteration orders the reference leaves to boost::unordered_map are the canonical ascending-key
 // orders of SURVEY.md 8(c).
+#include <chrono>
 #include <numeric>
 
 #include "../include/defuse_dsa.h"
@@ -20,13 +21,8 @@ struct AlignmentPacked { int fragmentIndex, readEnd; unsigned short relativeStar
 
 const int binLength = 1 << 15;
 
-// Binning::GetBins (tools/clustermatepairs.cpp:152-162): C++ int division
-void GetBins(const Region& region, int length, int extend, std::vector<int>& bins)
-{
-    const int startBin = (region.start - extend) / length, endBin = (region.end + extend) / length;
-    for (int b = startBin; b <= endBin; ++b) bins.push_back(b);
-}
-
+// Binning::GetBins (tools/clustermatepairs.cpp:152-162) appears inline below as
+//   startBin = (region.start - extend) / length, endBin = (region.end + extend) / length      (C++ int division)
 unsigned pack_ref_bin(int ref, int strand, int bin)   // RefBinPacked (:28-65)
 {
     if (ref >= (1 << 18)) { std::cout << ref << std::endl << (1 << 18) << std::endl; die("Packing failed, too many reference sequences"); }
@@ -86,27 +82,114 @@ struct Problem {
     std::vector<std::pair<int, int>> alignPairs;
 };
 
-typedef std::map<int, std::vector<int>> IntegerVecMap;   // canonical: ascending fragment index
+// the alignments of one side of a bin pair grouped by fragment: `idx` holds alignment indices, fragments ascending
+// (canonical order), indices ascending inside a fragment; group g owns idx[off[g] .. off[g+1])
+struct FragmentGroups {
+    std::vector<int> frag, off, idx;
+    size_t size() const { return frag.size(); }
+};
 
-void FilterOverlapping(IntegerVecMap& fragments, const std::vector<CompactAlignment>& alignments, int minFusionRange)   // :316-358
+void GroupByFragment(const std::vector<CompactAlignment>& alignments, FragmentGroups& g)   // GetFragmentAlignments :292-300
 {
-    for (auto& kv : fragments) {
-        std::set<std::pair<unsigned, int>> bins[2];
-        std::vector<int> filtered;
-        for (int idx : kv.second) {
-            const CompactAlignment& a = alignments[idx];
-            std::vector<int> rangeBins;
-            GetBins(a.region, minFusionRange, 0, rangeBins);
+    g.frag.clear(); g.off.clear(); g.idx.resize(alignments.size());
+    std::iota(g.idx.begin(), g.idx.end(), 0);
+    std::stable_sort(g.idx.begin(), g.idx.end(), [&](int a, int b) { return alignments[a].fragmentIndex < alignments[b].fragmentIndex; });
+    for (size_t k = 0; k < g.idx.size(); ++k)
+        if (k == 0 || alignments[g.idx[k]].fragmentIndex != alignments[g.idx[k - 1]].fragmentIndex) {
+            g.frag.push_back(alignments[g.idx[k]].fragmentIndex);
+            g.off.push_back((int)k);
+        }
+    g.off.push_back((int)g.idx.size());
+}
+
+// FilterUnmatched (:302-314) then FilterOverlapping (:316-358) on one side: fragments absent from the other side go,
+// and per fragment an alignment is kept only if none of its minFusionRange bins was taken by an earlier one of the
+// same read end and (reference, strand)
+void FilterSide(FragmentGroups& g, const FragmentGroups& other, const std::vector<CompactAlignment>& alignments, int minFusionRange)
+{
+    FragmentGroups out;
+    out.idx.reserve(g.idx.size());
+    std::vector<std::pair<unsigned, int>> taken[2];
+    size_t o = 0;
+    for (size_t f = 0; f < g.size(); ++f) {
+        while (o < other.size() && other.frag[o] < g.frag[f]) ++o;
+        if (o == other.size() || other.frag[o] != g.frag[f]) continue;
+        out.frag.push_back(g.frag[f]);
+        out.off.push_back((int)out.idx.size());
+        taken[0].clear(); taken[1].clear();
+        for (int k = g.off[f]; k < g.off[f + 1]; ++k) {
+            const CompactAlignment& a = alignments[g.idx[k]];
+            const int startBin = a.region.start / minFusionRange, endBin = a.region.end / minFusionRange;   // GetBins, extend 0
             const unsigned refStrandId = (unsigned)a.referenceIndex | ((unsigned)a.strand << 31);
+            std::vector<std::pair<unsigned, int>>& t = taken[a.readEnd];
             bool overlapping = false;
-            for (int b : rangeBins) overlapping |= bins[a.readEnd].count(std::make_pair(refStrandId, b)) != 0;
+            for (int b = startBin; b <= endBin && !overlapping; ++b)
+                overlapping = std::find(t.begin(), t.end(), std::make_pair(refStrandId, b)) != t.end();
             if (!overlapping) {
-                for (int b : rangeBins) bins[a.readEnd].insert(std::make_pair(refStrandId, b));
-                filtered.push_back(idx);
+                for (int b = startBin; b <= endBin; ++b) t.push_back(std::make_pair(refStrandId, b));
+                out.idx.push_back(g.idx[k]);
             }
         }
-        kv.second.swap(filtered);
     }
+    out.off.push_back((int)out.idx.size());
+    g = std::move(out);
+}
+
+// lines of the alignment file without a std::string per line: blocks of 4 MiB, a line is [ptr, ptr + len)
+class LineReader {
+public:
+    explicit LineReader(FILE* f) : f_(f), buf_(1 << 22) {}
+    bool next(const char*& ptr, size_t& len)
+    {
+        for (;;) {
+            const char* nl = (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+            if (nl) {
+                ptr = buf_.data() + pos_;
+                len = (size_t)(nl - ptr);
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                return true;
+            }
+            if (eof_) {
+                if (pos_ == end_) return false;
+                ptr = buf_.data() + pos_;          // last line without a newline, as std::getline returns it
+                len = end_ - pos_;
+                pos_ = end_;
+                return true;
+            }
+            if (pos_ > 0) {
+                memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+                end_ -= pos_;
+                pos_ = 0;
+            }
+            if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+            const size_t got = fread(buf_.data() + end_, 1, buf_.size() - end_, f_);
+            end_ += got;
+            if (got == 0) eof_ = true;
+        }
+    }
+private:
+    FILE* f_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+};
+
+// boost::lexical_cast<int> on a field (tools/AlignmentStream.cpp:170-186): optional sign, digits only, int range
+bool field_int(const char* p, size_t n, int& out)
+{
+    if (n == 0) return false;
+    size_t k = (p[0] == '+' || p[0] == '-') ? 1 : 0;
+    if (k == n) return false;
+    long long v = 0;
+    for (; k < n; ++k) {
+        if (p[k] < '0' || p[k] > '9') return false;
+        v = v * 10 + (p[k] - '0');
+        if (v > 2147483648LL) return false;
+    }
+    if (p[0] == '-') v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
+    out = (int)v;
+    return true;
 }
 
 }  // namespace
@@ -125,86 +208,129 @@ int main(int argc, char* argv[])
     const int minClusterSize = cmd.integer("minclustersize");
     const int minFusionRange = (int)(fragmentMean + 10 * fragmentStdDev);
 
+    const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_stage = now();
+    auto stage = [&](const char* name) {
+        const double t = now();
+        if (timing) std::cerr << "[clustermatepairs] " << name << " " << (t - t_stage) << " s" << std::endl;
+        t_stage = t;
+    };
     std::cout << "Finding pairs of reference sequences connected by pairs of alignments" << std::endl;
-    std::ifstream file;
-    std::istream* in = &std::cin;
+    FILE* in = stdin;
     if (cmd.str("align") != "-") {
-        file.open(cmd.str("align").c_str());
-        if (!file.good()) die("Error: Unable to open alignment file " + cmd.str("align"));
-        in = &file;
+        in = fopen(cmd.str("align").c_str(), "rb");
+        if (!in) die("Error: Unable to open alignment file " + cmd.str("align"));
     }
     std::vector<std::string> refNames;
     std::unordered_map<std::string, int> refIndex;
     typedef std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>> PackedPair;
-    std::map<std::pair<unsigned, unsigned>, PackedPair> binPairs;   // canonical: ascending (first.id, second.id)
+    // bin pairs by (first.id, second.id): hashed while reading, visited in ascending key order afterwards (canonical)
+    std::unordered_map<uint64_t, uint32_t> binPairIndex;
+    std::vector<uint64_t> binPairKey;
+    std::vector<PackedPair> binPairStore;
+    auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
+        const uint64_t key = ((uint64_t)lo << 32) | hi;
+        auto it = binPairIndex.find(key);
+        if (it == binPairIndex.end()) {
+            it = binPairIndex.emplace(key, (uint32_t)binPairStore.size()).first;
+            binPairKey.push_back(key);
+            binPairStore.emplace_back();
+        }
+        return binPairStore[it->second];
+    };
 
+    std::vector<std::pair<int, int>> conc[2];
+    std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
     auto process_fragment = [&](const std::vector<CompactAlignment>& alignments) {
-        // CheckConcordant (:211-244)
-        std::set<std::pair<int, int>> conc[2];
+        // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
+        conc[0].clear(); conc[1].clear();
         for (const CompactAlignment& a : alignments) {
-            std::vector<int> bins;
-            GetBins(a.region, minFusionRange, minFusionRange, bins);
-            for (int b : bins) conc[a.readEnd].insert(std::make_pair(a.referenceIndex, b));
+            const int startBin = (a.region.start - minFusionRange) / minFusionRange, endBin = (a.region.end + minFusionRange) / minFusionRange;
+            for (int b = startBin; b <= endBin; ++b) conc[a.readEnd].push_back(std::make_pair(a.referenceIndex, b));
         }
         for (const auto& rb : conc[0])
-            if (conc[1].count(rb)) return;
-        // AddBinPairs (:246-290)
-        std::map<unsigned, std::vector<AlignmentPacked>> binned[2];
+            if (std::find(conc[1].begin(), conc[1].end(), rb) != conc[1].end()) return;
+        // AddBinPairs (:246-290): per read end the packed alignments by bin id ascending, arrival order inside a bin
+        binned[0].clear(); binned[1].clear();
         for (const CompactAlignment& a : alignments) {
-            std::vector<int> bins;
-            GetBins(a.region, binLength, minFusionRange, bins);
-            for (int b : bins) {
+            const int startBin = (a.region.start - minFusionRange) / binLength, endBin = (a.region.end + minFusionRange) / binLength;
+            for (int b = startBin; b <= endBin; ++b) {
                 const int rs = a.region.start - b * binLength + binLength / 2, re = a.region.end - b * binLength + binLength / 2;
                 if (rs < 0 || re < 0 || rs >= (1 << 16) || re >= (1 << 16)) die("Error: relativeStart >= 0 failed (alignment does not fit its bin)");
-                binned[a.readEnd][pack_ref_bin(a.referenceIndex, a.strand, b)].push_back(
-                    AlignmentPacked{a.fragmentIndex, a.readEnd, (unsigned short)rs, (unsigned short)re});
+                binned[a.readEnd].push_back(std::make_pair(pack_ref_bin(a.referenceIndex, a.strand, b),
+                                                           AlignmentPacked{a.fragmentIndex, a.readEnd, (unsigned short)rs, (unsigned short)re}));
             }
         }
-        for (const auto& b1 : binned[0])
-            for (const auto& b2 : binned[1]) {
-                if (b1.first < b2.first) {
-                    PackedPair& e = binPairs[std::make_pair(b1.first, b2.first)];
-                    e.first.insert(e.first.end(), b1.second.begin(), b1.second.end());
-                    e.second.insert(e.second.end(), b2.second.begin(), b2.second.end());
-                } else {
-                    PackedPair& e = binPairs[std::make_pair(b2.first, b1.first)];
-                    e.first.insert(e.first.end(), b2.second.begin(), b2.second.end());
-                    e.second.insert(e.second.end(), b1.second.begin(), b1.second.end());
-                }
+        for (int e = 0; e < 2; ++e)
+            std::stable_sort(binned[e].begin(), binned[e].end(), [](const std::pair<unsigned, AlignmentPacked>& x,
+                                                                    const std::pair<unsigned, AlignmentPacked>& y) { return x.first < y.first; });
+        for (size_t i0 = 0; i0 < binned[0].size();) {
+            size_t i1 = i0;
+            while (i1 < binned[0].size() && binned[0][i1].first == binned[0][i0].first) ++i1;
+            for (size_t j0 = 0; j0 < binned[1].size();) {
+                size_t j1 = j0;
+                while (j1 < binned[1].size() && binned[1][j1].first == binned[1][j0].first) ++j1;
+                const unsigned id1 = binned[0][i0].first, id2 = binned[1][j0].first;
+                const bool fwd = id1 < id2;
+                PackedPair& e = fwd ? bin_pair(id1, id2) : bin_pair(id2, id1);
+                std::vector<AlignmentPacked>& d1 = fwd ? e.first : e.second;
+                std::vector<AlignmentPacked>& d2 = fwd ? e.second : e.first;
+                for (size_t k = i0; k < i1; ++k) d1.push_back(binned[0][k].second);
+                for (size_t k = j0; k < j1; ++k) d2.push_back(binned[1][k].second);
+                j0 = j1;
             }
+            i0 = i1;
+        }
     };
 
     {   // CompactAlignmentStream + FragmentAlignmentStream (tools/AlignmentStream.cpp:156-221)
-        std::string line, curName;
+        LineReader reader(in);
+        const char* line;
+        size_t len;
+        std::string curName, refKey;
         std::vector<CompactAlignment> cur;
         int lineNumber = 0;
-        while (std::getline(*in, line)) {
+        while (reader.next(line, len)) {
             ++lineNumber;
-            if (line.empty()) die("Error: Empty alignment line " + std::to_string(lineNumber));
-            std::vector<std::string> f = split_tabs(line);
-            if (f.size() < 6) die("Error: Format error for alignment line " + std::to_string(lineNumber));
-            if (!cur.empty() && f[0] != curName) {
+            if (len == 0) die("Error: Empty alignment line " + std::to_string(lineNumber));
+            const char* fs[7];
+            int nf = 0;
+            fs[nf++] = line;
+            for (const char* p = line; nf < 7;) {
+                const char* tab = (const char*)memchr(p, '\t', (size_t)(line + len - p));
+                if (!tab) break;
+                fs[nf++] = p = tab + 1;
+            }
+            if (nf < 6) die("Error: Format error for alignment line " + std::to_string(lineNumber));
+            if (nf < 7) fs[6] = line + len + 1;                      // field k is [fs[k], fs[k+1] - 1)
+            auto flen = [&](int k) { return (size_t)(fs[k + 1] - 1 - fs[k]); };
+            if (!cur.empty() && (flen(0) != curName.size() || memcmp(fs[0], curName.data(), curName.size()) != 0)) {
                 process_fragment(cur);
                 cur.clear();
             }
-            curName = f[0];
+            if (cur.empty()) curName.assign(fs[0], flen(0));
             CompactAlignment a;
-            a.fragmentIndex = lexical_int_or_die(f[0], "as fragment name on line " + std::to_string(lineNumber));
-            a.readEnd = (f[1] == "1") ? 0 : 1;
-            auto ri = refIndex.find(f[2]);
+            if (!field_int(fs[0], flen(0), a.fragmentIndex))
+                die("Error: bad integer '" + std::string(fs[0], flen(0)) + "' as fragment name on line " + std::to_string(lineNumber));
+            a.readEnd = (flen(1) == 1 && fs[1][0] == '1') ? 0 : 1;
+            refKey.assign(fs[2], flen(2));
+            auto ri = refIndex.find(refKey);
             if (ri == refIndex.end()) {
-                ri = refIndex.emplace(f[2], (int)refNames.size()).first;
-                refNames.push_back(f[2]);
+                ri = refIndex.emplace(refKey, (int)refNames.size()).first;
+                refNames.push_back(refKey);
             }
             a.referenceIndex = ri->second;
-            a.strand = (f[3] == "-") ? MinusStrand : PlusStrand;
-            a.region.start = lexical_int_or_die(f[4], "on line " + std::to_string(lineNumber));
-            a.region.end = lexical_int_or_die(f[5], "on line " + std::to_string(lineNumber));
+            a.strand = (flen(3) == 1 && fs[3][0] == '-') ? MinusStrand : PlusStrand;
+            if (!field_int(fs[4], flen(4), a.region.start) || !field_int(fs[5], flen(5), a.region.end))
+                die("Error: bad integer '" + std::string(fs[4], (size_t)(line + len - fs[4])) + "' on line " + std::to_string(lineNumber));
             cur.push_back(a);
         }
         if (!cur.empty()) process_fragment(cur);
+        if (in != stdin) fclose(in);
     }
 
+    stage("read + bin pairs");
     std::cout << "Initializing clusterer" << std::endl;
     mpe_params prm{};
     prm.fragment_mean = fragmentMean;
@@ -224,8 +350,12 @@ int main(int argc, char* argv[])
     std::vector<int64_t> probOff(1, 0);
     std::vector<double> X, Y, U;
     std::vector<int32_t> toXO, toYO;
-    for (const auto& bp : binPairs) {
-        const PackedPair& pp = bp.second;
+    std::vector<uint32_t> bpOrder(binPairKey.size());
+    std::iota(bpOrder.begin(), bpOrder.end(), 0u);
+    std::sort(bpOrder.begin(), bpOrder.end(), [&](uint32_t a, uint32_t b) { return binPairKey[a] < binPairKey[b]; });
+    FragmentGroups fr1, fr2, fr2all;
+    for (uint32_t bpi : bpOrder) {
+        const PackedPair& pp = binPairStore[bpi];
         if ((int)pp.first.size() < minClusterSize || (int)pp.second.size() < minClusterSize) continue;
         Problem prob;
         auto unpack = [&](unsigned id, const std::vector<AlignmentPacked>& packed, std::vector<CompactAlignment>& al) {
@@ -240,21 +370,19 @@ int main(int argc, char* argv[])
                 al[k].region.end = packed[k].relativeEnd + bin * binLength - binLength / 2;
             }
         };
-        unpack(bp.first.first, pp.first, prob.alignments1);
-        unpack(bp.first.second, pp.second, prob.alignments2);
-        IntegerVecMap fr1, fr2;
-        for (size_t k = 0; k < prob.alignments1.size(); ++k) fr1[prob.alignments1[k].fragmentIndex].push_back((int)k);
-        for (size_t k = 0; k < prob.alignments2.size(); ++k) fr2[prob.alignments2[k].fragmentIndex].push_back((int)k);
-        for (auto it = fr2.begin(); it != fr2.end();) it = fr1.count(it->first) ? std::next(it) : fr2.erase(it);   // FilterUnmatched
-        for (auto it = fr1.begin(); it != fr1.end();) it = fr2.count(it->first) ? std::next(it) : fr1.erase(it);
-        FilterOverlapping(fr1, prob.alignments1, minFusionRange);
-        FilterOverlapping(fr2, prob.alignments2, minFusionRange);
+        unpack((unsigned)(binPairKey[bpi] >> 32), pp.first, prob.alignments1);
+        unpack((unsigned)(binPairKey[bpi] & 0xFFFFFFFFu), pp.second, prob.alignments2);
+        GroupByFragment(prob.alignments1, fr1);
+        GroupByFragment(prob.alignments2, fr2);
+        fr2all = fr2;
+        FilterSide(fr2, fr1, prob.alignments2, minFusionRange);      // FilterUnmatched: only the fragment sets matter
+        FilterSide(fr1, fr2all, prob.alignments1, minFusionRange);
         if ((int)fr1.size() < minClusterSize || (int)fr2.size() < minClusterSize) continue;
-        std::set<std::pair<int, int>> seen;                           // PairIndex: first-seen order
-        for (const auto& kv : fr1)
-            for (int i1 : kv.second)
-                for (int i2 : fr2[kv.first])
-                    if (seen.insert(std::make_pair(i1, i2)).second) prob.alignPairs.push_back(std::make_pair(i1, i2));
+        // GetAlignPairs (:360-375): per fragment the cartesian product; an alignment index belongs to one fragment,
+        // so no pair can come twice
+        for (size_t f = 0; f < fr1.size(); ++f)
+            for (int k1 = fr1.off[f]; k1 < fr1.off[f + 1]; ++k1)
+                for (int k2 = fr2.off[f]; k2 < fr2.off[f + 1]; ++k2) prob.alignPairs.push_back(std::make_pair(fr1.idx[k1], fr2.idx[k2]));
         const size_t n = prob.alignPairs.size(), base = X.size();
         for (size_t k = 0; k < n; ++k) {
             const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
@@ -277,8 +405,24 @@ int main(int argc, char* argv[])
         probOff.push_back((int64_t)X.size());
         problems.push_back(std::move(prob));
     }
-    binPairs.clear();
+    binPairStore.clear();
+    binPairStore.shrink_to_fit();
 
+    stage("problems");
+    if (const char* dump = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS")) {      // regression aid: the host stages' result, no GPU needed
+        std::ofstream d(dump, std::ios::binary);
+        auto put = [&](const void* p, size_t n) { d.write((const char*)p, (std::streamsize)n); };
+        put(probOff.data(), probOff.size() * sizeof(int64_t));
+        put(X.data(), X.size() * sizeof(double)); put(Y.data(), Y.size() * sizeof(double)); put(U.data(), U.size() * sizeof(double));
+        put(toXO.data(), toXO.size() * sizeof(int32_t)); put(toYO.data(), toYO.size() * sizeof(int32_t));
+        for (const Problem& pr : problems) {
+            put(pr.alignments1.data(), pr.alignments1.size() * sizeof(CompactAlignment));
+            put(pr.alignments2.data(), pr.alignments2.size() * sizeof(CompactAlignment));
+            put(pr.alignPairs.data(), pr.alignPairs.size() * sizeof(std::pair<int, int>));
+        }
+        for (const std::string& r : refNames) d << r << "\n";
+        return 0;
+    }
     std::vector<int32_t> nClusters(problems.size(), 0), status(problems.size(), 0);
     std::vector<uint16_t> member(X.size(), 0);
     if (!problems.empty()) {
@@ -293,28 +437,43 @@ int main(int argc, char* argv[])
             if (status[p]) die("Error: a consistency check of the mate pair clusterer failed (DebugCheck in the reference)");
     }
 
+    stage("clustering");
     // output (:549-583): per emitted cluster one alignment pair per distinct fragment, in mate pair order
     int clusterID = 0;
+    std::string buf;
+    buf.reserve((1u << 22) + 4096);
+    std::vector<int> usedFragments;
+    auto put_int = [&](long long v) {
+        char tmp[24];
+        const int n = snprintf(tmp, sizeof tmp, "%lld", v);
+        buf.append(tmp, (size_t)n);
+    };
     for (size_t p = 0; p < problems.size(); ++p) {
         const Problem& prob = problems[p];
         const int64_t base = probOff[p];
         for (int j = 0; j < nClusters[p]; ++j) {
-            std::set<int> usedFragments;
+            usedFragments.clear();
             for (size_t k = 0; k < prob.alignPairs.size(); ++k) {
                 if (!((member[base + k] >> j) & 1)) continue;
                 const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
                 const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
-                if (!usedFragments.insert(a1.fragmentIndex).second) continue;
+                // mate pairs are listed fragment by fragment, so a fragment seen before is the last one used
+                if (!usedFragments.empty() && usedFragments.back() == a1.fragmentIndex) continue;
+                usedFragments.push_back(a1.fragmentIndex);
                 for (int ce = 0; ce <= 1; ++ce) {
                     const CompactAlignment& a = ce ? a2 : a1;
-                    out << clusterID << "\t" << ce << "\t" << a.fragmentIndex << "\t" << a.readEnd << "\t" << refNames[a.referenceIndex]
-                        << "\t" << (a.strand == PlusStrand ? "+" : "-") << "\t" << a.region.start << "\t" << a.region.end << std::endl;
+                    put_int(clusterID); buf += '\t'; put_int(ce); buf += '\t'; put_int(a.fragmentIndex); buf += '\t'; put_int(a.readEnd);
+                    buf += '\t'; buf += refNames[a.referenceIndex]; buf += '\t'; buf += (a.strand == PlusStrand ? '+' : '-'); buf += '\t';
+                    put_int(a.region.start); buf += '\t'; put_int(a.region.end); buf += '\n';
                 }
+                if (buf.size() > (1u << 22)) { out.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
             }
             ++clusterID;
         }
     }
+    out.write(buf.data(), (std::streamsize)buf.size());
     out.close();
+    stage("output");
     std::cout << "Created " << clusterID << " clusters" << std::endl;
     return 0;
 }
