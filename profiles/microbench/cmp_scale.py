@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--fragments", type=int, default=5_000_000)
     ap.add_argument("--out", default="gpurun_out/cmp_scale")
     ap.add_argument("--generate-only", action="store_true")
+    ap.add_argument("--keep", action="store_true", help="leave the input and output files in --out")
     ap.add_argument("--compare-lane", action="store_true", help="run again with a lane per fit for every problem and compare the cluster files")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -110,7 +111,7 @@ def main():
         res["cluster_lines"] = sum(1 for _ in open(cl))
         res["cover_lines"] = sum(1 for _ in open(sc)) if os.path.exists(sc) else None
     for f in (span, cl, sc):                      # large scratch files do not travel back
-        if os.path.exists(f):
+        if os.path.exists(f) and not args.keep:
             os.remove(f)
     print(json.dumps(res), flush=True)
 

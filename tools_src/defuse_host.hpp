@@ -73,6 +73,74 @@ inline int lexical_int_or_die(const std::string& s, const std::string& context)
     return v;
 }
 
+// lines of a text file without a std::string per line: blocks of 4 MiB, a line is [ptr, ptr + len)
+class LineReader {
+public:
+    explicit LineReader(FILE* f) : f_(f), buf_(1 << 22) {}
+    bool next(const char*& ptr, size_t& len)
+    {
+        for (;;) {
+            const char* nl = (const char*)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+            if (nl) {
+                ptr = buf_.data() + pos_;
+                len = (size_t)(nl - ptr);
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                return true;
+            }
+            if (eof_) {
+                if (pos_ == end_) return false;
+                ptr = buf_.data() + pos_;          // last line without a newline, as std::getline returns it
+                len = end_ - pos_;
+                pos_ = end_;
+                return true;
+            }
+            if (pos_ > 0) {
+                memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+                end_ -= pos_;
+                pos_ = 0;
+            }
+            if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+            const size_t got = fread(buf_.data() + end_, 1, buf_.size() - end_, f_);
+            end_ += got;
+            if (got == 0) eof_ = true;
+        }
+    }
+private:
+    FILE* f_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+};
+
+// boost::lexical_cast<int> on a field (tools/AlignmentStream.cpp:170-186): optional sign, digits only, int range
+inline bool field_int(const char* p, size_t n, int& out)
+{
+    if (n == 0) return false;
+    size_t k = (p[0] == '+' || p[0] == '-') ? 1 : 0;
+    if (k == n) return false;
+    long long v = 0;
+    for (; k < n; ++k) {
+        if (p[k] < '0' || p[k] > '9') return false;
+        v = v * 10 + (p[k] - '0');
+        if (v > 2147483648LL) return false;
+    }
+    if (p[0] == '-') v = -v;
+    if (v > 2147483647LL || v < -2147483648LL) return false;
+    out = (int)v;
+    return true;
+}
+
+// decimal text of an integer appended to a buffer (what operator<< prints for an int)
+inline void append_int(std::string& buf, long long v)
+{
+    char tmp[24];
+    char* p = tmp + sizeof tmp;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *--p = '-';
+    buf.append(p, (size_t)(tmp + sizeof tmp - p));
+}
+
 // tools/Common.cpp:32-54
 inline void ReverseComplement(std::string& seq)
 {

@@ -12,16 +12,21 @@ namespace {
 
 struct ClusterLine { int clusterID, clusterEnd, fragmentIndex; };
 
-bool parse_cluster_line(const std::string& line, int lineNumber, const std::string& filename, ClusterLine& out)
+// ClusterMembership line (tools/Parsers.cpp:36-78): at least three tab-separated fields, the first three integers
+void parse_cluster_line(const char* line, size_t len, int lineNumber, const std::string& filename, ClusterLine& out)
 {
-    if (line.empty()) die("Error: Empty clusters line " + std::to_string(lineNumber) + " of " + filename);
-    std::vector<std::string> f = split_tabs(line);
-    if (f.size() < 3) die("Error: Format error for clusters line " + std::to_string(lineNumber) + " of " + filename);
-    if (!lexical_int(f[0], out.clusterID) || !lexical_int(f[1], out.clusterEnd) || !lexical_int(f[2], out.fragmentIndex)) {
-        std::cerr << "Failed to interpret line:" << std::endl << line << std::endl;
+    if (len == 0) die("Error: Empty clusters line " + std::to_string(lineNumber) + " of " + filename);
+    const char* end = line + len;
+    const char* t1 = (const char*)memchr(line, '\t', len);
+    const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(end - t1 - 1)) : nullptr;
+    if (!t2) die("Error: Format error for clusters line " + std::to_string(lineNumber) + " of " + filename);
+    const char* t3 = (const char*)memchr(t2 + 1, '\t', (size_t)(end - t2 - 1));
+    if (!t3) t3 = end;
+    if (!field_int(line, (size_t)(t1 - line), out.clusterID) || !field_int(t1 + 1, (size_t)(t2 - t1 - 1), out.clusterEnd) ||
+        !field_int(t2 + 1, (size_t)(t3 - t2 - 1), out.fragmentIndex)) {
+        std::cerr << "Failed to interpret line:" << std::endl << std::string(line, len) << std::endl;
         std::exit(1);
     }
-    return true;
 }
 
 }  // namespace
@@ -40,18 +45,21 @@ int main(int argc, char* argv[])
     // ReadClusters (tools/Parsers.cpp:23-84): cluster-end-0 lines only, clusters[id] in file order
     std::vector<std::vector<int>> clusters;
     {
-        std::ifstream in(inName.c_str());
+        FILE* in = fopen(inName.c_str(), "rb");
         if (!in) die("Error: unable to read from clusters file " + inName);
-        std::string line;
+        LineReader reader(in);
+        const char* line;
+        size_t len;
         int lineNumber = 0;
         ClusterLine cl;
-        while (std::getline(in, line)) {
-            parse_cluster_line(line, ++lineNumber, inName, cl);
+        while (reader.next(line, len)) {
+            parse_cluster_line(line, len, ++lineNumber, inName, cl);
             if (cl.clusterEnd != 0) continue;
             if (cl.clusterID < 0) die("Error: Invalid cluster ID for line " + std::to_string(lineNumber) + " of " + inName);
             if ((int)clusters.size() < cl.clusterID + 1) clusters.resize(cl.clusterID + 1);
             clusters[cl.clusterID].push_back(cl.fragmentIndex);
         }
+        fclose(in);
     }
 
     std::cout << "Calculating set cover solution" << std::endl;
@@ -85,18 +93,28 @@ int main(int argc, char* argv[])
     // assigned to the line's cluster, for clusters that kept at least minClusterSize fragments
     std::ofstream out(outName.c_str());
     if (!out) die("Error: unable to write to clusters file " + outName);
-    std::ifstream in(inName.c_str());
+    FILE* in = fopen(inName.c_str(), "rb");
     if (!in) die("Error: unable to read from clusters file " + inName);
-    std::string line;
+    LineReader reader(in);
+    const char* line;
+    size_t len;
     int lineNumber = 0;
     ClusterLine cl;
-    while (std::getline(in, line)) {
-        parse_cluster_line(line, ++lineNumber, outName, cl);
+    std::string buf;
+    buf.reserve((1u << 22) + 4096);
+    while (reader.next(line, len)) {
+        parse_cluster_line(line, len, ++lineNumber, outName, cl);
         if (cl.clusterID < 0) die("Error: Invalid cluster ID for line " + std::to_string(lineNumber) + " of " + outName);
         if ((size_t)cl.clusterID >= clusters.size()) continue;            // an id that only occurs with end 1 (UB in the reference)
         if ((int64_t)solutionSize[cl.clusterID] < (int64_t)minClusterSize) continue;
-        if (cl.fragmentIndex >= 0 && cl.fragmentIndex <= maxElement && owner[cl.fragmentIndex] == cl.clusterID) out << line << std::endl;
+        if (cl.fragmentIndex >= 0 && cl.fragmentIndex <= maxElement && owner[cl.fragmentIndex] == cl.clusterID) {
+            buf.append(line, len);
+            buf += '\n';
+            if (buf.size() > (1u << 22)) { out.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
+        }
     }
+    out.write(buf.data(), (std::streamsize)buf.size());
+    fclose(in);
     out.close();
     return out.good() ? 0 : 1;
 }
