@@ -52,6 +52,9 @@ struct Work {
     double *SX, *SY;                // [N]
     double *CX, *CY, *CS;           // [4N+4]
     double *ka, *kd, *dist;         // kmns: a [2N], d [N]; KKZ: DistMin [N]
+    const double* XYU;              // wave version: X + Y + U per mate pair (constant over a fit)
+    const int* TX;                  // wave version: ToXO
+    int* XfromY;                    // wave version: rank in x order of the mate pair with rank s in y order
     int *ic1, *ic2;                 // [N]
     double W[MPE_KMAX], A[MPE_KMAX], B[MPE_KMAX];
     double sd;
@@ -439,20 +442,43 @@ struct WaveShared {
 };
 
 constexpr int WV = 64;
+#ifndef MPE_WPE
+#define MPE_WPE 5       // waves per SIMD the wave kernels are compiled for (profiles/microbench/mpe_occ.sh)
+#endif
+
+#ifdef MPE_PROFILE
+// phase cycle counters of the wave kernels (profiles/microbench/mpe_phase.sh): init, M step, E step, LL chain, R update;
+// [5..8] = cycles, N, K, iterations of the longest fit
+__device__ unsigned long long g_mpe_prof[16];
+#define MPE_T(var) const long long var = clock64()
+#define MPE_ADD(slot, t0, t1) do { if (lane == 0) atomicAdd(&g_mpe_prof[slot], (unsigned long long)((t1) - (t0))); } while (0)
+#else
+#define MPE_T(var)
+#define MPE_ADD(slot, t0, t1)
+#endif
 
 // MaxLikelihood (:192-325) for one component in one lane, streaming: the two prefix sums advance with the
 // walk (SX[i] = SX[i-1] + RXO[i]) and the first breakpoint with a positive derivative ends it, so neither the
 // prefix arrays nor the breakpoint list are stored.  nk receives the component's sum of responsibilities
 // (UpdateMixWeights :183-190 takes the same sum in the same order).  Return codes as max_likelihood.
-__device__ int max_likelihood_stream(const Work& w, const double* R, const double* RXO, const double* RYO, double& a, double& b,
-                                     double& nk)
+__device__ int max_likelihood_stream(const Work& w, const double* RXO, double& a, double& b, double& nk)
 {
     const int N = w.N;
+    const int* TX = w.TX;
+    const int* XfromY = w.XfromY;
     double NK = 0.0, RXYU = 0.0;
-    for (int t = 0; t < N; ++t) {
-        const double r = R[t];
+    int t = 0;
+    for (; t + 4 <= N; t += 4) {              // loads in batches so that only the additions are serial
+        double r[4], q[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { r[v] = RXO[TX[t + v]]; q[v] = w.XYU[t + v]; }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
+    }
+    for (; t < N; ++t) {
+        const double r = RXO[TX[t]];
         NK += r;
-        RXYU += r * (w.X[t] + w.Y[t] + w.U[t]);
+        RXYU += r * w.XYU[t];
     }
     nk = NK;
     if (NK == 0.0) return 0;
@@ -460,34 +486,53 @@ __device__ int max_likelihood_stream(const Work& w, const double* R, const doubl
     double pcx = 0.0, pcy = 0.0, pcs = 0.0, ccx = 0.0, ccy = 0.0, ccs = 0.0;
     int mi = 0;
     bool found = false;
+    // the sign of (RXYU - NK*(cx+cy))/var + LAMBDA*cs without the division wherever it is not in doubt: the product with
+    // the rounded reciprocal is within a few ulp of the quotient, so an estimate clear of zero by 1e-9 of its terms has the
+    // sign of the exact expression; otherwise the expression itself is evaluated
+    const double inv_var = 1.0 / var;
     auto push = [&](double cx, double cy, double cs) {
         if (found) return;
-        if ((RXYU - NK * (cx + cy)) / var + LAMBDA * cs > 0) { found = true; ccx = cx; ccy = cy; ccs = cs; }
+        const double q = RXYU - NK * (cx + cy), lc = LAMBDA * cs;
+        const double est = q * inv_var + lc;
+        bool pos;
+        if (fabs(est) > 1e-9 * (fabs(q * inv_var) + fabs(lc)) && fabs(est) > 1e-290 && fabs(est) < 1e290) pos = est > 0;
+        else pos = q / var + lc > 0;
+        if (pos) { found = true; ccx = cx; ccy = cy; ccs = cs; }
         else { pcx = cx; pcy = cy; pcs = cs; ++mi; }
     };
+    // the walk keeps XO[i], XO[i+1], RXO[i+1] (and the same for j) in registers: one load per advance, off the
+    // critical compare; every kind of step advances through the same code so that the lanes of a wave stay together
     int i = 0, j = 0;
-    double sx = RXO[0], sy = RYO[0];
-    push(w.XO[0], w.YO[0], 0.0);
+    double sx = RXO[0], sy = RXO[XfromY[0]];
+    double xi = w.XO[0], yj = w.YO[0];
+    double xn = 0.0, yn = 0.0, rxn = 0.0, ryn = 0.0;
+    if (N > 1) { xn = w.XO[1]; yn = w.YO[1]; rxn = RXO[1]; ryn = RXO[XfromY[1]]; }
+    push(xi, yj, 0.0);
     while (!found && i < N && j < N) {
-        if (i + 1 < N && w.XO[i] == w.XO[i + 1]) { ++i; sx = sx + RXO[i]; continue; }
-        if (j + 1 < N && w.YO[j] == w.YO[j + 1]) { ++j; sy = sy + RYO[j]; continue; }
-        if (sx == sy) {
-            push(w.XO[i], w.YO[j], sx);
-            if (i + 1 < N && j + 1 < N) push(w.XO[i + 1], w.YO[j + 1], sx);
+        const bool hi = i + 1 < N, hj = j + 1 < N;
+        bool adv_i, adv_j;
+        if (hi && xi == xn) { adv_i = true; adv_j = false; }
+        else if (hj && yj == yn) { adv_i = false; adv_j = true; }
+        else {
+            const bool eq = sx == sy, lt = sx < sy;
+            const double cs = (eq || lt) ? sx : sy;
+            push(xi, yj, cs);
+            const bool second = eq ? (hi && hj) : (lt ? hi : hj);
+            if (second) push((eq || lt) ? xn : xi, (eq || !lt) ? yn : yj, cs);
+            adv_i = eq || lt;
+            adv_j = eq || !lt;
+        }
+        if (adv_i) {
             ++i;
+            xi = xn;
+            if (i < N) sx = sx + rxn;
+            if (i + 1 < N) { xn = w.XO[i + 1]; rxn = RXO[i + 1]; }
+        }
+        if (adv_j) {
             ++j;
-            if (i < N) sx = sx + RXO[i];
-            if (j < N) sy = sy + RYO[j];
-        } else if (sx < sy) {
-            push(w.XO[i], w.YO[j], sx);
-            if (i + 1 < N) push(w.XO[i + 1], w.YO[j], sx);
-            ++i;
-            if (i < N) sx = sx + RXO[i];
-        } else {
-            push(w.XO[i], w.YO[j], sy);
-            if (j + 1 < N) push(w.XO[i], w.YO[j + 1], sy);
-            ++j;
-            if (j < N) sy = sy + RYO[j];
+            yj = yn;
+            if (j < N) sy = sy + ryn;
+            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO[XfromY[j + 1]]; }
         }
     }
     if (!found) return -1;
@@ -557,9 +602,10 @@ __device__ bool select_kkz_wave(Work& w, WaveShared& s, int k, int lane)   // :3
 __device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int lane, double& ll)
 {
     const int N = w.N;
+    MPE_T(t_init0);
     if (K == 1 || K == N) {
         const double v = 1.0 / K;
-        for (size_t t = lane; t < (size_t)K * N; t += WV) { w.R[t] = v; w.RXO[t] = v; w.RYO[t] = v; }
+        for (size_t t = lane; t < (size_t)K * N; t += WV) w.RXO[t] = v;
     } else {
         if (!select_kkz_wave(w, s, K, lane)) return false;
         for (int i = lane; i < N; i += WV) { w.ka[i] = w.Y[i]; w.ka[N + i] = w.X[i]; }
@@ -569,30 +615,30 @@ __device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int
         __syncthreads();
         if (s.ifault == 1 || s.ifault == 3) { w.fail = 1; return false; }
         for (int i = lane; i < N; i += WV) {
-            const int own = w.ic1[i] - 1, ixo = w.ToXO[i], iyo = w.ToYO[i];
-            for (int j = 0; j < K; ++j) {
-                const double v = (j == own) ? 1.0 : 0.0;
-                w.R[(size_t)j * N + i] = v;
-                w.RXO[(size_t)j * N + ixo] = v;
-                w.RYO[(size_t)j * N + iyo] = v;
-            }
+            const int own = w.ic1[i] - 1, ixo = w.TX[i];
+            for (int j = 0; j < K; ++j) w.RXO[(size_t)j * N + ixo] = (j == own) ? 1.0 : 0.0;
         }
     }
     __syncthreads();
+    MPE_T(t_init1);
+    MPE_ADD(0, t_init0, t_init1);
     double last = 0.0;
     bool valid = false;
     for (;;) {
         // M step: component j in lane j
+        MPE_T(t_m0);
         int rc = 0;
         if (lane < K) {
             double a = 0.0, b = 0.0, nk = 0.0;
-            rc = max_likelihood_stream(w, w.R + (size_t)lane * N, w.RXO + (size_t)lane * N, w.RYO + (size_t)lane * N, a, b, nk);
+            rc = max_likelihood_stream(w, w.RXO + (size_t)lane * N, a, b, nk);
             if (rc > 0) { s.A[lane] = a; s.B[lane] = b; }
             s.W[lane] = nk / N;
         }
         if (__any(rc < 0)) { w.fail = 1; return false; }
         if (lane == 0) s.flag = 0;
         __syncthreads();
+        MPE_T(t_m1);
+        MPE_ADD(1, t_m0, t_m1);
         // E step, elementwise part: exponents, exp, mixture sum, log.  EX keeps exp(EX - maxexp), kd the mixture
         // sum, SX / SY the two terms of the log-likelihood chain.
         bool zero = false;
@@ -616,14 +662,27 @@ __device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int
         }
         if (zero) s.flag = 1;
         __syncthreads();
+        MPE_T(t_e1);
+        MPE_ADD(2, t_m1, t_e1);
         if (lane == 0) {                       // LogLikelihood :96-137, the serial chain
             double LL = 0.0;
             if (s.flag) LL = -DBL_MAX_;
-            else
-                for (int i = 0; i < N; ++i) LL = LL + w.SX[i] + w.SY[i];
+            else {
+                int i = 0;
+                for (; i + 4 <= N; i += 4) {
+                    double l1[4], l2[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { l1[v] = w.SX[i + v]; l2[v] = w.SY[i + v]; }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) LL = LL + l1[v] + l2[v];
+                }
+                for (; i < N; ++i) LL = LL + w.SX[i] + w.SY[i];
+            }
             s.like = LL;
         }
         __syncthreads();
+        MPE_T(t_l1);
+        MPE_ADD(3, t_e1, t_l1);
         const double like = s.like;
         const bool any_zero = s.flag != 0;
         w.iters += 1;
@@ -634,22 +693,23 @@ __device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int
         valid = true;
         if (any_zero) { w.fail = 1; return false; }                              // DebugCheck(norm != 0.0), :172
         for (int i = lane; i < N; i += WV) {                                     // UpdateResponsibilities :139-181
-            const int ixo = w.ToXO[i], iyo = w.ToYO[i];
+            const int ixo = w.TX[i];
             const double norm = w.kd[i];
-            for (int j = 0; j < K; ++j) {
-                const double r = s.W[j] * w.EX[(size_t)j * N + i] / norm;
-                w.R[(size_t)j * N + i] = r;
-                w.RXO[(size_t)j * N + ixo] = r;
-                w.RYO[(size_t)j * N + iyo] = r;
-            }
+            for (int j = 0; j < K; ++j) w.RXO[(size_t)j * N + ixo] = s.W[j] * w.EX[(size_t)j * N + i] / norm;
         }
         __syncthreads();
+        MPE_T(t_r1);
+        MPE_ADD(4, t_l1, t_r1);
     }
     ll = last;
     return true;
 }
 
 // carve the workspace of a fit with up to K components and set up the sorted copies
+// The wave version keeps the responsibilities only in x order (R[t] = RXO[ToXO[t]], RYO[s] = RXO[XfromY[s]]) and its
+// arrays in the global workspace.  Keeping them in LDS was tried (profiles/microbench/mpe_share.sh): a fit's chains get
+// about three times faster, but 160 KiB per CU hold a quarter of the fits the wave slots do and the kernel as a whole got
+// slower at every share of fits moved to LDS; with many fits in flight per CU the L2 hit latency is hidden well enough.
 __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, const double* y, const double* u, const int32_t* to_xo,
                           const int32_t* to_yo, double* d, int* ip, double sd, int first = 0, int step = 1)
 {
@@ -672,6 +732,10 @@ __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, con
     w.dist = d; d += N;
     w.ic1 = ip;
     w.ic2 = ip + N;
+    double* xyu = w.CX;                       // the breakpoint list is not stored by the wave version
+    w.TX = w.ToXO;
+    w.XfromY = (int*)w.CY;
+    w.XYU = xyu;
     w.sd = sd;
     w.iters = 0;
     w.fail = 0;
@@ -679,6 +743,10 @@ __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, con
     for (int i = first; i < N; i += step) {
         w.XO[w.ToXO[i]] = w.X[i];
         w.YO[w.ToYO[i]] = w.Y[i];
+        if (step > 1) {
+            xyu[i] = w.X[i] + w.Y[i] + w.U[i];
+            w.XfromY[w.ToYO[i]] = w.ToXO[i];
+        }
     }
 }
 
@@ -774,9 +842,12 @@ __global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off
     atomicAdd(iters, (unsigned long long)w.iters);
 }
 
-// one wave per (problem, K) fit of the chunk's n_large largest problems; heaviest fits first
-__global__ __launch_bounds__(WV) void k_mpe_fit_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
-                          const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
+// one (problem, K) fit, or one problem of the final pass with K = its largest K
+struct FitRef { int32_t q, K; };
+
+// one wave per fit of the list (costliest first)
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_fit_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
+                          const FitRef* __restrict__ fits, const double* __restrict__ x, const double* __restrict__ y,
                           const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
                           const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
                           int* __restrict__ wints, double* __restrict__ bic, int32_t* __restrict__ fit_state,
@@ -784,8 +855,8 @@ __global__ __launch_bounds__(WV) void k_mpe_fit_wave(mpe_params prm, const int64
 {
     __shared__ WaveShared s;
     const int lane = threadIdx.x;
-    const int q = order[blockIdx.x / MPE_KMAX];
-    const int K = MPE_KMAX - (int)(blockIdx.x % MPE_KMAX);
+    const int q = fits[blockIdx.x].q;
+    const int K = fits[blockIdx.x].K;
     const int p = p0 + q;
     const int64_t b = prob_off[p];
     const int N = (int)(prob_off[p + 1] - b);
@@ -798,7 +869,15 @@ __global__ __launch_bounds__(WV) void k_mpe_fit_wave(mpe_params prm, const int64
     if (lane < MPE_KMAX) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
     __syncthreads();
     double ll;
+    MPE_T(t_fit0);
     const bool ok = expectation_maximization_wave(w, s, K, lane, ll);
+#ifdef MPE_PROFILE
+    if (lane == 0) {
+        const unsigned long long cyc = (unsigned long long)(clock64() - t_fit0);
+        if (atomicMax(&g_mpe_prof[5], cyc) < cyc) { g_mpe_prof[6] = N; g_mpe_prof[7] = K; g_mpe_prof[8] = w.iters; }
+        atomicAdd(&g_mpe_prof[9], cyc);
+    }
+#endif
     if (lane == 0) {
         if (ok) {
             bic[slot] = -2.0 * ll + K * 2.0 * log((double)N);
@@ -810,8 +889,8 @@ __global__ __launch_bounds__(WV) void k_mpe_fit_wave(mpe_params prm, const int64
 }
 
 // model selection, refit and memberships of one large problem per wave
-__global__ __launch_bounds__(WV) void k_mpe_final_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
-                            const int32_t* __restrict__ order, const double* __restrict__ x, const double* __restrict__ y,
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_final_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
+                            const FitRef* __restrict__ fits, const double* __restrict__ x, const double* __restrict__ y,
                             const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
                             const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
                             int* __restrict__ wints, const double* __restrict__ bic, const int32_t* __restrict__ fit_state,
@@ -820,7 +899,7 @@ __global__ __launch_bounds__(WV) void k_mpe_final_wave(mpe_params prm, const int
 {
     __shared__ WaveShared s;
     const int lane = threadIdx.x;
-    const int q = order[blockIdx.x];
+    const int q = fits[blockIdx.x].q;
     const int p = p0 + q;
     const int64_t b = prob_off[p];
     const int N = (int)(prob_off[p + 1] - b);
@@ -925,12 +1004,14 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     MPE_HIP(hipEventCreate(&e2));
     hipStream_t s_wave;
     MPE_HIP(hipStreamCreateWithFlags(&s_wave, hipStreamNonBlocking));
-    // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none)
-    int64_t wave_min = 40;
+    // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none).  The wave
+    // version is the faster one at every size (profiles/microbench/mpe_sweep.sh); the lane version stays as the literal
+    // transcription it is checked against
+    int64_t wave_min = 0;
     if (const char* e = getenv("DEFUSE_MPE_WAVE_MIN")) wave_min = atoll(e);
 
     // problems are taken in chunks whose fit workspaces (one per problem and K) fit the budget
-    size_t budget = (size_t)8 << 30;
+    size_t budget = (size_t)32 << 30;       // of 288 GB HBM: one chunk for tens of millions of fragments
     if (const char* e = getenv("DEFUSE_MPE_SCRATCH_MB")) budget = std::max<size_t>(1, (size_t)atoll(e)) << 20;
     auto slot_doubles = [&](int p, int K) -> size_t {
         const int n = (int)(prob_off[p + 1] - prob_off[p]);
@@ -963,6 +1044,7 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
             return prob_off[p0 + a + 1] - prob_off[p0 + a] > prob_off[p0 + b + 1] - prob_off[p0 + b];
         });
         DBuf<int64_t> d_wd, d_wi;
+        DBuf<FitRef> d_fits;
         DBuf<int32_t> d_order, d_state;
         DBuf<double> d_work, d_bic;
         DBuf<int> d_iwork;
@@ -981,10 +1063,25 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         MPE_HIP(hipEventRecord(e0, 0));
         MPE_HIP(hipStreamWaitEvent(s_wave, e0, 0));
         if (n_large) {
-            hipLaunchKernelGGL(k_mpe_fit_wave, dim3((unsigned)n_large * MPE_KMAX), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p,
-                               d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
-            hipLaunchKernelGGL(k_mpe_final_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
-                               d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p,
+            // fit list of the wave kernels, costliest (N*K) first: the long fits start early and the short ones fill in
+            std::vector<FitRef> fits, fins;
+            for (int r = 0; r < n_large; ++r) {
+                const int q = order[r];
+                const int n = (int)(prob_off[p0 + q + 1] - prob_off[p0 + q]);
+                const int kmax = n < MPE_KMAX ? n : MPE_KMAX;
+                for (int K = kmax; K >= 1; --K) fits.push_back(FitRef{q, K});
+                fins.push_back(FitRef{q, kmax});
+            }
+            auto size_of = [&](const FitRef& f) { return (int64_t)(prob_off[p0 + f.q + 1] - prob_off[p0 + f.q]) * f.K; };
+            std::stable_sort(fits.begin(), fits.end(), [&](const FitRef& a, const FitRef& b) { return size_of(a) > size_of(b); });
+            const size_t n_fits = fits.size();
+            fits.insert(fits.end(), fins.begin(), fins.end());
+            MPE_HIP(d_fits.alloc(fits.size()));
+            MPE_HIP(hipMemcpy(d_fits.p, fits.data(), fits.size() * sizeof(FitRef), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_mpe_fit_wave, dim3((unsigned)n_fits), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_fits.p, d_x.p, d_y.p,
+                               d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
+            hipLaunchKernelGGL(k_mpe_final_wave, dim3((unsigned)fins.size()), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_fits.p + n_fits,
+                               d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p,
                                d_member.p, d_status.p, d_iters.p);
         }
         if (n_small) {
@@ -1011,10 +1108,19 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     if (n_mp) MPE_HIP(hipMemcpy(member, d_member.p, n_mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
     unsigned long long it = 0;
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
+#ifdef MPE_PROFILE
+    {
+        unsigned long long pr[16];
+        MPE_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_mpe_prof), sizeof pr));
+        fprintf(stderr, "[mpe profile] cycles: init %llu  M %llu  E %llu  LL %llu  R %llu | all fits %llu | longest fit %llu cycles N=%llu K=%llu iters=%llu\n",
+                pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[5], pr[6], pr[7], pr[8]);
+    }
+#endif
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(e2);
     (void)hipStreamDestroy(s_wave);
+
     t.em_iterations = (int64_t)it;
     for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;
     if (timing) *timing = t;

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 D=/tmp/cmp_scale
 python profiles/microbench/cmp_scale.py --fragments ${1:-5000000} --out $D --keep > gpurun_out/mpe_sweep_base.json
 A="-a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5"
-for w in 8 16 24 40 64 128; do
+for w in 0 8 12 16 24 40; do
   DEFUSE_TIMING=1 DEFUSE_MPE_WAVE_MIN=$w bin/clustermatepairs $A -c $D/cl.$w 2>&1 | grep "EM iterations" | sed "s/^/wave_min=$w /"
   cmp -s $D/clusters.txt $D/cl.$w && echo "  identical" || echo "  DIFFERENT"
   rm -f $D/cl.$w

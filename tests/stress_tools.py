@@ -48,7 +48,7 @@ def main():
         m = int(rng.integers(3, 7))
         run = subprocess.run([os.path.join(ROOT, "bin", "clustermatepairs"), "-a", p, "-c", out, "-u", "300", "-s", "30", "-p", "0.95",
                               "-m", str(m)], capture_output=True, text=True,
-                             env=dict(os.environ, DEFUSE_MPE_WAVE_MIN=["40", "0", "1000000000"][r % 3]))   # default split / all waves / all lanes
+                             env=dict(os.environ, DEFUSE_MPE_WAVE_MIN=["0", "40", "1000000000"][r % 3]))   # all waves (default) / split by size / all lanes
         exp_txt, _ = cmp_o.clustermatepairs(lines, 300, 30, 0.95, m)
         assert run.returncode == 0 and open(out).read() == exp_txt, ("clustermatepairs", seed, m, run.stderr[-300:])
         if r % 5 == 4:

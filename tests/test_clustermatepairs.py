@@ -89,8 +89,8 @@ def test_tool_matches_oracle(built, tmp_path, seed):
     r, txt = run_tool(lines, tmp_path, env={"DEFUSE_MPE_SCRATCH_MB": "1"})
     assert r.returncode == 0, r.stderr
     assert txt == exp
-    # every fit in a wave of its own / every fit in one lane (the default splits by problem size)
-    for wave_min in ("0", "1000000000"):
+    # split by problem size / every fit in one lane (the default gives every fit a wave of its own)
+    for wave_min in ("40", "1000000000"):
         r, txt = run_tool(lines, tmp_path, env={"DEFUSE_MPE_WAVE_MIN": wave_min})
         assert r.returncode == 0, r.stderr
         assert txt == exp, "DEFUSE_MPE_WAVE_MIN=" + wave_min
@@ -113,7 +113,7 @@ def test_tool_large_bin_pairs(built, tmp_path):
     assert r.returncode == 0, r.stderr
     exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 3)
     assert n >= 4 and txt == exp
-    for wave_min in ("0", "1000000000"):
+    for wave_min in ("100", "1000000000"):
         r, txt = run_tool(lines, tmp_path, m=3, env={"DEFUSE_MPE_WAVE_MIN": wave_min})
         assert r.returncode == 0, r.stderr
         assert txt == exp, "DEFUSE_MPE_WAVE_MIN=" + wave_min
