@@ -15,6 +15,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <string>
@@ -629,15 +630,21 @@ public:
         regions_.push_back(Region{loc.start, loc.end});
         for (int b = loc.start / spacing_; b <= loc.end / spacing_; ++b) binned_[loc.strand][loc.refName][b].push_back(idx);
     }
-    void Overlapping(const std::string& ref, int strand, const Region& region, std::set<int>& ids) const
+    // ids of the regions that overlap, each once, ascending as signed ints (the canonical visiting order)
+    void Overlapping(const std::string& ref, int strand, const Region& region, std::vector<int>& ids) const
     {
+        ids.clear();
         auto ri = binned_[strand].find(ref);
         if (ri == binned_[strand].end()) return;
         for (int b = region.start / spacing_; b <= region.end / spacing_; ++b) {
             auto bi = ri->second.find(b);
             if (bi == ri->second.end()) continue;
             for (int idx : bi->second)
-                if (regions_[idx].start <= region.end && regions_[idx].end >= region.start) ids.insert(ids_[idx]);
+                if (regions_[idx].start <= region.end && regions_[idx].end >= region.start) ids.push_back(ids_[idx]);
+        }
+        if (ids.size() > 1) {
+            std::sort(ids.begin(), ids.end());
+            ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
         }
     }
 
@@ -683,47 +690,64 @@ class SamAlignmentStream {
 public:
     explicit SamAlignmentStream(const std::string& filename)
     {
-        if (filename == "-") in_ = &std::cin;
-        else {
-            file_.open(filename.c_str());
-            if (!file_.good()) die("Error: Unable to open sam file " + filename);
-            in_ = &file_;
-        }
+        file_ = filename == "-" ? stdin : fopen(filename.c_str(), "rb");
+        if (!file_) die("Error: Unable to open sam file " + filename);
+        reader_.reset(new LineReader(file_));
     }
+    ~SamAlignmentStream() { if (file_ && file_ != stdin) fclose(file_); }
+    SamAlignmentStream(const SamAlignmentStream&) = delete;
+    SamAlignmentStream& operator=(const SamAlignmentStream&) = delete;
     bool GetNextAlignment(RawAlignment& a)
     {
-        std::string line;
-        while (std::getline(*in_, line)) {
+        const char* line;
+        size_t len;
+        while (reader_->next(line, len)) {
             ++line_no_;
-            if (line.empty()) die("Error: Empty alignment line " + std::to_string(line_no_));
+            if (len == 0) die("Error: Empty alignment line " + std::to_string(line_no_));
             if (line[0] == '@') continue;
-            std::vector<std::string> f = split_tabs(line);
-            if (f.size() < 10) die("Error: Format error for alignment line " + std::to_string(line_no_));
-            const int flag = lexical_int_or_die(f[1], "in sam line " + std::to_string(line_no_));
-            const int pos = lexical_int_or_die(f[3], "in sam line " + std::to_string(line_no_));
-            if (f[2] == "*") continue;
+            // fields in place: field k is [fs[k], fs[k+1] - 1); at least 10 are needed, the tenth (SEQ) ends at the next tab
+            const char* fs[11];
+            int nf = 0;
+            fs[nf++] = line;
+            const char* end = line + len;
+            for (const char* p = line; nf < 11;) {
+                const char* tab = (const char*)memchr(p, '\t', (size_t)(end - p));
+                if (!tab) break;
+                fs[nf++] = p = tab + 1;
+            }
+            if (nf < 10) die("Error: Format error for alignment line " + std::to_string(line_no_));
+            if (nf < 11) fs[10] = end + 1;
+            auto flen = [&](int k) { return (size_t)(fs[k + 1] - 1 - fs[k]); };
+            int flag, pos;
+            if (!field_int(fs[1], flen(1), flag) || !field_int(fs[3], flen(3), pos))
+                die("Error: bad integer in sam line " + std::to_string(line_no_));        // reference: uncaught bad_lexical_cast
+            if (flen(2) == 1 && fs[2][0] == '*') continue;
             a.strand = (flag & 0x10) ? MinusStrand : PlusStrand;
-            std::vector<std::string> q = split_tabs(f[0], '/');
-            if (q.size() == 2) {
-                if (q[1] != "1" && q[1] != "2") die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no_));
-                a.fragment = q[0];
-                a.readEnd = (q[1] == "1") ? 0 : 1;
+            // qname split at '/': exactly two parts name the read end, anything else leaves it to the flag bits
+            const char* slash = (const char*)memchr(fs[0], '/', flen(0));
+            const bool two_parts = slash && !memchr(slash + 1, '/', (size_t)(fs[0] + flen(0) - slash - 1));
+            if (two_parts) {
+                const size_t tail = (size_t)(fs[0] + flen(0) - slash - 1);
+                if (tail != 1 || (slash[1] != '1' && slash[1] != '2'))
+                    die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no_));
+                a.fragment.assign(fs[0], (size_t)(slash - fs[0]));
+                a.readEnd = (slash[1] == '1') ? 0 : 1;
             } else {
-                a.fragment = f[0];
+                a.fragment.assign(fs[0], flen(0));
                 if (flag & 0x40) a.readEnd = 0;
                 else if (flag & 0x80) a.readEnd = 1;
             }
-            a.reference = f[2];
+            a.reference.assign(fs[2], flen(2));
             a.region.start = pos;
-            a.region.end = pos + (int)f[9].size() - 1;
+            a.region.end = pos + (int)flen(9) - 1;
             return true;
         }
         return false;
     }
 
 private:
-    std::ifstream file_;
-    std::istream* in_ = nullptr;
+    FILE* file_ = nullptr;
+    std::unique_ptr<LineReader> reader_;
     int line_no_ = 0;
 };
 

@@ -10,6 +10,7 @@
 // Environment: DEFUSE_GPU=<ordinal> selects the device (default: pid mod device count, so the processes the
 // pipeline runs side by side spread over a node's GPUs; with HIP_VISIBLE_DEVICES the
 // ordinal is relative to the visible set).
+#include <chrono>
 #include <numeric>
 
 #include "../include/defuse_dsa.h"
@@ -32,6 +33,14 @@ int main(int argc, char* argv[])
     cmd.add("2", "seq2", "End 2 Sequences", "string");
     cmd.add("a", "align", "Split Alignments Filename", "string");
     cmd.parse(argc, argv);
+    const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_stage = now(), t_gpu = 0.0, t_write = 0.0;
+    auto stage = [&](const char* name) {
+        const double t = now();
+        if (timing) std::cerr << "[dosplitalign] " << name << " " << (t - t_stage) << " s" << std::endl;
+        t_stage = t;
+    };
 
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
@@ -43,18 +52,20 @@ int main(int argc, char* argv[])
         for (int ce = 0; ce <= 1; ++ce)
             for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id(kv.first, ce), loc);
 
+    stage("regions + windows");
     std::unordered_map<int, std::string> reads;
     if (!AddReads(cmd.str("seq1"), reads) || !AddReads(cmd.str("seq2"), reads)) {
         std::cout << "Error: unable to read sequences" << std::endl;
         return 1;
     }
 
+    stage("reads");
     // the GPU batch: one dsa_fusion per task that gets at least one candidate
     std::vector<uint8_t> ref_bytes, read_bytes;
     std::vector<dsa_fusion> fusions;
     std::vector<dsa_pair> cand;                    // candidates in the reference's visiting order
     std::unordered_map<int, int> fusion_index;     // fusion id -> index into fusions
-    std::unordered_map<int, std::set<std::pair<int, int>>> candidate_unique;   // :268, :292
+    std::unordered_set<uint64_t> candidate_unique;   // (fusion, read id, revComp) seen (:268, :292)
 
     std::ofstream out(cmd.str("align").c_str());
     if (!out.good()) die("Error: Unable to open " + cmd.str("align"));
@@ -87,6 +98,7 @@ int main(int argc, char* argv[])
         }
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
         int64_t n = 0;
+        const double t_g0 = now();
         int rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
                                  read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
                                  (int64_t)recs.size(), &n);
@@ -97,6 +109,8 @@ int main(int argc, char* argv[])
                                  recs.data(), (int64_t)recs.size(), &n);
         }
         if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
+        const double t_g1 = now();
+        t_gpu += t_g1 - t_g0;
 
         // back to the visiting order: records arrive grouped by batch pair index
         std::vector<int64_t> first(pairs.size() + 1, 0);
@@ -110,13 +124,16 @@ int main(int argc, char* argv[])
             for (int64_t r = first[k]; r < first[k + 1]; ++r) {
                 const dsa_record& a = recs[r];
                 // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
-                buf += std::to_string(a.fusion_id) + "\t" + std::to_string(a.frag) + "\t" + std::to_string(a.read_end) + "\t" +
-                       std::to_string(a.revcomp) + "\t" + std::to_string(a.ref_first) + "\t" + std::to_string(a.ref_second) + "\t" +
-                       std::to_string(a.read_first) + "\t" + std::to_string(a.read_second) + "\t" + std::to_string(a.score) + "\t\n";
+                for (int v : {a.fusion_id, a.frag, a.read_end, a.revcomp, a.ref_first, a.ref_second, a.read_first, a.read_second, a.score}) {
+                    append_int(buf, v);
+                    buf += '\t';
+                }
+                buf += '\n';
             }
             if (buf.size() > (1u << 20)) { out << buf; buf.clear(); }
         }
         out << buf;
+        t_write += now() - t_g1;
         ref_bytes.clear();
         read_bytes.clear();
         fusions.clear();
@@ -126,18 +143,21 @@ int main(int argc, char* argv[])
 
     SamAlignmentStream sam(cmd.str("improper"));
     RawAlignment mate;
+    std::vector<int> overlapping;
+    std::string seq;
     while (sam.GetNextAlignment(mate)) {
-        std::set<int> overlapping;                 // ascending signed order: end-1 ids (negative) first
-        binned.Overlapping(mate.reference, mate.strand, mate.region, overlapping);
+        binned.Overlapping(mate.reference, mate.strand, mate.region, overlapping);   // ascending signed order: end-1 ids (negative) first
+        int frag = 0;
+        if (!overlapping.empty()) frag = lexical_int_or_die(mate.fragment, "as fragment name");
         for (int cid : overlapping) {
             const int cluster_end = cid < 0 ? 1 : 0;
             const int fusion_id = cid & 0x7FFFFFFF;
-            const int frag = lexical_int_or_die(mate.fragment, "as fragment name");
             const int read_end = (mate.readEnd == 0) ? 1 : 0;
             const int revcomp = (cluster_end == 0) ? 1 : 0;
             const int rid = pack_id(frag, read_end);
-            if (!candidate_unique[fusion_id].insert(std::make_pair(rid, revcomp)).second) continue;
-            std::string seq = reads[rid];          // operator[]: a missing read aligns as the empty string (:286)
+            if (!candidate_unique.insert(((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp).second) continue;
+            auto rd = reads.find(rid);             // a missing read aligns as the empty string (operator[] in the reference, :286)
+            seq.assign(rd == reads.end() ? std::string() : rd->second);
             if (revcomp) ReverseComplement(seq);
             auto fi = fusion_index.find(fusion_id);
             if (fi == fusion_index.end()) {
@@ -167,6 +187,8 @@ int main(int argc, char* argv[])
         if (cand.size() >= batch_pairs || read_bytes.size() > ((size_t)1 << 30) || ref_bytes.size() > ((size_t)1 << 30)) flush();
     }
     flush();
+    stage("candidates + alignment + output");
+    if (timing) std::cerr << "[dosplitalign] of which GPU calls " << t_gpu << " s, formatting and writing " << t_write << " s" << std::endl;
     if (ctx) dsa_destroy(ctx);
     out.close();
     if (!out.good()) die("Error: failed writing " + cmd.str("align"));
