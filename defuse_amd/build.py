@@ -39,7 +39,7 @@ def build_lib(force=False):
     return LIB
 
 
-TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign"]
+TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign", "defuse_glue"]
 
 
 def build_tools(force=False):

@@ -1,0 +1,131 @@
+"""The glue steps between the tools (tools_src/defuse_glue.cpp) against the outputs of the reference's
+own Perl scripts on the same inputs (tests/golden/glue/, written by tests/golden/make_glue.py from /root/reference/scripts).
+Host text tools: no GPU needed.  Where a script prints in Perl's hash order the comparison is order-free and the canonical
+order of the new tool is checked on its own."""
+import os
+import shutil
+import subprocess
+from collections import Counter, defaultdict
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "glue")
+TOOL = os.path.join(ROOT, "bin", "defuse_glue")
+
+
+@pytest.fixture(scope="module")
+def glue(built):
+    from defuse_amd import build
+    build.build_tools()
+    return TOOL
+
+
+def run(tool, args, stdin=None, cwd=None):
+    r = subprocess.run([tool] + args, input=stdin, capture_output=True, text=True, cwd=cwd)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def read(name):
+    with open(os.path.join(G, name)) as f:
+        return f.read()
+
+
+def test_merge_clusters(glue):
+    got = run(glue, ["merge_clusters", "merge_in0.txt", "merge_in1.txt", "merge_in2.txt"], cwd=G)
+    assert got == read("merge_out.txt")
+
+
+def test_get_align_regions(glue):
+    got = run(glue, ["get_align_regions"], stdin=read("regions_in.txt"))
+    exp = read("regions_out.perl.txt")
+    assert sorted(got.splitlines()) == sorted(exp.splitlines())          # the script prints in hash order
+    keys = [tuple(int(v) for v in l.split("\t")[:2]) for l in got.splitlines()]
+    assert keys == sorted(keys)                                           # canonical: cluster ascending, end 0 then 1
+
+
+def test_get_align_regions_needs_both_ends(glue):
+    r = subprocess.run([glue, "get_align_regions"], input="4\t0\t1\t0\tchr1\t+\t5\t9\n", capture_output=True, text=True)
+    assert r.returncode != 0                                              # the script dies: "Did not find 2 ends"
+
+
+def _by_cluster(text):
+    d = defaultdict(list)
+    for l in text.splitlines():
+        d[int(l.split("\t")[0])].append(l)
+    return d
+
+
+def _pos(line):
+    f = line.split("\t")
+    return int(f[6]) if f[5] == "+" else int(f[7])
+
+
+def test_remove_duplicates(glue):
+    inp = read("dups_in.txt")
+    got, exp = run(glue, ["remove_duplicates", "3"], stdin=inp), read("dups_out.perl.txt")
+    g, e, src = _by_cluster(got), _by_cluster(exp), set(inp.splitlines())
+    assert sorted(g) == sorted(e)                                          # the same clusters survive
+    assert list(g) == sorted(g)
+    for cid in g:
+        assert len(g[cid]) == len(e[cid])
+        assert all(l in src for l in g[cid])
+
+        def pairs(lines):
+            frag = defaultdict(dict)
+            for l in lines:
+                f = l.split("\t")
+                frag[int(f[2])][f[1]] = _pos(l)
+            return sorted((v["0"], v["1"]) for v in frag.values())
+        assert pairs(g[cid]) == pairs(e[cid])                              # which duplicate stays is hash order in the script
+        assert len(set(pairs(g[cid]))) == len(pairs(g[cid]))
+    # canonical choice: of a set of duplicates the smallest fragment index stays, fragments ascending
+    for cid, lines in _by_cluster(inp).items():
+        first = {}
+        frag = defaultdict(dict)
+        for l in lines:
+            f = l.split("\t")
+            frag[int(f[2])][f[1]] = _pos(l)
+        for fr in sorted(frag):
+            first.setdefault((frag[fr]["0"], frag[fr]["1"]), fr)
+        if len(first) >= 3:
+            assert [int(l.split("\t")[2]) for l in g[cid]][::2] == sorted(first.values())
+        else:
+            assert cid not in g
+
+
+def test_filter_unmatched(glue):
+    body = "".join(l for l in read("improper.sam").splitlines(True) if not l.startswith("@"))
+    assert run(glue, ["filter_unmatched"], stdin=body) == read("matched.sam")
+
+
+def test_divide_sam_chr_pairs(glue, tmp_path):
+    shutil.copy(os.path.join(G, "trans_chr.txt"), tmp_path / "trans_chr.txt")
+    os.makedirs(tmp_path / "div")
+    (tmp_path / "div" / "chr1-chr2").write_text("stale\n")                 # an old file is replaced, not appended to
+    listing = run(glue, ["divide_sam_chr_pairs", "-t", "trans_chr.txt", "-p", "div/"], stdin=read("matched.sam"), cwd=tmp_path)
+    assert listing == read("div_list.txt")
+    names = sorted(os.listdir(os.path.join(G, "div")))
+    assert sorted(os.listdir(tmp_path / "div")) == names
+    for n in names:
+        got = (tmp_path / "div" / n).read_text().splitlines()
+        exp = read(os.path.join("div", n)).splitlines()
+        assert Counter(got) == Counter(exp), n                             # inside a fragment the script's order is hash order
+
+        def runs(lines):
+            out = []
+            for l in lines:
+                fr = l.split("\t")[0]
+                if not out or out[-1] != fr:
+                    out.append(fr)
+            return out
+        assert runs(got) == runs(exp), n                                   # fragments in the same order, each one run
+        assert len(runs(got)) == len(set(runs(got)))
+
+
+def test_script_name_selects_the_step(glue, tmp_path):
+    link = tmp_path / "merge_clusters.pl"
+    os.symlink(glue, link)
+    got = run(str(link), ["merge_in0.txt", "merge_in1.txt", "merge_in2.txt"], cwd=G)
+    assert got == read("merge_out.txt")
