@@ -55,7 +55,7 @@ def build_tools(force=False):
                 os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
                 os.path.join(ROOT, "include", "defuse_la.h"), lib]
         if force or _newer(out, deps):
-            _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-o", out, src, lib,
+            _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, lib,
                   "-Wl,-rpath,$ORIGIN/../defuse_amd"])
         outs.append(out)
     return outs

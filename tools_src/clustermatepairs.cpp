@@ -5,8 +5,15 @@
 // all bin pairs runs on the GPU in one batch through include/defuse_mpe.h (no CPU fallback).
 // Iteration orders the reference leaves to boost::unordered_map are the canonical ascending-key
 // orders of SURVEY.md 8(c).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
+#include <functional>
 #include <numeric>
+#include <thread>
 
 #include "../include/defuse_dsa.h"
 #include "../include/defuse_mpe.h"
@@ -23,10 +30,8 @@ const int binLength = 1 << 15;
 
 // Binning::GetBins (tools/clustermatepairs.cpp:152-162) appears inline below as
 //   startBin = (region.start - extend) / length, endBin = (region.end + extend) / length      (C++ int division)
-unsigned pack_ref_bin(int ref, int strand, int bin)   // RefBinPacked (:28-65)
+unsigned pack_ref_bin(int ref, int strand, int bin)   // RefBinPacked (:28-65); the caller has checked ref < 2^18 and bin < 2^13
 {
-    if (ref >= (1 << 18)) { std::cout << ref << std::endl << (1 << 18) << std::endl; die("Packing failed, too many reference sequences"); }
-    if (bin >= (1 << 13)) { std::cout << bin << std::endl << (1 << 13) << std::endl; die("Packing failed, chromosome too large"); }
     return (unsigned)ref | ((unsigned)strand << 18) | (((unsigned)bin & 0x1FFFu) << 19);
 }
 
@@ -160,83 +165,132 @@ int main(int argc, char* argv[])
         t_stage = t;
     };
     std::cout << "Finding pairs of reference sequences connected by pairs of alignments" << std::endl;
-    FILE* in = stdin;
+    // The input is taken into memory whole and cut into one piece per host thread at fragment boundaries.  Every piece is
+    // parsed, then (with reference indices in order of first appearance over the whole file, as a serial reader gives
+    // them) binned into bin pairs of its own; the pieces' bin pairs are joined in file order, so every list holds its
+    // alignments in the order a single reader would have appended them.
+    // a file is mapped (the parsing threads fault its pages in side by side), stdin is collected in a plain buffer
+    struct Text {
+        char* p = nullptr;
+        size_t n = 0, cap = 0;
+        bool mapped = false;
+        const char* data() const { return p; }
+        size_t size() const { return n; }
+        char operator[](size_t k) const { return p[k]; }
+        void release()
+        {
+            if (mapped) munmap(p, n); else free(p);
+            p = nullptr; n = cap = 0;
+        }
+    } text;
     if (cmd.str("align") != "-") {
-        in = fopen(cmd.str("align").c_str(), "rb");
-        if (!in) die("Error: Unable to open alignment file " + cmd.str("align"));
+        const int fd = open(cmd.str("align").c_str(), O_RDONLY);
+        if (fd < 0) die("Error: Unable to open alignment file " + cmd.str("align"));
+        struct stat st;
+        if (fstat(fd, &st) != 0) die("Error: Unable to open alignment file " + cmd.str("align"));
+        if (S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m == MAP_FAILED) die("Error: Unable to map alignment file " + cmd.str("align"));
+            text.p = (char*)m; text.n = (size_t)st.st_size; text.mapped = true;
+            close(fd);
+        } else {
+            FILE* in = fdopen(fd, "rb");
+            for (;;) {
+                if (text.cap - text.n < ((size_t)1 << 24)) {
+                    text.cap = std::max<size_t>(text.cap * 2, (size_t)1 << 26);
+                    text.p = (char*)realloc(text.p, text.cap);
+                    if (!text.p) die("Error: out of memory reading the alignments");
+                }
+                const size_t got = fread(text.p + text.n, 1, text.cap - text.n, in);
+                if (got == 0) break;
+                text.n += got;
+            }
+            fclose(in);
+        }
+    } else {
+        for (;;) {
+            if (text.cap - text.n < ((size_t)1 << 24)) {
+                text.cap = std::max<size_t>(text.cap * 2, (size_t)1 << 26);
+                text.p = (char*)realloc(text.p, text.cap);
+                if (!text.p) die("Error: out of memory reading the alignments");
+            }
+            const size_t got = fread(text.p + text.n, 1, text.cap - text.n, stdin);
+            if (got == 0) break;
+            text.n += got;
+        }
     }
-    std::vector<std::string> refNames;
-    std::unordered_map<std::string, int> refIndex;
-    typedef std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>> PackedPair;
-    // bin pairs by (first.id, second.id): hashed while reading, visited in ascending key order afterwards (canonical)
-    std::unordered_map<uint64_t, uint32_t> binPairIndex;
-    std::vector<uint64_t> binPairKey;
-    std::vector<PackedPair> binPairStore;
-    auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
-        const uint64_t key = ((uint64_t)lo << 32) | hi;
-        auto it = binPairIndex.find(key);
-        if (it == binPairIndex.end()) {
-            it = binPairIndex.emplace(key, (uint32_t)binPairStore.size()).first;
-            binPairKey.push_back(key);
-            binPairStore.emplace_back();
+    stage("  input in memory");
+    unsigned nThreads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));       // profiles/microbench/cmp_threads.sh
+    if (const char* e = std::getenv("DEFUSE_THREADS")) nThreads = (unsigned)std::max(1, std::atoi(e));
+    if (text.size() < ((size_t)1 << 20)) nThreads = 1;
+
+    auto line_end = [&](size_t pos) {                       // one past the line's newline (or the end of the text)
+        const char* nl = (const char*)memchr(text.data() + pos, '\n', text.size() - pos);
+        return nl ? (size_t)(nl - text.data()) + 1 : text.size();
+    };
+    auto name_of = [&](size_t pos, size_t& len) {           // first field of the line at pos
+        const size_t e = line_end(pos);
+        size_t stop = (e > pos && text[e - 1] == '\n') ? e - 1 : e;
+        const char* tab = (const char*)memchr(text.data() + pos, '\t', stop - pos);
+        len = tab ? (size_t)(tab - (text.data() + pos)) : stop - pos;
+        return text.data() + pos;
+    };
+    std::vector<size_t> cut(nThreads + 1, text.size());
+    cut[0] = 0;
+    for (unsigned t = 1; t < nThreads; ++t) {
+        size_t pos = std::max(cut[t - 1], text.size() / nThreads * t);
+        if (pos > 0 && pos < text.size() && text[pos - 1] != '\n') pos = line_end(pos);
+        while (pos > 0 && pos < text.size()) {                // not inside a fragment: move on while the name repeats
+            size_t prev = pos - 1;
+            while (prev > 0 && text[prev - 1] != '\n') --prev;
+            size_t l0, l1;
+            const char* n0 = name_of(prev, l0);
+            const char* n1 = name_of(pos, l1);
+            if (l0 != l1 || memcmp(n0, n1, l0) != 0) break;
+            pos = line_end(pos);
         }
-        return binPairStore[it->second];
+        cut[t] = pos;
+    }
+
+    struct Piece {
+        std::vector<CompactAlignment> recs;                  // referenceIndex: piece-local until remapped
+        std::vector<uint32_t> fragStart;                     // first record of every fragment, plus the end
+        std::vector<std::string> refNames;
+        std::unordered_map<std::string, int> refIndex;
+        size_t lines = 0;
+        size_t errorLine = 0;                                // 1-based line inside the piece, 0 = none
+        std::string error;
+        std::vector<std::string> errorStdout;
+        std::unordered_map<uint64_t, uint32_t> binPairIndex;
+        std::vector<uint64_t> binPairKey;
+        std::vector<std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>>> binPairStore;
+    };
+    std::vector<Piece> pieces(nThreads);
+    auto run_threads = [&](const std::function<void(unsigned)>& fn) {
+        if (nThreads == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nThreads; ++t) th.emplace_back(fn, t);
+        for (std::thread& x : th) x.join();
     };
 
-    std::vector<std::pair<int, int>> conc[2];
-    std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
-    auto process_fragment = [&](const std::vector<CompactAlignment>& alignments) {
-        // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
-        conc[0].clear(); conc[1].clear();
-        for (const CompactAlignment& a : alignments) {
-            const int startBin = (a.region.start - minFusionRange) / minFusionRange, endBin = (a.region.end + minFusionRange) / minFusionRange;
-            for (int b = startBin; b <= endBin; ++b) conc[a.readEnd].push_back(std::make_pair(a.referenceIndex, b));
-        }
-        for (const auto& rb : conc[0])
-            if (std::find(conc[1].begin(), conc[1].end(), rb) != conc[1].end()) return;
-        // AddBinPairs (:246-290): per read end the packed alignments by bin id ascending, arrival order inside a bin
-        binned[0].clear(); binned[1].clear();
-        for (const CompactAlignment& a : alignments) {
-            const int startBin = (a.region.start - minFusionRange) / binLength, endBin = (a.region.end + minFusionRange) / binLength;
-            for (int b = startBin; b <= endBin; ++b) {
-                const int rs = a.region.start - b * binLength + binLength / 2, re = a.region.end - b * binLength + binLength / 2;
-                if (rs < 0 || re < 0 || rs >= (1 << 16) || re >= (1 << 16)) die("Error: relativeStart >= 0 failed (alignment does not fit its bin)");
-                binned[a.readEnd].push_back(std::make_pair(pack_ref_bin(a.referenceIndex, a.strand, b),
-                                                           AlignmentPacked{a.fragmentIndex, a.readEnd, (unsigned short)rs, (unsigned short)re}));
-            }
-        }
-        for (int e = 0; e < 2; ++e)
-            std::stable_sort(binned[e].begin(), binned[e].end(), [](const std::pair<unsigned, AlignmentPacked>& x,
-                                                                    const std::pair<unsigned, AlignmentPacked>& y) { return x.first < y.first; });
-        for (size_t i0 = 0; i0 < binned[0].size();) {
-            size_t i1 = i0;
-            while (i1 < binned[0].size() && binned[0][i1].first == binned[0][i0].first) ++i1;
-            for (size_t j0 = 0; j0 < binned[1].size();) {
-                size_t j1 = j0;
-                while (j1 < binned[1].size() && binned[1][j1].first == binned[1][j0].first) ++j1;
-                const unsigned id1 = binned[0][i0].first, id2 = binned[1][j0].first;
-                const bool fwd = id1 < id2;
-                PackedPair& e = fwd ? bin_pair(id1, id2) : bin_pair(id2, id1);
-                std::vector<AlignmentPacked>& d1 = fwd ? e.first : e.second;
-                std::vector<AlignmentPacked>& d2 = fwd ? e.second : e.first;
-                for (size_t k = i0; k < i1; ++k) d1.push_back(binned[0][k].second);
-                for (size_t k = j0; k < j1; ++k) d2.push_back(binned[1][k].second);
-                j0 = j1;
-            }
-            i0 = i1;
-        }
-    };
-
-    {   // CompactAlignmentStream + FragmentAlignmentStream (tools/AlignmentStream.cpp:156-221)
-        LineReader reader(in);
-        const char* line;
-        size_t len;
-        std::string curName, refKey;
-        std::vector<CompactAlignment> cur;
-        int lineNumber = 0;
-        while (reader.next(line, len)) {
-            ++lineNumber;
-            if (len == 0) die("Error: Empty alignment line " + std::to_string(lineNumber));
+    // CompactAlignmentStream + FragmentAlignmentStream (tools/AlignmentStream.cpp:156-221), one piece
+    auto parse_piece = [&](unsigned t) {
+        Piece& pc = pieces[t];
+        size_t pos = cut[t];
+        const size_t stop = cut[t + 1];
+        pc.recs.reserve((stop - pos) / 28 + 16);              // a line is at least ~30 bytes; no regrowth while parsing
+        pc.fragStart.reserve((stop - pos) / 56 + 16);
+        const char* curName = nullptr;
+        size_t curLen = 0;
+        std::string refKey;
+        while (pos < stop) {
+            const size_t e = line_end(pos);
+            const char* line = text.data() + pos;
+            const size_t len = (e > pos && text[e - 1] == '\n') ? e - 1 - pos : e - pos;
+            pos = e;
+            ++pc.lines;
+            auto fail = [&](const std::string& msg) { pc.errorLine = pc.lines; pc.error = msg; };
+            if (len == 0) { fail("Error: Empty alignment line "); return; }
             const char* fs[7];
             int nf = 0;
             fs[nf++] = line;
@@ -245,32 +299,179 @@ int main(int argc, char* argv[])
                 if (!tab) break;
                 fs[nf++] = p = tab + 1;
             }
-            if (nf < 6) die("Error: Format error for alignment line " + std::to_string(lineNumber));
+            if (nf < 6) { fail("Error: Format error for alignment line "); return; }
             if (nf < 7) fs[6] = line + len + 1;                      // field k is [fs[k], fs[k+1] - 1)
             auto flen = [&](int k) { return (size_t)(fs[k + 1] - 1 - fs[k]); };
-            if (!cur.empty() && (flen(0) != curName.size() || memcmp(fs[0], curName.data(), curName.size()) != 0)) {
-                process_fragment(cur);
-                cur.clear();
+            if (!curName || flen(0) != curLen || memcmp(fs[0], curName, curLen) != 0) {
+                pc.fragStart.push_back((uint32_t)pc.recs.size());
+                curName = fs[0];
+                curLen = flen(0);
             }
-            if (cur.empty()) curName.assign(fs[0], flen(0));
             CompactAlignment a;
-            if (!field_int(fs[0], flen(0), a.fragmentIndex))
-                die("Error: bad integer '" + std::string(fs[0], flen(0)) + "' as fragment name on line " + std::to_string(lineNumber));
+            if (!field_int(fs[0], flen(0), a.fragmentIndex)) { fail("Error: bad integer '" + std::string(fs[0], flen(0)) + "' as fragment name on line "); return; }
             a.readEnd = (flen(1) == 1 && fs[1][0] == '1') ? 0 : 1;
             refKey.assign(fs[2], flen(2));
-            auto ri = refIndex.find(refKey);
-            if (ri == refIndex.end()) {
-                ri = refIndex.emplace(refKey, (int)refNames.size()).first;
-                refNames.push_back(refKey);
+            auto ri = pc.refIndex.find(refKey);
+            if (ri == pc.refIndex.end()) {
+                ri = pc.refIndex.emplace(refKey, (int)pc.refNames.size()).first;
+                pc.refNames.push_back(refKey);
             }
             a.referenceIndex = ri->second;
             a.strand = (flen(3) == 1 && fs[3][0] == '-') ? MinusStrand : PlusStrand;
-            if (!field_int(fs[4], flen(4), a.region.start) || !field_int(fs[5], flen(5), a.region.end))
-                die("Error: bad integer '" + std::string(fs[4], (size_t)(line + len - fs[4])) + "' on line " + std::to_string(lineNumber));
-            cur.push_back(a);
+            if (!field_int(fs[4], flen(4), a.region.start) || !field_int(fs[5], flen(5), a.region.end)) {
+                fail("Error: bad integer '" + std::string(fs[4], (size_t)(line + len - fs[4])) + "' on line ");
+                return;
+            }
+            pc.recs.push_back(a);
         }
-        if (!cur.empty()) process_fragment(cur);
-        if (in != stdin) fclose(in);
+    };
+    run_threads(parse_piece);
+    if (timing) { std::cerr << "[clustermatepairs]   lines per piece:"; for (const Piece& pc : pieces) std::cerr << " " << pc.lines; std::cerr << std::endl; }
+    stage("  parsed");
+    {
+        size_t lineBase = 0;
+        for (const Piece& pc : pieces) {                      // the first bad line of the file, as a serial reader meets it
+            if (pc.errorLine) die(pc.error + std::to_string(lineBase + pc.errorLine));
+            lineBase += pc.lines;
+        }
+    }
+    text.release();
+
+    std::vector<std::string> refNames;
+    {
+        std::unordered_map<std::string, int> refIndex;
+        for (Piece& pc : pieces) {
+            std::vector<int> remap(pc.refNames.size());
+            for (size_t k = 0; k < pc.refNames.size(); ++k) {
+                auto ri = refIndex.find(pc.refNames[k]);
+                if (ri == refIndex.end()) {
+                    ri = refIndex.emplace(pc.refNames[k], (int)refNames.size()).first;
+                    refNames.push_back(pc.refNames[k]);
+                }
+                remap[k] = ri->second;
+            }
+            for (CompactAlignment& a : pc.recs) a.referenceIndex = remap[a.referenceIndex];
+            pc.fragStart.push_back((uint32_t)pc.recs.size());
+        }
+    }
+
+    typedef std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>> PackedPair;
+    auto bin_piece = [&](unsigned t) {
+        Piece& pc = pieces[t];
+        auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
+            const uint64_t key = ((uint64_t)lo << 32) | hi;
+            auto it = pc.binPairIndex.find(key);
+            if (it == pc.binPairIndex.end()) {
+                it = pc.binPairIndex.emplace(key, (uint32_t)pc.binPairStore.size()).first;
+                pc.binPairKey.push_back(key);
+                pc.binPairStore.emplace_back();
+            }
+            return pc.binPairStore[it->second];
+        };
+        std::vector<std::pair<int, int>> conc[2];
+        std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
+        for (size_t fr = 0; fr + 1 < pc.fragStart.size(); ++fr) {
+            const CompactAlignment* first = pc.recs.data() + pc.fragStart[fr];
+            const CompactAlignment* last = pc.recs.data() + pc.fragStart[fr + 1];
+            // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
+            conc[0].clear(); conc[1].clear();
+            for (const CompactAlignment* a = first; a != last; ++a) {
+                const int startBin = (a->region.start - minFusionRange) / minFusionRange, endBin = (a->region.end + minFusionRange) / minFusionRange;
+                for (int b = startBin; b <= endBin; ++b) conc[a->readEnd].push_back(std::make_pair(a->referenceIndex, b));
+            }
+            bool concordant = false;
+            for (const auto& rb : conc[0])
+                if (std::find(conc[1].begin(), conc[1].end(), rb) != conc[1].end()) { concordant = true; break; }
+            if (concordant) continue;
+            // AddBinPairs (:246-290): per read end the packed alignments by bin id ascending, arrival order inside a bin
+            binned[0].clear(); binned[1].clear();
+            for (const CompactAlignment* a = first; a != last; ++a) {
+                const int startBin = (a->region.start - minFusionRange) / binLength, endBin = (a->region.end + minFusionRange) / binLength;
+                for (int b = startBin; b <= endBin; ++b) {
+                    const int rs = a->region.start - b * binLength + binLength / 2, re = a->region.end - b * binLength + binLength / 2;
+                    if (rs < 0 || re < 0 || rs >= (1 << 16) || re >= (1 << 16)) {
+                        pc.errorLine = 1;
+                        pc.error = "Error: relativeStart >= 0 failed (alignment does not fit its bin)";
+                        return;
+                    }
+                    if (a->referenceIndex >= (1 << 18) || b >= (1 << 13)) {        // RefBinPacked (:28-65)
+                        const bool refs = a->referenceIndex >= (1 << 18);
+                        pc.errorLine = 1;
+                        pc.errorStdout = {std::to_string(refs ? a->referenceIndex : b), std::to_string(refs ? (1 << 18) : (1 << 13))};
+                        pc.error = refs ? "Packing failed, too many reference sequences" : "Packing failed, chromosome too large";
+                        return;
+                    }
+                    binned[a->readEnd].push_back(std::make_pair(pack_ref_bin(a->referenceIndex, a->strand, b),
+                                                                AlignmentPacked{a->fragmentIndex, a->readEnd, (unsigned short)rs, (unsigned short)re}));
+                }
+            }
+            for (int e = 0; e < 2; ++e)
+                std::stable_sort(binned[e].begin(), binned[e].end(), [](const std::pair<unsigned, AlignmentPacked>& x,
+                                                                        const std::pair<unsigned, AlignmentPacked>& y) { return x.first < y.first; });
+            for (size_t i0 = 0; i0 < binned[0].size();) {
+                size_t i1 = i0;
+                while (i1 < binned[0].size() && binned[0][i1].first == binned[0][i0].first) ++i1;
+                for (size_t j0 = 0; j0 < binned[1].size();) {
+                    size_t j1 = j0;
+                    while (j1 < binned[1].size() && binned[1][j1].first == binned[1][j0].first) ++j1;
+                    const unsigned id1 = binned[0][i0].first, id2 = binned[1][j0].first;
+                    const bool fwd = id1 < id2;
+                    PackedPair& e = fwd ? bin_pair(id1, id2) : bin_pair(id2, id1);
+                    std::vector<AlignmentPacked>& d1 = fwd ? e.first : e.second;
+                    std::vector<AlignmentPacked>& d2 = fwd ? e.second : e.first;
+                    for (size_t k = i0; k < i1; ++k) d1.push_back(binned[0][k].second);
+                    for (size_t k = j0; k < j1; ++k) d2.push_back(binned[1][k].second);
+                    j0 = j1;
+                }
+                i0 = i1;
+            }
+        }
+        pc.recs.clear();
+        pc.recs.shrink_to_fit();
+    };
+    run_threads(bin_piece);
+    stage("  binned");
+    for (const Piece& pc : pieces)
+        if (pc.errorLine) {
+            for (const std::string& l : pc.errorStdout) std::cout << l << std::endl;
+            die(pc.error);
+        }
+
+    // bin pairs by (first.id, second.id), the pieces joined in file order; visited in ascending key order afterwards (canonical)
+    std::vector<uint64_t> binPairKey;
+    std::vector<PackedPair> binPairStore;
+    if (nThreads == 1) {
+        binPairKey.swap(pieces[0].binPairKey);
+        binPairStore.swap(pieces[0].binPairStore);
+    } else {
+        // thread t joins the keys whose hash falls to it, walking the pieces in file order
+        struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
+        std::vector<Joined> joined(nThreads);
+        auto join_keys = [&](unsigned t) {
+            Joined& j = joined[t];
+            std::unordered_map<uint64_t, uint32_t> index;
+            for (Piece& pc : pieces)
+                for (size_t k = 0; k < pc.binPairKey.size(); ++k) {
+                    const uint64_t key = pc.binPairKey[k];
+                    if ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads != t) continue;
+                    auto it = index.find(key);
+                    if (it == index.end()) {
+                        index.emplace(key, (uint32_t)j.store.size());
+                        j.key.push_back(key);
+                        j.store.push_back(std::move(pc.binPairStore[k]));
+                    } else {
+                        PackedPair& d = j.store[it->second];
+                        d.first.insert(d.first.end(), pc.binPairStore[k].first.begin(), pc.binPairStore[k].first.end());
+                        d.second.insert(d.second.end(), pc.binPairStore[k].second.begin(), pc.binPairStore[k].second.end());
+                    }
+                }
+        };
+        run_threads(join_keys);
+        for (Joined& j : joined) {
+            binPairKey.insert(binPairKey.end(), j.key.begin(), j.key.end());
+            for (PackedPair& pp : j.store) binPairStore.push_back(std::move(pp));
+        }
+        pieces.clear();
     }
 
     stage("read + bin pairs");
@@ -289,15 +490,36 @@ int main(int argc, char* argv[])
 
     std::cout << "Creating clusters" << std::endl;
     // per bin pair: unpack, match fragments, drop overlapping alignments, enumerate alignment pairs (:478-545)
-    std::vector<Problem> problems;
-    std::vector<int64_t> probOff(1, 0);
-    std::vector<double> X, Y, U;
-    std::vector<int32_t> toXO, toYO;
     std::vector<uint32_t> bpOrder(binPairKey.size());
     std::iota(bpOrder.begin(), bpOrder.end(), 0u);
     std::sort(bpOrder.begin(), bpOrder.end(), [&](uint32_t a, uint32_t b) { return binPairKey[a] < binPairKey[b]; });
-    FragmentGroups fr1, fr2, fr2all;
-    for (uint32_t bpi : bpOrder) {
+    // bin pairs are independent: every host thread takes a contiguous share of them (balanced by alignment count), the
+    // shares are joined in order
+    struct PartOut {
+        std::vector<Problem> problems;
+        std::vector<int64_t> sizes;
+        std::vector<double> X, Y, U;
+        std::vector<int32_t> toXO, toYO;
+    };
+    std::vector<PartOut> parts(nThreads);
+    std::vector<size_t> share(nThreads + 1, bpOrder.size());
+    {
+        size_t total = 0;
+        for (const PackedPair& pp : binPairStore) total += pp.first.size() + pp.second.size();
+        size_t acc = 0;
+        unsigned t = 1;
+        share[0] = 0;
+        for (size_t oi = 0; oi < bpOrder.size() && t < nThreads; ++oi) {
+            acc += binPairStore[bpOrder[oi]].first.size() + binPairStore[bpOrder[oi]].second.size();
+            if (acc >= total / nThreads * t) share[t++] = oi + 1;
+        }
+    }
+    auto build_share = [&](unsigned t) {
+        PartOut& o = parts[t];
+        const size_t lo = share[t], hi = share[t + 1];
+        FragmentGroups fr1, fr2, fr2all;
+        for (size_t oi = lo; oi < hi; ++oi) {
+        const uint32_t bpi = bpOrder[oi];
         const PackedPair& pp = binPairStore[bpi];
         if ((int)pp.first.size() < minClusterSize || (int)pp.second.size() < minClusterSize) continue;
         Problem prob;
@@ -326,27 +548,45 @@ int main(int argc, char* argv[])
         for (size_t f = 0; f < fr1.size(); ++f)
             for (int k1 = fr1.off[f]; k1 < fr1.off[f + 1]; ++k1)
                 for (int k2 = fr2.off[f]; k2 < fr2.off[f + 1]; ++k2) prob.alignPairs.push_back(std::make_pair(fr1.idx[k1], fr2.idx[k2]));
-        const size_t n = prob.alignPairs.size(), base = X.size();
+        const size_t n = prob.alignPairs.size(), base = o.X.size();
         for (size_t k = 0; k < n; ++k) {
             const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
             const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
             const Region r1 = StrandRemap(a1.region, a1.strand), r2 = StrandRemap(a2.region, a2.strand);
-            X.push_back(r1.end);
-            Y.push_back(r2.end);
-            U.push_back(fragmentMean - (r1.end - r1.start + 1) - (r2.end - r2.start + 1));   // DoClustering :554-556
+            o.X.push_back(r1.end);
+            o.Y.push_back(r2.end);
+            o.U.push_back(fragmentMean - (r1.end - r1.start + 1) - (r2.end - r2.start + 1));   // DoClustering :554-556
         }
         // ranks when sorted by x (y) descending, ties by index ascending (the reference's std::sort leaves ties open)
         std::vector<int> ord(n);
-        toXO.resize(base + n);
-        toYO.resize(base + n);
+        o.toXO.resize(base + n);
+        o.toYO.resize(base + n);
         std::iota(ord.begin(), ord.end(), 0);
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return X[base + a] > X[base + b]; });
-        for (size_t r = 0; r < n; ++r) toXO[base + ord[r]] = (int32_t)r;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return o.X[base + a] > o.X[base + b]; });
+        for (size_t r = 0; r < n; ++r) o.toXO[base + ord[r]] = (int32_t)r;
         std::iota(ord.begin(), ord.end(), 0);
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return Y[base + a] > Y[base + b]; });
-        for (size_t r = 0; r < n; ++r) toYO[base + ord[r]] = (int32_t)r;
-        probOff.push_back((int64_t)X.size());
-        problems.push_back(std::move(prob));
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return o.Y[base + a] > o.Y[base + b]; });
+        for (size_t r = 0; r < n; ++r) o.toYO[base + ord[r]] = (int32_t)r;
+        o.sizes.push_back((int64_t)n);
+        o.problems.push_back(std::move(prob));
+    }
+    };
+    run_threads(build_share);
+    std::vector<Problem> problems;
+    std::vector<int64_t> probOff(1, 0);
+    std::vector<double> X, Y, U;
+    std::vector<int32_t> toXO, toYO;
+    for (PartOut& o : parts) {
+        for (size_t k = 0; k < o.problems.size(); ++k) {
+            problems.push_back(std::move(o.problems[k]));
+            probOff.push_back(probOff.back() + o.sizes[k]);
+        }
+        X.insert(X.end(), o.X.begin(), o.X.end());
+        Y.insert(Y.end(), o.Y.begin(), o.Y.end());
+        U.insert(U.end(), o.U.begin(), o.U.end());
+        toXO.insert(toXO.end(), o.toXO.begin(), o.toXO.end());
+        toYO.insert(toYO.end(), o.toYO.begin(), o.toYO.end());
+        o = PartOut();
     }
     binPairStore.clear();
     binPairStore.shrink_to_fit();
@@ -382,35 +622,53 @@ int main(int argc, char* argv[])
 
     stage("clustering");
     // output (:549-583): per emitted cluster one alignment pair per distinct fragment, in mate pair order
-    int clusterID = 0;
-    std::string buf;
-    buf.reserve((1u << 22) + 4096);
-    std::vector<int> usedFragments;
-    auto put_int = [&](long long v) { append_int(buf, v); };
-    for (size_t p = 0; p < problems.size(); ++p) {
-        const Problem& prob = problems[p];
-        const int64_t base = probOff[p];
-        for (int j = 0; j < nClusters[p]; ++j) {
-            usedFragments.clear();
-            for (size_t k = 0; k < prob.alignPairs.size(); ++k) {
-                if (!((member[base + k] >> j) & 1)) continue;
-                const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
-                const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
-                // mate pairs are listed fragment by fragment, so a fragment seen before is the last one used
-                if (!usedFragments.empty() && usedFragments.back() == a1.fragmentIndex) continue;
-                usedFragments.push_back(a1.fragmentIndex);
-                for (int ce = 0; ce <= 1; ++ce) {
-                    const CompactAlignment& a = ce ? a2 : a1;
-                    put_int(clusterID); buf += '\t'; put_int(ce); buf += '\t'; put_int(a.fragmentIndex); buf += '\t'; put_int(a.readEnd);
-                    buf += '\t'; buf += refNames[a.referenceIndex]; buf += '\t'; buf += (a.strand == PlusStrand ? '+' : '-'); buf += '\t';
-                    put_int(a.region.start); buf += '\t'; put_int(a.region.end); buf += '\n';
+    // every host thread formats a contiguous share of the problems (cluster ids from a prefix sum of the emitted
+    // clusters), the texts are written in order
+    std::vector<int> firstCluster(problems.size() + 1, 0);
+    for (size_t p = 0; p < problems.size(); ++p) firstCluster[p + 1] = firstCluster[p] + nClusters[p];
+    const int clusterID = firstCluster[problems.size()];
+    std::vector<size_t> outShare(nThreads + 1, 0);
+    std::vector<std::string> texts(nThreads);
+    auto format_share = [&](unsigned t) {
+        std::string& buf = texts[t];
+        std::vector<int> usedFragments;
+        auto put_int = [&](long long v) { append_int(buf, v); };
+        for (size_t p = outShare[t]; p < outShare[t + 1]; ++p) {
+            const Problem& prob = problems[p];
+            const int64_t base = probOff[p];
+            for (int j = 0; j < nClusters[p]; ++j) {
+                const int id = firstCluster[p] + j;
+                usedFragments.clear();
+                for (size_t k = 0; k < prob.alignPairs.size(); ++k) {
+                    if (!((member[base + k] >> j) & 1)) continue;
+                    const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
+                    const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
+                    // mate pairs are listed fragment by fragment, so a fragment seen before is the last one used
+                    if (!usedFragments.empty() && usedFragments.back() == a1.fragmentIndex) continue;
+                    usedFragments.push_back(a1.fragmentIndex);
+                    for (int ce = 0; ce <= 1; ++ce) {
+                        const CompactAlignment& a = ce ? a2 : a1;
+                        put_int(id); buf += '\t'; put_int(ce); buf += '\t'; put_int(a.fragmentIndex); buf += '\t'; put_int(a.readEnd);
+                        buf += '\t'; buf += refNames[a.referenceIndex]; buf += '\t'; buf += (a.strand == PlusStrand ? '+' : '-'); buf += '\t';
+                        put_int(a.region.start); buf += '\t'; put_int(a.region.end); buf += '\n';
+                    }
                 }
-                if (buf.size() > (1u << 22)) { out.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
             }
-            ++clusterID;
         }
+    };
+    for (size_t lo = 0; lo < problems.size();) {              // rounds of about a million mate pairs bound the text held in memory
+        size_t hi = lo;
+        while (hi < problems.size() && probOff[hi] - probOff[lo] < (1 << 20)) ++hi;
+        outShare[0] = lo;
+        for (unsigned t = 1; t <= nThreads; ++t) {
+            const int64_t want = probOff[lo] + (probOff[hi] - probOff[lo]) / nThreads * t;
+            size_t at = t == nThreads ? hi : (size_t)(std::lower_bound(probOff.begin() + lo, probOff.begin() + hi, want) - probOff.begin());
+            outShare[t] = std::min(std::max(at, outShare[t - 1]), hi);
+        }
+        run_threads(format_share);
+        for (std::string& tbuf : texts) { out.write(tbuf.data(), (std::streamsize)tbuf.size()); tbuf.clear(); }
+        lo = hi;
     }
-    out.write(buf.data(), (std::streamsize)buf.size());
     out.close();
     stage("output");
     std::cout << "Created " << clusterID << " clusters" << std::endl;
