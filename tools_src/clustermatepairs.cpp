@@ -5,15 +5,8 @@
 // all bin pairs runs on the GPU in one batch through include/defuse_mpe.h (no CPU fallback).
 // Iteration orders the reference leaves to boost::unordered_map are the canonical ascending-key
 // orders of SURVEY.md 8(c).
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include <chrono>
-#include <functional>
 #include <numeric>
-#include <thread>
 
 #include "../include/defuse_dsa.h"
 #include "../include/defuse_mpe.h"
@@ -169,59 +162,10 @@ int main(int argc, char* argv[])
     // parsed, then (with reference indices in order of first appearance over the whole file, as a serial reader gives
     // them) binned into bin pairs of its own; the pieces' bin pairs are joined in file order, so every list holds its
     // alignments in the order a single reader would have appended them.
-    // a file is mapped (the parsing threads fault its pages in side by side), stdin is collected in a plain buffer
-    struct Text {
-        char* p = nullptr;
-        size_t n = 0, cap = 0;
-        bool mapped = false;
-        const char* data() const { return p; }
-        size_t size() const { return n; }
-        char operator[](size_t k) const { return p[k]; }
-        void release()
-        {
-            if (mapped) munmap(p, n); else free(p);
-            p = nullptr; n = cap = 0;
-        }
-    } text;
-    if (cmd.str("align") != "-") {
-        const int fd = open(cmd.str("align").c_str(), O_RDONLY);
-        if (fd < 0) die("Error: Unable to open alignment file " + cmd.str("align"));
-        struct stat st;
-        if (fstat(fd, &st) != 0) die("Error: Unable to open alignment file " + cmd.str("align"));
-        if (S_ISREG(st.st_mode) && st.st_size > 0) {
-            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-            if (m == MAP_FAILED) die("Error: Unable to map alignment file " + cmd.str("align"));
-            text.p = (char*)m; text.n = (size_t)st.st_size; text.mapped = true;
-            close(fd);
-        } else {
-            FILE* in = fdopen(fd, "rb");
-            for (;;) {
-                if (text.cap - text.n < ((size_t)1 << 24)) {
-                    text.cap = std::max<size_t>(text.cap * 2, (size_t)1 << 26);
-                    text.p = (char*)realloc(text.p, text.cap);
-                    if (!text.p) die("Error: out of memory reading the alignments");
-                }
-                const size_t got = fread(text.p + text.n, 1, text.cap - text.n, in);
-                if (got == 0) break;
-                text.n += got;
-            }
-            fclose(in);
-        }
-    } else {
-        for (;;) {
-            if (text.cap - text.n < ((size_t)1 << 24)) {
-                text.cap = std::max<size_t>(text.cap * 2, (size_t)1 << 26);
-                text.p = (char*)realloc(text.p, text.cap);
-                if (!text.p) die("Error: out of memory reading the alignments");
-            }
-            const size_t got = fread(text.p + text.n, 1, text.cap - text.n, stdin);
-            if (got == 0) break;
-            text.n += got;
-        }
-    }
+    MappedText text;
+    text.load(cmd.str("align"), "Error: Unable to open alignment file ");
     stage("  input in memory");
-    unsigned nThreads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));       // profiles/microbench/cmp_threads.sh
-    if (const char* e = std::getenv("DEFUSE_THREADS")) nThreads = (unsigned)std::max(1, std::atoi(e));
+    unsigned nThreads = host_threads();
     if (text.size() < ((size_t)1 << 20)) nThreads = 1;
 
     auto line_end = [&](size_t pos) {                       // one past the line's newline (or the end of the text)
@@ -266,12 +210,7 @@ int main(int argc, char* argv[])
         std::vector<std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>>> binPairStore;
     };
     std::vector<Piece> pieces(nThreads);
-    auto run_threads = [&](const std::function<void(unsigned)>& fn) {
-        if (nThreads == 1) { fn(0); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nThreads; ++t) th.emplace_back(fn, t);
-        for (std::thread& x : th) x.join();
-    };
+    auto run_threads = [&](const std::function<void(unsigned)>& fn) { defuse::run_threads(nThreads, fn); };
 
     // CompactAlignmentStream + FragmentAlignmentStream (tools/AlignmentStream.cpp:156-221), one piece
     auto parse_piece = [&](unsigned t) {

@@ -5,6 +5,11 @@
 // to the reference tree).  The DP itself is NOT here: candidates are batched and handed to the HIP
 // library through include/defuse_dsa.h.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -13,12 +18,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -130,6 +137,88 @@ inline bool field_int(const char* p, size_t n, int& out)
     out = (int)v;
     return true;
 }
+
+// host threads of a tool: DEFUSE_THREADS, else 8 (profiles/microbench/cmp_threads.sh: beyond that the joins cost more than
+// the pieces save), never more than the machine has
+inline unsigned host_threads()
+{
+    if (const char* e = std::getenv("DEFUSE_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+    return std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+}
+inline void run_threads(unsigned n, const std::function<void(unsigned)>& fn)
+{
+    if (n <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n; ++t) th.emplace_back(fn, t);
+    for (std::thread& x : th) x.join();
+}
+
+// A whole text input in memory: a regular file is mapped (threads that parse pieces of it fault its pages in side by side),
+// anything else ("-" = stdin, pipes) is collected in a plain buffer.
+struct MappedText {
+    char* p = nullptr;
+    size_t n = 0, cap = 0;
+    bool mapped = false;
+    MappedText() = default;
+    MappedText(const MappedText&) = delete;
+    MappedText& operator=(const MappedText&) = delete;
+    ~MappedText() { release(); }
+    const char* data() const { return p; }
+    size_t size() const { return n; }
+    char operator[](size_t k) const { return p[k]; }
+    void release()
+    {
+        if (p) { if (mapped) munmap(p, n); else free(p); }
+        p = nullptr; n = cap = 0; mapped = false;
+    }
+    void load(const std::string& name, const std::string& open_error)
+    {
+        FILE* in = stdin;
+        if (name != "-") {
+            const int fd = open(name.c_str(), O_RDONLY);
+            if (fd < 0) die(open_error + name);
+            struct stat st;
+            if (fstat(fd, &st) != 0) die(open_error + name);
+            if (S_ISREG(st.st_mode) && st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (m == MAP_FAILED) die(open_error + name);
+                p = (char*)m; n = (size_t)st.st_size; mapped = true;
+                close(fd);
+                return;
+            }
+            in = fdopen(fd, "rb");
+        }
+        for (;;) {
+            if (cap - n < ((size_t)1 << 24)) {
+                cap = std::max<size_t>(cap * 2, (size_t)1 << 26);
+                p = (char*)realloc(p, cap);
+                if (!p) die("Error: out of memory reading " + name);
+            }
+            const size_t got = fread(p + n, 1, cap - n, in);
+            if (got == 0) break;
+            n += got;
+        }
+        if (in != stdin) fclose(in);
+    }
+    // one past the newline of the line that contains pos (or the end of the text)
+    size_t line_end(size_t pos) const
+    {
+        const char* nl = (const char*)memchr(p + pos, '\n', n - pos);
+        return nl ? (size_t)(nl - p) + 1 : n;
+    }
+    // [lo, hi) cut into `pieces` ranges that begin at line starts (lo must be one)
+    std::vector<size_t> cut_lines(size_t lo, size_t hi, unsigned pieces) const
+    {
+        std::vector<size_t> cut(pieces + 1, hi);
+        cut[0] = lo;
+        for (unsigned t = 1; t < pieces; ++t) {
+            size_t pos = std::max(cut[t - 1], lo + (hi - lo) / pieces * t);
+            if (pos > lo && pos < hi && p[pos - 1] != '\n') pos = std::min(hi, line_end(pos));
+            cut[t] = pos;
+        }
+        return cut;
+    }
+};
 
 // decimal text of an integer appended to a buffer (what operator<< prints for an int)
 inline void append_int(std::string& buf, long long v)

@@ -6,28 +6,13 @@
 #include "../include/defuse_sc.h"
 #include "defuse_host.hpp"
 
+#include <chrono>
+
 using namespace defuse;
 
 namespace {
 
 struct ClusterLine { int clusterID, clusterEnd, fragmentIndex; };
-
-// ClusterMembership line (tools/Parsers.cpp:36-78): at least three tab-separated fields, the first three integers
-void parse_cluster_line(const char* line, size_t len, int lineNumber, const std::string& filename, ClusterLine& out)
-{
-    if (len == 0) die("Error: Empty clusters line " + std::to_string(lineNumber) + " of " + filename);
-    const char* end = line + len;
-    const char* t1 = (const char*)memchr(line, '\t', len);
-    const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(end - t1 - 1)) : nullptr;
-    if (!t2) die("Error: Format error for clusters line " + std::to_string(lineNumber) + " of " + filename);
-    const char* t3 = (const char*)memchr(t2 + 1, '\t', (size_t)(end - t2 - 1));
-    if (!t3) t3 = end;
-    if (!field_int(line, (size_t)(t1 - line), out.clusterID) || !field_int(t1 + 1, (size_t)(t2 - t1 - 1), out.clusterEnd) ||
-        !field_int(t2 + 1, (size_t)(t3 - t2 - 1), out.fragmentIndex)) {
-        std::cerr << "Failed to interpret line:" << std::endl << std::string(line, len) << std::endl;
-        std::exit(1);
-    }
-}
 
 }  // namespace
 
@@ -41,50 +26,109 @@ int main(int argc, char* argv[])
     const std::string inName = cmd.str("clusters"), outName = cmd.str("outclust");
     const int minClusterSize = cmd.integer("minclustersize");
 
+    const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_stage = now();
+    auto stage = [&](const char* name) {
+        const double t = now();
+        if (timing) std::cerr << "[setcover] " << name << " " << (t - t_stage) << " s" << std::endl;
+        t_stage = t;
+    };
     std::cout << "Reading clusters" << std::endl;
-    // ReadClusters (tools/Parsers.cpp:23-84): cluster-end-0 lines only, clusters[id] in file order
-    std::vector<std::vector<int>> clusters;
-    {
-        FILE* in = fopen(inName.c_str(), "rb");
-        if (!in) die("Error: unable to read from clusters file " + inName);
-        LineReader reader(in);
-        const char* line;
-        size_t len;
-        int lineNumber = 0;
+    // ReadClusters (tools/Parsers.cpp:23-84): cluster-end-0 lines only, clusters[id] in file order.  The file is mapped and
+    // parsed in one piece per host thread; the pieces' (cluster, fragment) lists are laid out cluster by cluster in file order.
+    MappedText text;
+    text.load(inName, "Error: unable to read from clusters file ");
+    unsigned nThreads = host_threads();
+    if (text.size() < ((size_t)1 << 20)) nThreads = 1;
+    struct Piece {
+        std::vector<std::pair<int, int>> members;          // (cluster, fragment) of the end-0 lines, in order
+        size_t lines = 0, errorLine = 0;
+        int errorKind = 0;                                 // 1 empty line, 2 format, 3 not an integer, 4 negative cluster id
+        std::string errorText;
+        int maxCluster = -1;
+    };
+    std::vector<Piece> pieces(nThreads);
+    const std::vector<size_t> cut = text.cut_lines(0, text.size(), nThreads);
+    auto parse_line = [](const char* line, size_t len, ClusterLine& out) -> int {     // 0 ok, else the error kind
+        if (len == 0) return 1;
+        const char* end = line + len;
+        const char* t1 = (const char*)memchr(line, '\t', len);
+        const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(end - t1 - 1)) : nullptr;
+        if (!t2) return 2;
+        const char* t3 = (const char*)memchr(t2 + 1, '\t', (size_t)(end - t2 - 1));
+        if (!t3) t3 = end;
+        if (!field_int(line, (size_t)(t1 - line), out.clusterID) || !field_int(t1 + 1, (size_t)(t2 - t1 - 1), out.clusterEnd) ||
+            !field_int(t2 + 1, (size_t)(t3 - t2 - 1), out.fragmentIndex))
+            return 3;
+        return 0;
+    };
+    auto report = [&](int kind, size_t lineNumber, const std::string& lineText, const std::string& filename) {
+        if (kind == 1) die("Error: Empty clusters line " + std::to_string(lineNumber) + " of " + filename);
+        if (kind == 2) die("Error: Format error for clusters line " + std::to_string(lineNumber) + " of " + filename);
+        if (kind == 3) { std::cerr << "Failed to interpret line:" << std::endl << lineText << std::endl; std::exit(1); }
+        die("Error: Invalid cluster ID for line " + std::to_string(lineNumber) + " of " + filename);
+    };
+    run_threads(nThreads, [&](unsigned t) {
+        Piece& pc = pieces[t];
+        pc.members.reserve((cut[t + 1] - cut[t]) / 60 + 16);
         ClusterLine cl;
-        while (reader.next(line, len)) {
-            parse_cluster_line(line, len, ++lineNumber, inName, cl);
+        for (size_t pos = cut[t]; pos < cut[t + 1];) {
+            const size_t e = text.line_end(pos);
+            const char* line = text.data() + pos;
+            const size_t len = (e > pos && text[e - 1] == '\n') ? e - 1 - pos : e - pos;
+            pos = e;
+            ++pc.lines;
+            int kind = parse_line(line, len, cl);
+            if (!kind && cl.clusterEnd == 0 && cl.clusterID < 0) kind = 4;
+            if (kind) { pc.errorLine = pc.lines; pc.errorKind = kind; pc.errorText.assign(line, len); return; }
             if (cl.clusterEnd != 0) continue;
-            if (cl.clusterID < 0) die("Error: Invalid cluster ID for line " + std::to_string(lineNumber) + " of " + inName);
-            if ((int)clusters.size() < cl.clusterID + 1) clusters.resize(cl.clusterID + 1);
-            clusters[cl.clusterID].push_back(cl.fragmentIndex);
+            pc.maxCluster = std::max(pc.maxCluster, cl.clusterID);
+            pc.members.push_back(std::make_pair(cl.clusterID, cl.fragmentIndex));
         }
-        fclose(in);
+    });
+    {
+        size_t lineBase = 0;
+        for (const Piece& pc : pieces) {                     // the first bad line of the file, as a serial reader meets it
+            if (pc.errorLine) report(pc.errorKind, lineBase + pc.errorLine, pc.errorText, inName);
+            lineBase += pc.lines;
+        }
     }
+    int maxCluster = -1;
+    for (const Piece& pc : pieces) maxCluster = std::max(maxCluster, pc.maxCluster);
+    const size_t nClusters = (size_t)(maxCluster + 1);
+    stage("read");
 
     std::cout << "Calculating set cover solution" << std::endl;
     int maxElement = -1;                                  // FindMaxElement (tools/Common.cpp:71-89)
-    std::vector<int64_t> off(clusters.size() + 1, 0);
-    std::vector<int32_t> elements;
-    for (size_t c = 0; c < clusters.size(); ++c) {
-        for (int e : clusters[c]) {
-            if (e < 0) die("Error: negative elements not permitted");
-            maxElement = std::max(maxElement, e);
-            elements.push_back(e);
+    std::vector<int64_t> off(nClusters + 1, 0);
+    for (const Piece& pc : pieces)
+        for (const auto& m : pc.members) ++off[(size_t)m.first + 1];
+    for (size_t c = 0; c < nClusters; ++c) off[c + 1] += off[c];
+    std::vector<int32_t> elements((size_t)off[nClusters]);
+    {
+        std::vector<int64_t> at(off.begin(), off.end() - 1);
+        for (Piece& pc : pieces) {                            // pieces in file order: every cluster keeps its file order
+            for (const auto& m : pc.members) {
+                if (m.second < 0) die("Error: negative elements not permitted");
+                maxElement = std::max(maxElement, m.second);
+                elements[(size_t)at[m.first]++] = m.second;
+            }
+            std::vector<std::pair<int, int>>().swap(pc.members);
         }
-        off[c + 1] = (int64_t)elements.size();
     }
     std::vector<int32_t> owner((size_t)maxElement + 1, -1);
     if (!elements.empty()) {
         sc_timing t;
-        const int rc = sc_cover(dsa_pick_device(), off.data(), elements.data(), (int32_t)clusters.size(), maxElement,
+        const int rc = sc_cover(dsa_pick_device(), off.data(), elements.data(), (int32_t)nClusters, maxElement,
                                 owner.data(), &t);
         if (rc != 0) die(std::string("Error: set cover on the GPU failed: ") + sc_last_error());
         if (std::getenv("DEFUSE_TIMING"))
             std::cerr << "[setcover] components " << t.n_components << " (large " << t.n_large << "), build " << t.build_ms
                       << " ms, components " << t.components_ms << " ms, greedy " << t.greedy_ms << " ms" << std::endl;
     }
-    std::vector<int64_t> solutionSize(clusters.size(), 0);
+    stage("set cover");
+    std::vector<int64_t> solutionSize(nClusters, 0);
     for (int32_t o : owner)
         if (o >= 0) ++solutionSize[o];
 
@@ -93,28 +137,45 @@ int main(int argc, char* argv[])
     // assigned to the line's cluster, for clusters that kept at least minClusterSize fragments
     std::ofstream out(outName.c_str());
     if (!out) die("Error: unable to write to clusters file " + outName);
-    FILE* in = fopen(inName.c_str(), "rb");
-    if (!in) die("Error: unable to read from clusters file " + inName);
-    LineReader reader(in);
-    const char* line;
-    size_t len;
-    int lineNumber = 0;
-    ClusterLine cl;
-    std::string buf;
-    buf.reserve((1u << 22) + 4096);
-    while (reader.next(line, len)) {
-        parse_cluster_line(line, len, ++lineNumber, outName, cl);
-        if (cl.clusterID < 0) die("Error: Invalid cluster ID for line " + std::to_string(lineNumber) + " of " + outName);
-        if ((size_t)cl.clusterID >= clusters.size()) continue;            // an id that only occurs with end 1 (UB in the reference)
-        if ((int64_t)solutionSize[cl.clusterID] < (int64_t)minClusterSize) continue;
-        if (cl.fragmentIndex >= 0 && cl.fragmentIndex <= maxElement && owner[cl.fragmentIndex] == cl.clusterID) {
-            buf.append(line, len);
-            buf += '\n';
-            if (buf.size() > (1u << 22)) { out.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
+    // the lines are filtered in rounds of 256 MiB of input, each cut into one piece per host thread; texts written in order
+    std::vector<std::string> texts(nThreads);
+    std::vector<Piece> round(nThreads);
+    size_t lineBase = 0;
+    for (size_t lo = 0; lo < text.size();) {
+        size_t hi = std::min(text.size(), lo + ((size_t)1 << 28));
+        if (hi < text.size()) hi = text.line_end(hi - 1);
+        const std::vector<size_t> rc = text.cut_lines(lo, hi, nThreads);
+        run_threads(nThreads, [&](unsigned t) {
+            Piece& pc = round[t];
+            pc = Piece();
+            std::string& buf = texts[t];
+            buf.clear();
+            ClusterLine cl;
+            for (size_t pos = rc[t]; pos < rc[t + 1];) {
+                const size_t e = text.line_end(pos);
+                const char* line = text.data() + pos;
+                const size_t len = (e > pos && text[e - 1] == '\n') ? e - 1 - pos : e - pos;
+                pos = e;
+                ++pc.lines;
+                int kind = parse_line(line, len, cl);
+                if (!kind && cl.clusterID < 0) kind = 4;
+                if (kind) { pc.errorLine = pc.lines; pc.errorKind = kind; pc.errorText.assign(line, len); return; }
+                if ((size_t)cl.clusterID >= nClusters) continue;            // an id that only occurs with end 1 (UB in the reference)
+                if ((int64_t)solutionSize[cl.clusterID] < (int64_t)minClusterSize) continue;
+                if (cl.fragmentIndex >= 0 && cl.fragmentIndex <= maxElement && owner[cl.fragmentIndex] == cl.clusterID) {
+                    buf.append(line, len);
+                    buf += '\n';
+                }
+            }
+        });
+        for (unsigned t = 0; t < nThreads; ++t) {
+            if (round[t].errorLine) report(round[t].errorKind, lineBase + round[t].errorLine, round[t].errorText, outName);
+            lineBase += round[t].lines;
+            out.write(texts[t].data(), (std::streamsize)texts[t].size());
         }
+        lo = hi;
     }
-    out.write(buf.data(), (std::streamsize)buf.size());
-    fclose(in);
+    stage("write");
     out.close();
     return out.good() ? 0 : 1;
 }
