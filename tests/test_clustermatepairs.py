@@ -117,3 +117,34 @@ def test_tool_large_bin_pairs(built, tmp_path):
         r, txt = run_tool(lines, tmp_path, m=3, env={"DEFUSE_MPE_WAVE_MIN": wave_min})
         assert r.returncode == 0, r.stderr
         assert txt == exp, "DEFUSE_MPE_WAVE_MIN=" + wave_min
+
+
+@pytest.mark.parametrize("seed", [3, 6])
+def test_host_stages_same_for_every_thread_count(built, tmp_path, seed):
+    """No GPU needed: DEFUSE_CMP_DUMP_PROBLEMS writes what the host stages hand to the device (bin pairs in canonical order,
+    mate pair coordinates, sort ranks, alignment tables) and stops.  Pieces cut at fragment boundaries, parsed and binned side
+    by side, must give the bytes a single reader gives — also when there are more threads than fragments."""
+    from defuse_amd import build
+    build.build_tools()
+    lines = cmp_cases.many_loci(seed)
+    dumps = []
+    for threads in ("1", "2", "3", "7", "16", "300"):
+        dump = tmp_path / ("dump." + threads)
+        r, _ = run_tool(lines, tmp_path, env={"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(dump)})
+        assert r.returncode == 0, r.stderr
+        dumps.append(dump.read_bytes())
+    assert len(dumps[0]) > 1000
+    assert all(d == dumps[0] for d in dumps[1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_tool_matches_oracle_threads(built, tmp_path, threads):
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = cmp_cases.many_loci(8)
+    r, txt = run_tool(lines, tmp_path, env={"DEFUSE_THREADS": threads})
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert n >= 5 and txt == exp

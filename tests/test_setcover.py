@@ -91,7 +91,9 @@ def test_gpu_cover_matches_oracle(built, seed, big):
 
 
 @pytest.mark.gpu
-def test_setcover_tool_matches_oracle(built, tmp_path):
+@pytest.mark.parametrize("threads", [None, "1", "7", "200"])
+def test_setcover_tool_matches_oracle(built, tmp_path, threads):
+    import os
     from defuse_amd import build
     from oracle import setcover_oracle as o
     build.build_tools()
@@ -99,7 +101,8 @@ def test_setcover_tool_matches_oracle(built, tmp_path):
     p = tmp_path / "clusters.txt"
     write_cluster_file(p, clusters)
     outp = tmp_path / "clusters.sc"
-    r = subprocess.run([TOOL, "-c", str(p), "-m", "3", "-o", str(outp)], capture_output=True, text=True)
+    env = dict(os.environ, DEFUSE_THREADS=threads) if threads else None        # host pieces: one, several, more than lines
+    r = subprocess.run([TOOL, "-c", str(p), "-m", "3", "-o", str(outp)], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     assert r.stdout == "Reading clusters\nCalculating set cover solution\nWriting out clusters\n"
     exp = o.setcover(str(p), 3)

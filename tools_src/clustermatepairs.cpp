@@ -166,7 +166,7 @@ int main(int argc, char* argv[])
     text.load(cmd.str("align"), "Error: Unable to open alignment file ");
     stage("  input in memory");
     unsigned nThreads = host_threads();
-    if (text.size() < ((size_t)1 << 20)) nThreads = 1;
+    if (text.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nThreads = 1;      // small inputs: threads only on request (tests)
 
     auto line_end = [&](size_t pos) {                       // one past the line's newline (or the end of the text)
         const char* nl = (const char*)memchr(text.data() + pos, '\n', text.size() - pos);

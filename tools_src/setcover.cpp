@@ -40,7 +40,7 @@ int main(int argc, char* argv[])
     MappedText text;
     text.load(inName, "Error: unable to read from clusters file ");
     unsigned nThreads = host_threads();
-    if (text.size() < ((size_t)1 << 20)) nThreads = 1;
+    if (text.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nThreads = 1;      // small inputs: threads only on request (tests)
     struct Piece {
         std::vector<std::pair<int, int>> members;          // (cluster, fragment) of the end-0 lines, in order
         size_t lines = 0, errorLine = 0;
