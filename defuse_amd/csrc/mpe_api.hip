@@ -18,13 +18,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/defuse_mpe.h"
 
 namespace {
 
-std::string g_mpe_err;
+thread_local std::string g_mpe_err;     // per host thread: the sharded call runs one per device
+std::string g_mpe_err_sharded;
 
 #define MPE_HIP(call)                                                                             \
     do {                                                                                          \
@@ -961,7 +963,7 @@ struct DBuf {
 
 }  // namespace
 
-extern "C" const char* mpe_last_error(void) { return g_mpe_err.c_str(); }
+extern "C" const char* mpe_last_error(void) { return g_mpe_err.empty() ? g_mpe_err_sharded.c_str() : g_mpe_err.c_str(); }
 
 extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int64_t* prob_off, int32_t n_problems,
                                  const double* x, const double* y, const double* u, const int32_t* to_xo,
@@ -1123,6 +1125,54 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
 
     t.em_iterations = (int64_t)it;
     for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;
+    if (timing) *timing = t;
+    return 0;
+}
+
+extern "C" int mpe_cluster_batch_sharded(const int* devices, int32_t n_devices, const mpe_params* params, const int64_t* prob_off,
+                                         int32_t n_problems, const double* x, const double* y, const double* u,
+                                         const int32_t* to_xo, const int32_t* to_yo, int32_t* n_clusters, uint16_t* member,
+                                         int32_t* status, mpe_timing* timing)
+{
+    if (!devices || n_devices < 1 || !params || n_problems < 0 || (n_problems && !prob_off)) { g_mpe_err = "bad arguments"; return -3; }
+    if (n_devices == 1 || n_problems == 0)
+        return mpe_cluster_batch(devices[0], params, prob_off, n_problems, x, y, u, to_xo, to_yo, n_clusters, member, status, timing);
+    // contiguous shares of about equal mate pair count
+    std::vector<int32_t> cut((size_t)n_devices + 1, n_problems);
+    cut[0] = 0;
+    const int64_t total = prob_off[n_problems];
+    for (int k = 1; k < n_devices; ++k) {
+        const int64_t want = total / n_devices * k;
+        int32_t at = (int32_t)(std::lower_bound(prob_off, prob_off + n_problems + 1, want) - prob_off);
+        cut[k] = std::min(std::max(at, cut[k - 1]), n_problems);
+    }
+    std::vector<mpe_timing> tm((size_t)n_devices);
+    std::vector<int> rc((size_t)n_devices, 0);
+    std::vector<std::string> err((size_t)n_devices);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_devices; ++k)
+        th.emplace_back([&, k]() {
+            const int32_t p0 = cut[k], p1 = cut[k + 1];
+            tm[k] = mpe_timing{};
+            if (p1 == p0) return;
+            const int64_t base = prob_off[p0];
+            std::vector<int64_t> off((size_t)(p1 - p0) + 1);
+            for (int32_t p = p0; p <= p1; ++p) off[(size_t)(p - p0)] = prob_off[p] - base;
+            rc[k] = mpe_cluster_batch(devices[k], params, off.data(), p1 - p0, x + base, y + base, u + base, to_xo + base, to_yo + base,
+                                      n_clusters + p0, member + base, status + p0, &tm[k]);
+            if (rc[k]) err[k] = g_mpe_err;
+        });
+    for (std::thread& t : th) t.join();
+    mpe_timing t{};
+    t.n_problems = n_problems;
+    t.n_mate_pairs = total;
+    for (int k = 0; k < n_devices; ++k) {
+        if (rc[k]) { g_mpe_err.clear(); g_mpe_err_sharded = "share " + std::to_string(k) + " on device " + std::to_string(devices[k]) + ": " + err[k]; return rc[k]; }
+        t.kernel_ms = std::max(t.kernel_ms, tm[k].kernel_ms);
+        t.em_iterations += tm[k].em_iterations;
+        t.n_failed += tm[k].n_failed;
+        t.n_wave_problems += tm[k].n_wave_problems;
+    }
     if (timing) *timing = t;
     return 0;
 }

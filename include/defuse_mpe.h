@@ -51,6 +51,14 @@ typedef struct mpe_timing {
 int mpe_cluster_batch(int device, const mpe_params* params, const int64_t* prob_off, int32_t n_problems,
                       const double* x, const double* y, const double* u, const int32_t* to_xo, const int32_t* to_yo,
                       int32_t* n_clusters, uint16_t* member, int32_t* status, mpe_timing* timing);
+/* The same over several GPUs of the node (bin pairs are independent): the problems are cut into n_devices
+ * contiguous shares of about equal mate pair count, share k runs on HIP device devices[k] from a host thread of its own, and
+ * the results land in the caller's arrays exactly as one call would have left them (cluster numbering is the caller's
+ * prefix sum over n_clusters, so it does not depend on the shares).  A device may be named more than once.  timing->kernel_ms
+ * is the longest share's. */
+int mpe_cluster_batch_sharded(const int* devices, int32_t n_devices, const mpe_params* params, const int64_t* prob_off,
+                              int32_t n_problems, const double* x, const double* y, const double* u, const int32_t* to_xo,
+                              const int32_t* to_yo, int32_t* n_clusters, uint16_t* member, int32_t* status, mpe_timing* timing);
 const char* mpe_last_error(void);
 
 #ifdef __cplusplus

@@ -148,3 +148,20 @@ def test_tool_matches_oracle_threads(built, tmp_path, threads):
     assert r.returncode == 0, r.stderr
     exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
     assert n >= 5 and txt == exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", ["0,0,0", "2", "all"])
+def test_tool_shares_bin_pairs_over_devices(built, tmp_path, gpus):
+    """DEFUSE_GPUS: the bin pairs go to several devices in contiguous shares (here every share lands on the box's one GPU,
+    from host threads of their own); the cluster file must not depend on the shares."""
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = cmp_cases.many_loci(9)
+    r, txt = run_tool(lines, tmp_path, env={"DEFUSE_GPUS": gpus, "DEFUSE_TIMING": "1"})
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert n >= 5 and txt == exp
+    shares = {"0,0,0": "3 device share(s)", "2": "2 device share(s)", "all": "device share(s)"}[gpus]
+    assert shares in r.stderr

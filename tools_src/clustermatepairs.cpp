@@ -549,12 +549,24 @@ int main(int argc, char* argv[])
     std::vector<uint16_t> member(X.size(), 0);
     if (!problems.empty()) {
         mpe_timing t;
-        const int rc = mpe_cluster_batch(dsa_pick_device(), &prm, probOff.data(), (int32_t)problems.size(), X.data(), Y.data(),
-                                         U.data(), toXO.data(), toYO.data(), nClusters.data(), member.data(), status.data(), &t);
+        // DEFUSE_GPUS = "all", a count, or a list of device ordinals: the bin pairs are shared out over those GPUs
+        // (bin pairs are independent); otherwise one GPU as for every tool (DEFUSE_GPU / pid mod count)
+        std::vector<int> devices;
+        if (const char* g = std::getenv("DEFUSE_GPUS")) {
+            const std::string spec = g;
+            const int have = dsa_device_count();
+            if (spec == "all") for (int d = 0; d < have; ++d) devices.push_back(d);
+            else if (spec.find(',') != std::string::npos) for (const std::string& f : split_tabs(spec, ',')) devices.push_back(std::atoi(f.c_str()));
+            else for (int d = 0; d < std::atoi(spec.c_str()); ++d) devices.push_back(have > 0 ? d % have : d);
+        }
+        if (devices.empty()) devices.push_back(dsa_pick_device());
+        const int rc = mpe_cluster_batch_sharded(devices.data(), (int32_t)devices.size(), &prm, probOff.data(), (int32_t)problems.size(),
+                                                 X.data(), Y.data(), U.data(), toXO.data(), toYO.data(), nClusters.data(), member.data(),
+                                                 status.data(), &t);
         if (rc != 0) die(std::string("Error: mate pair clustering on the GPU failed: ") + mpe_last_error());
         if (std::getenv("DEFUSE_TIMING"))
             std::cerr << "[clustermatepairs] " << t.n_problems << " bin pairs, " << t.n_mate_pairs << " mate pairs, " << t.em_iterations
-                      << " EM iterations, " << t.n_wave_problems << " bin pairs with a wave per fit, kernel " << t.kernel_ms << " ms" << std::endl;
+                      << " EM iterations, " << t.n_wave_problems << " bin pairs with a wave per fit, " << devices.size() << " device share(s), kernel " << t.kernel_ms << " ms" << std::endl;
         for (size_t p = 0; p < problems.size(); ++p)
             if (status[p]) die("Error: a consistency check of the mate pair clusterer failed (DebugCheck in the reference)");
     }
