@@ -41,6 +41,24 @@ def measured_traffic(args):
     return d["hbm_bytes_per_launch"], "profiles/r01/pmc_traffic.json"
 
 
+def valu_issue(args, launch_ms):
+    """The roofline that binds this integer kernel (not HBM, not MFMA): VALU issue.  Wave instructions per
+    launch come from the committed SQ counter passes of this very workload (SQ_INSTS_VALU, profiles/r01/pmc_sq.json: one
+    quad-cycle of issue per wave instruction whatever its kind); the duration is the live HIP-event time of this run; the
+    peak is 256 CUs x 4 SIMDs x one wave instruction per 4 cycles at the 2.4 GHz nominal clock."""
+    if (args.fusions, args.reads, args.lq, args.lr) != (10000, 100, 76, 389):
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_sq.json")))
+    except OSError:
+        return None
+    instr = d["pass1"]["SQ_INSTS_VALU"] / d["launches"]
+    peak = 256 * 4 * 2.4e9 / 4
+    achieved = instr / (launch_ms * 1e-3)
+    return {"achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": achieved / peak,
+            "valu_instructions_per_launch": instr, "source": "profiles/r01/pmc_sq.json (SQ_INSTS_VALU) / live kernel_ms"}
+
+
 def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
     """Times the CPU oracle (a literal port of the reference's algorithm, oracle/dsa_oracle.c) on a
     bounded sample of the same workload: one thread per host core this process may use (the way deFuse
@@ -200,6 +218,7 @@ def main():
                          "kernel": "k_fill_fast", "kernel_ms": launch_ms,
                          "algorithmic_bytes_per_align": round(bytes_per_align, 2),
                          "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
+                         "valu_issue": valu_issue(args, launch_ms),
                          "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)): "
                                  "profiles/r01/pmc_sq.json has the kernel at 0.81 of the VALU issue slots of a nominal 2.4 GHz clock; "
                                  "traffic >> algorithmic bytes because tile checkpoints and tile maxima "
