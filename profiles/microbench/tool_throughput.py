@@ -30,6 +30,19 @@ def main():
     print("dosplitalign: rc %d, %.2f s wall, %d alignment lines" % (p.returncode, dt, n))
     print(p.stdout[-600:])
     print(p.stderr[-600:])
+    # the pipeline's next steps: sort -n -k 1 (scripts/defuse_run.pl:528) and evalsplitalign
+    srt = out + ".sorted"
+    t0 = time.time()
+    subprocess.run("LC_ALL=C sort -n -k 1 %s > %s" % (out, srt), shell=True, check=True)
+    print("sort: %.2f s" % (time.time() - t0))
+    a = ["-f", case["fasta"], "-e", case["exons"], "-u", str(case["ufrag"]), "-s", str(case["sfrag"]), "-n", str(case["minread"]),
+         "-x", str(case["maxread"]), "-r", case["regions"], "-a", srt, "-q", os.path.join(d, "seq.txt"), "-b", os.path.join(d, "break.txt"),
+         "-p", os.path.join(d, "predalign.txt")]
+    t0 = time.time()
+    p = subprocess.run(["bin/evalsplitalign"] + a, capture_output=True, text=True)
+    print("evalsplitalign: rc %d, %.2f s wall, %d break lines" % (p.returncode, time.time() - t0,
+          sum(1 for _ in open(os.path.join(d, "break.txt"))) if p.returncode == 0 else -1))
+    print(p.stderr[-300:])
 
 
 if __name__ == "__main__":

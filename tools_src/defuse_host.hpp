@@ -744,8 +744,49 @@ private:
     std::vector<Region> regions_;
 };
 
+// The reads of both FASTQ files by ReadID (fragment index, read end): sequences in one byte pool, found through a table
+// indexed by 2*fragment + end (fragment indices are the running numbers scripts/index_paired_fastq.pl gives the reads;
+// an index beyond 2^28 goes to a hash map instead).  A later read of the same id replaces the earlier one, as
+// `reads[id] = sequence` does in the reference (tools/SplitAlignment.cpp:253-264).
+class ReadStore {
+public:
+    void put(int frag, int end, const char* s, size_t n)
+    {
+        const uint64_t v = ((uint64_t)pool_.size() << 24) | (uint64_t)n;
+        pool_.insert(pool_.end(), s, s + n);
+        if (frag >= 0 && frag < (1 << 28)) {
+            const size_t k = (size_t)frag * 2 + (size_t)end;
+            if (k >= dense_.size()) dense_.resize(std::max(k + 1, dense_.size() * 2), NONE);
+            dense_[k] = v;
+        } else {
+            sparse_[pack_id(frag, end)] = v;
+        }
+    }
+    // false: no such read (it then aligns as the empty string, tools/SplitAlignment.cpp:286)
+    bool get(int frag, int end, const char*& s, size_t& n) const
+    {
+        uint64_t v = NONE;
+        if (frag >= 0 && frag < (1 << 28)) {
+            const size_t k = (size_t)frag * 2 + (size_t)end;
+            if (k < dense_.size()) v = dense_[k];
+        } else {
+            auto it = sparse_.find(pack_id(frag, end));
+            if (it != sparse_.end()) v = it->second;
+        }
+        if (v == NONE) return false;
+        s = pool_.data() + (v >> 24);
+        n = (size_t)(v & 0xFFFFFF);
+        return true;
+    }
+private:
+    static constexpr uint64_t NONE = ~(uint64_t)0;
+    std::vector<char> pool_;
+    std::vector<uint64_t> dense_;
+    std::unordered_map<int, uint64_t> sparse_;
+};
+
 // FASTQ: tools/ReadStream.cpp:18-32 (extension check), :57-104 (record parsing), AddReads SplitAlignment.cpp:253-264
-inline bool AddReads(const std::string& filename, std::unordered_map<int, std::string>& reads)
+inline bool AddReads(const std::string& filename, ReadStore& reads)
 {
     const size_t dot = filename.find_last_of('.');
     const std::string ext = filename.substr(dot + 1);
@@ -753,28 +794,90 @@ inline bool AddReads(const std::string& filename, std::unordered_map<int, std::s
         std::cerr << "Error: unrecognized extension " << ext << std::endl;
         return false;
     }
-    std::ifstream in(filename.c_str());
-    if (!in.good()) {
+    FILE* in = fopen(filename.c_str(), "rb");
+    if (!in) {
         std::cerr << "Error: unable to open file " << filename << std::endl;
         return false;
     }
-    std::string l[4];
+    LineReader reader(in);
+    std::string name, sequence;
     for (;;) {
-        int n = 0;
-        while (n < 4 && std::getline(in, l[n])) ++n;
-        if (n < 4) break;
-        if (l[0].empty() || l[0][0] != '@') { std::cerr << "Error: Unable to interpret read name " << l[0] << std::endl; break; }
-        const size_t slash = l[0].find_first_of('/');
-        const char endc = (slash != std::string::npos && slash + 1 < l[0].size()) ? l[0][slash + 1] : '\0';
-        if (endc != '1' && endc != '2') { std::cerr << "Error: Unable to interpret read end " << l[0] << std::endl; break; }
-        const int frag = lexical_int_or_die(l[0].substr(1, slash - 1), "in read name " + l[0]);
-        reads[pack_id(frag, endc == '1' ? 0 : 1)] = l[1];
+        const char* l;
+        size_t n;
+        if (!reader.next(l, n)) break;                     // records of four lines; an incomplete one ends the file
+        name.assign(l, n);
+        if (!reader.next(l, n)) break;
+        sequence.assign(l, n);
+        if (!reader.next(l, n) || !reader.next(l, n)) break;
+        if (name.empty() || name[0] != '@') { std::cerr << "Error: Unable to interpret read name " << name << std::endl; break; }
+        const size_t slash = name.find_first_of('/');
+        const char endc = (slash != std::string::npos && slash + 1 < name.size()) ? name[slash + 1] : '\0';
+        if (endc != '1' && endc != '2') { std::cerr << "Error: Unable to interpret read end " << name << std::endl; break; }
+        int frag;
+        if (!field_int(name.data() + 1, slash - 1, frag)) die("Error: bad integer '" + name.substr(1, slash - 1) + "' in read name " + name);
+        if (sequence.size() >= ((size_t)1 << 24)) die("Error: read longer than 16 M bases: " + name);
+        reads.put(frag, endc == '1' ? 0 : 1, sequence.data(), sequence.size());
     }
+    fclose(in);
     return true;
 }
 
 // One record of the improper SAM: tools/AlignmentStream.cpp:39-130
 struct RawAlignment { std::string fragment, reference; int readEnd = 0, strand = 0; Region region; };
+// One SAM line (tools/AlignmentStream.cpp:39-130).  Returns 0 = a record, 1 = nothing to return (header line, rname "*"),
+// 2.. = the reference dies: 2 empty line, 3 fewer than ten fields, 4 flag or position not an integer, 5 qname "x/y" with y
+// not 1 or 2.  read_end is left alone when neither the name nor the flag bits tell it (the reference's object keeps the
+// previous record's value); fragment points into the line.
+struct SamFields { const char* fragment; size_t fragment_len; const char* reference; size_t reference_len; int strand; Region region; };
+inline int ParseSamLine(const char* line, size_t len, SamFields& a, int& read_end)
+{
+    if (len == 0) return 2;
+    if (line[0] == '@') return 1;
+    const char* fs[11];
+    int nf = 0;
+    fs[nf++] = line;
+    const char* end = line + len;
+    for (const char* p = line; nf < 11;) {
+        const char* tab = (const char*)memchr(p, '\t', (size_t)(end - p));
+        if (!tab) break;
+        fs[nf++] = p = tab + 1;
+    }
+    if (nf < 10) return 3;
+    if (nf < 11) fs[10] = end + 1;                                   // field k is [fs[k], fs[k+1] - 1)
+    auto flen = [&](int k) { return (size_t)(fs[k + 1] - 1 - fs[k]); };
+    int flag, pos;
+    if (!field_int(fs[1], flen(1), flag) || !field_int(fs[3], flen(3), pos)) return 4;
+    if (flen(2) == 1 && fs[2][0] == '*') return 1;
+    a.strand = (flag & 0x10) ? MinusStrand : PlusStrand;
+    // qname split at '/': exactly two parts name the read end, anything else leaves it to the flag bits
+    const char* slash = (const char*)memchr(fs[0], '/', flen(0));
+    const bool two_parts = slash && !memchr(slash + 1, '/', (size_t)(fs[0] + flen(0) - slash - 1));
+    if (two_parts) {
+        const size_t tail = (size_t)(fs[0] + flen(0) - slash - 1);
+        if (tail != 1 || (slash[1] != '1' && slash[1] != '2')) return 5;
+        a.fragment = fs[0];
+        a.fragment_len = (size_t)(slash - fs[0]);
+        read_end = (slash[1] == '1') ? 0 : 1;
+    } else {
+        a.fragment = fs[0];
+        a.fragment_len = flen(0);
+        if (flag & 0x40) read_end = 0;
+        else if (flag & 0x80) read_end = 1;
+    }
+    a.reference = fs[2];
+    a.reference_len = flen(2);
+    a.region.start = pos;
+    a.region.end = pos + (int)flen(9) - 1;
+    return 0;
+}
+[[noreturn]] inline void DieSamLine(int kind, size_t line_no)
+{
+    if (kind == 2) die("Error: Empty alignment line " + std::to_string(line_no));
+    if (kind == 3) die("Error: Format error for alignment line " + std::to_string(line_no));
+    if (kind == 4) die("Error: bad integer in sam line " + std::to_string(line_no));        // reference: uncaught bad_lexical_cast
+    die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no));
+}
+
 class SamAlignmentStream {
 public:
     explicit SamAlignmentStream(const std::string& filename)
@@ -790,45 +893,16 @@ public:
     {
         const char* line;
         size_t len;
+        SamFields f;
         while (reader_->next(line, len)) {
             ++line_no_;
-            if (len == 0) die("Error: Empty alignment line " + std::to_string(line_no_));
-            if (line[0] == '@') continue;
-            // fields in place: field k is [fs[k], fs[k+1] - 1); at least 10 are needed, the tenth (SEQ) ends at the next tab
-            const char* fs[11];
-            int nf = 0;
-            fs[nf++] = line;
-            const char* end = line + len;
-            for (const char* p = line; nf < 11;) {
-                const char* tab = (const char*)memchr(p, '\t', (size_t)(end - p));
-                if (!tab) break;
-                fs[nf++] = p = tab + 1;
-            }
-            if (nf < 10) die("Error: Format error for alignment line " + std::to_string(line_no_));
-            if (nf < 11) fs[10] = end + 1;
-            auto flen = [&](int k) { return (size_t)(fs[k + 1] - 1 - fs[k]); };
-            int flag, pos;
-            if (!field_int(fs[1], flen(1), flag) || !field_int(fs[3], flen(3), pos))
-                die("Error: bad integer in sam line " + std::to_string(line_no_));        // reference: uncaught bad_lexical_cast
-            if (flen(2) == 1 && fs[2][0] == '*') continue;
-            a.strand = (flag & 0x10) ? MinusStrand : PlusStrand;
-            // qname split at '/': exactly two parts name the read end, anything else leaves it to the flag bits
-            const char* slash = (const char*)memchr(fs[0], '/', flen(0));
-            const bool two_parts = slash && !memchr(slash + 1, '/', (size_t)(fs[0] + flen(0) - slash - 1));
-            if (two_parts) {
-                const size_t tail = (size_t)(fs[0] + flen(0) - slash - 1);
-                if (tail != 1 || (slash[1] != '1' && slash[1] != '2'))
-                    die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no_));
-                a.fragment.assign(fs[0], (size_t)(slash - fs[0]));
-                a.readEnd = (slash[1] == '1') ? 0 : 1;
-            } else {
-                a.fragment.assign(fs[0], flen(0));
-                if (flag & 0x40) a.readEnd = 0;
-                else if (flag & 0x80) a.readEnd = 1;
-            }
-            a.reference.assign(fs[2], flen(2));
-            a.region.start = pos;
-            a.region.end = pos + (int)flen(9) - 1;
+            const int kind = ParseSamLine(line, len, f, a.readEnd);
+            if (kind == 1) continue;
+            if (kind) DieSamLine(kind, (size_t)line_no_);
+            a.fragment.assign(f.fragment, f.fragment_len);
+            a.reference.assign(f.reference, f.reference_len);
+            a.strand = f.strand;
+            a.region = f.region;
             return true;
         }
         return false;

@@ -53,7 +53,7 @@ int main(int argc, char* argv[])
             for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id(kv.first, ce), loc);
 
     stage("regions + windows");
-    std::unordered_map<int, std::string> reads;
+    ReadStore reads;
     if (!AddReads(cmd.str("seq1"), reads) || !AddReads(cmd.str("seq2"), reads)) {
         std::cout << "Error: unable to read sequences" << std::endl;
         return 1;
@@ -141,50 +141,115 @@ int main(int argc, char* argv[])
         fusion_index.clear();
     };
 
-    SamAlignmentStream sam(cmd.str("improper"));
-    RawAlignment mate;
-    std::vector<int> overlapping;
+    // SplitReadRealigner::DoAlignment (tools/SplitAlignment.cpp:266-303).  The SAM text is mapped and taken in rounds of
+    // 256 MiB, each cut into one piece per host thread: the pieces parse their records and look up the mate regions they
+    // overlap side by side; the candidates are then taken up in file order by one thread (the seen-set, the batches and the
+    // output are sequential by nature).
+    MappedText sam;
+    sam.load(cmd.str("improper"), "Error: Unable to open sam file ");
+    unsigned nThreads = host_threads();
+    if (sam.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nThreads = 1;
+    struct Hit { int frag, readEnd; uint32_t first, count; };           // readEnd -1: inherited from before the piece
+    struct SamPiece {
+        std::vector<Hit> hits;
+        std::vector<int> ids;
+        size_t lines = 0, errorLine = 0;
+        int errorKind = 0, lastReadEnd = -2;                             // -2: no record of the piece set the read end
+        std::string errorText;
+    };
+    std::vector<SamPiece> pieces(nThreads);
     std::string seq;
-    while (sam.GetNextAlignment(mate)) {
-        binned.Overlapping(mate.reference, mate.strand, mate.region, overlapping);   // ascending signed order: end-1 ids (negative) first
-        int frag = 0;
-        if (!overlapping.empty()) frag = lexical_int_or_die(mate.fragment, "as fragment name");
-        for (int cid : overlapping) {
-            const int cluster_end = cid < 0 ? 1 : 0;
-            const int fusion_id = cid & 0x7FFFFFFF;
-            const int read_end = (mate.readEnd == 0) ? 1 : 0;
-            const int revcomp = (cluster_end == 0) ? 1 : 0;
-            const int rid = pack_id(frag, read_end);
-            if (!candidate_unique.insert(((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp).second) continue;
-            auto rd = reads.find(rid);             // a missing read aligns as the empty string (operator[] in the reference, :286)
-            seq.assign(rd == reads.end() ? std::string() : rd->second);
-            if (revcomp) ReverseComplement(seq);
-            auto fi = fusion_index.find(fusion_id);
-            if (fi == fusion_index.end()) {
-                const SplitAlignmentTask& t = tasks[fusion_id];
-                dsa_fusion f;
-                f.fusion_id = fusion_id;
-                f.ref0_off = (int32_t)ref_bytes.size();
-                f.ref0_len = (int32_t)t.mSplitAlignSeq[0].size();
-                ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
-                f.ref1_off = (int32_t)ref_bytes.size();
-                f.ref1_len = (int32_t)t.mSplitAlignSeq[1].size();
-                ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
-                fi = fusion_index.emplace(fusion_id, (int)fusions.size()).first;
-                fusions.push_back(f);
+    size_t lineBase = 0;
+    int carryReadEnd = 0;                                                // RawAlignment's initial read end
+    for (size_t lo = 0; lo < sam.size();) {
+        size_t hi = std::min(sam.size(), lo + ((size_t)1 << 28));
+        if (hi < sam.size()) hi = sam.line_end(hi - 1);
+        const std::vector<size_t> cut = sam.cut_lines(lo, hi, nThreads);
+        run_threads(nThreads, [&](unsigned t) {
+            SamPiece& pc = pieces[t];
+            pc = SamPiece();
+            std::vector<int> overlapping;
+            std::string reference;
+            SamFields f;
+            int readEnd = -1;
+            for (size_t pos = cut[t]; pos < cut[t + 1];) {
+                const size_t e = sam.line_end(pos);
+                const char* line = sam.data() + pos;
+                const size_t len = (e > pos && sam[e - 1] == '\n') ? e - 1 - pos : e - pos;
+                pos = e;
+                ++pc.lines;
+                const int kind = ParseSamLine(line, len, f, readEnd);
+                if (kind == 1) continue;
+                if (kind) { pc.errorLine = pc.lines; pc.errorKind = kind; return; }
+                reference.assign(f.reference, f.reference_len);
+                binned.Overlapping(reference, f.strand, f.region, overlapping);   // ascending signed order: end-1 ids (negative) first
+                if (overlapping.empty()) continue;
+                Hit h;
+                if (!field_int(f.fragment, f.fragment_len, h.frag)) {
+                    pc.errorLine = pc.lines; pc.errorKind = 6; pc.errorText.assign(f.fragment, f.fragment_len);
+                    return;
+                }
+                h.readEnd = readEnd;
+                h.first = (uint32_t)pc.ids.size();
+                h.count = (uint32_t)overlapping.size();
+                pc.ids.insert(pc.ids.end(), overlapping.begin(), overlapping.end());
+                pc.hits.push_back(h);
             }
-            dsa_pair p{};
-            p.fusion_idx = fi->second;
-            p.read_off = (int32_t)read_bytes.size();
-            p.read_len = (int32_t)seq.size();
-            p.frag = frag;
-            p.read_end = (uint8_t)read_end;
-            p.revcomp = (uint8_t)revcomp;
-            read_bytes.insert(read_bytes.end(), seq.begin(), seq.end());
-            cand.push_back(p);
+            if (readEnd >= 0) pc.lastReadEnd = readEnd;
+        });
+        stage("  sam records + overlaps of a round");
+        for (SamPiece& pc : pieces) {
+            for (const Hit& h : pc.hits) {
+                const int mateReadEnd = h.readEnd < 0 ? carryReadEnd : h.readEnd;
+                const int frag = h.frag;
+                for (uint32_t k = 0; k < h.count; ++k) {
+                    const int cid = pc.ids[h.first + k];
+                    const int cluster_end = cid < 0 ? 1 : 0;
+                    const int fusion_id = cid & 0x7FFFFFFF;
+                    const int read_end = (mateReadEnd == 0) ? 1 : 0;
+                    const int revcomp = (cluster_end == 0) ? 1 : 0;
+                    const int rid = pack_id(frag, read_end);
+                    if (!candidate_unique.insert(((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp).second) continue;
+                    const char* rs = nullptr;              // a missing read aligns as the empty string (operator[] in the reference, :286)
+                    size_t rn = 0;
+                    if (reads.get(frag, read_end, rs, rn)) seq.assign(rs, rn); else seq.clear();
+                    if (revcomp) ReverseComplement(seq);
+                    auto fi = fusion_index.find(fusion_id);
+                    if (fi == fusion_index.end()) {
+                        const SplitAlignmentTask& t = tasks[fusion_id];
+                        dsa_fusion f;
+                        f.fusion_id = fusion_id;
+                        f.ref0_off = (int32_t)ref_bytes.size();
+                        f.ref0_len = (int32_t)t.mSplitAlignSeq[0].size();
+                        ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
+                        f.ref1_off = (int32_t)ref_bytes.size();
+                        f.ref1_len = (int32_t)t.mSplitAlignSeq[1].size();
+                        ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
+                        fi = fusion_index.emplace(fusion_id, (int)fusions.size()).first;
+                        fusions.push_back(f);
+                    }
+                    dsa_pair p{};
+                    p.fusion_idx = fi->second;
+                    p.read_off = (int32_t)read_bytes.size();
+                    p.read_len = (int32_t)seq.size();
+                    p.frag = frag;
+                    p.read_end = (uint8_t)read_end;
+                    p.revcomp = (uint8_t)revcomp;
+                    read_bytes.insert(read_bytes.end(), seq.begin(), seq.end());
+                    cand.push_back(p);
+                }
+                // between two SAM records: a batch never splits the candidates of one record
+                if (cand.size() >= batch_pairs || read_bytes.size() > ((size_t)1 << 30) || ref_bytes.size() > ((size_t)1 << 30)) flush();
+            }
+            if (pc.errorLine) {                                         // the records before the bad line were taken up, as a serial reader does
+                flush();
+                if (pc.errorKind == 6) die("Error: bad integer '" + pc.errorText + "' as fragment name");
+                DieSamLine(pc.errorKind, lineBase + pc.errorLine);
+            }
+            lineBase += pc.lines;
+            if (pc.lastReadEnd != -2) carryReadEnd = pc.lastReadEnd;
         }
-        // between two SAM records: a batch never splits the candidates of one record
-        if (cand.size() >= batch_pairs || read_bytes.size() > ((size_t)1 << 30) || ref_bytes.size() > ((size_t)1 << 30)) flush();
+        lo = hi;
     }
     flush();
     stage("candidates + alignment + output");
