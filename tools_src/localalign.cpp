@@ -41,13 +41,23 @@ void flush(Batch& b, int matchScore, int misMatchScore, int gapScore, double thr
     if (la_align_batch_min(device, matchScore, misMatchScore, gapScore, b.pool.data(), (int64_t)b.pool.size(), b.items.data(),
                            (int64_t)b.items.size(), need.data(), scores.data(), nullptr) != 0)
         die(std::string("Error: GPU alignment failed: ") + la_last_error());
+    std::string out;
+    char num[40];
     for (size_t k = 0; k < b.items.size(); ++k) {
         const int score = scores[k];
         const int maxScore = (size_t)b.items[k].seq_len * matchScore;      // tools/localalign.cpp:86
         const double percent = (double)score / (double)maxScore;
         if (percent < threshold) continue;
-        std::cout << b.ids[k] << "\t" << score << "\t" << percent << std::endl;
+        out += b.ids[k];
+        out += '\t';
+        append_int(out, score);
+        out += '\t';
+        out.append(num, (size_t)snprintf(num, sizeof num, "%g", percent));   // operator<<(double): six significant digits
+        out += '\n';
+        if (out.size() > (1u << 22)) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
     }
+    fwrite(out.data(), 1, out.size(), stdout);
+    fflush(stdout);
     b = Batch();
 }
 
@@ -66,30 +76,36 @@ int main(int argc, char* argv[])
 
     Batch batch;
     const size_t flush_bytes = (size_t)1 << 30;           // bounds host memory on very large inputs
-    std::string line;
+    LineReader reader(stdin);
+    const char* line;
+    size_t len;
     int lineNumber = 0;
-    while (std::getline(std::cin, line)) {
+    while (reader.next(line, len)) {
         lineNumber++;
-        if (line.length() == 0) {
+        if (len == 0) {
             flush(batch, matchScore, misMatchScore, gapScore, threshold);
             std::cerr << "Error: Empty line " << lineNumber << std::endl;
             return 1;
         }
-        std::vector<std::string> f = split_tabs(line);
-        if (f.size() < 3) {
+        const char* end = line + len;
+        const char* t1 = (const char*)memchr(line, '\t', len);
+        const char* t2 = t1 ? (const char*)memchr(t1 + 1, '\t', (size_t)(end - t1 - 1)) : nullptr;
+        if (!t2) {
             flush(batch, matchScore, misMatchScore, gapScore, threshold);
             std::cerr << "Error: Format error for line " << lineNumber << std::endl;
             return 1;
         }
+        const char* t3 = (const char*)memchr(t2 + 1, '\t', (size_t)(end - t2 - 1));     // further fields are ignored
+        if (!t3) t3 = end;
         la_item it;
         it.ref_off = (int64_t)batch.pool.size();
-        it.ref_len = (int32_t)f[1].size();
-        batch.pool.insert(batch.pool.end(), f[1].begin(), f[1].end());
+        it.ref_len = (int32_t)(t2 - t1 - 1);
+        batch.pool.insert(batch.pool.end(), t1 + 1, t2);
         it.seq_off = (int64_t)batch.pool.size();
-        it.seq_len = (int32_t)f[2].size();
-        batch.pool.insert(batch.pool.end(), f[2].begin(), f[2].end());
+        it.seq_len = (int32_t)(t3 - t2 - 1);
+        batch.pool.insert(batch.pool.end(), t2 + 1, t3);
         batch.items.push_back(it);
-        batch.ids.push_back(f[0]);
+        batch.ids.emplace_back(line, (size_t)(t1 - line));
         if (batch.pool.size() >= flush_bytes) flush(batch, matchScore, misMatchScore, gapScore, threshold);
     }
     flush(batch, matchScore, misMatchScore, gapScore, threshold);
