@@ -424,39 +424,19 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Wave-per-fit version for the larger problems.  A lane that works through a whole fit by itself spends
-// N*K exp/log/divide sequences per EM iteration one after the other and reads its private arrays with 64
-// different addresses per wave instruction; the few largest bin pairs of a run then decide the kernel time.
-// Here one wave owns one fit:
-//   * everything elementwise over the mate pairs (exponents, exp, log, responsibilities, KKZ distances,
-//     memberships) runs lane-strided over i, coalesced;
-//   * every sum the reference takes serially stays one serial chain of the same additions in the same order,
-//     but independent chains run side by side: lane j owns component j (its NK, RXYU and the breakpoint
-//     walk of MaxLikelihood), lane 0 owns the log-likelihood chain;
-//   * the AS 136 k-means is sequential by construction (every transfer changes the centres the next point
-//     sees) and runs on lane 0.
+// Wave versions.  A lane that works through a whole fit by itself spends N*K exp/log/divide sequences per EM iteration one
+// after the other and reads its private arrays with 64 different addresses per wave instruction; the few largest bin pairs
+// of a run then decide the kernel time.  In the wave kernel (k_mpe_problem_wave, below)
+//   * everything elementwise over the mate pairs (exponents, exp, log, responsibilities, KKZ distances, memberships) runs
+//     lane-strided over i, coalesced;
+//   * every sum the reference takes serially stays one serial chain of the same additions in the same order, but
+//     independent chains run side by side in different lanes;
+//   * the AS 136 k-means is sequential by construction (every transfer changes the centres the next point sees): one lane
+//     per fit.
 // Results are those of the lane version operation for operation: same expressions, same order, same ocml calls.
-struct WaveShared {
-    double W[MPE_KMAX], A[MPE_KMAX], B[MPE_KMAX];
-    double px[MPE_KMAX], py[MPE_KMAX], c[2 * MPE_KMAX];
-    double like;
-    int ifault, flag;
-};
-
 constexpr int WV = 64;
 #ifndef MPE_WPE
-#define MPE_WPE 5       // waves per SIMD the wave kernels are compiled for (profiles/microbench/mpe_occ.sh)
-#endif
-
-#ifdef MPE_PROFILE
-// phase cycle counters of the wave kernels (profiles/microbench/mpe_phase.sh): init, M step, E step, LL chain, R update;
-// [5..8] = cycles, N, K, iterations of the longest fit
-__device__ unsigned long long g_mpe_prof[16];
-#define MPE_T(var) const long long var = clock64()
-#define MPE_ADD(slot, t0, t1) do { if (lane == 0) atomicAdd(&g_mpe_prof[slot], (unsigned long long)((t1) - (t0))); } while (0)
-#else
-#define MPE_T(var)
-#define MPE_ADD(slot, t0, t1)
+#define MPE_WPE 4       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
 #endif
 
 // MaxLikelihood (:192-325) for one component in one lane, streaming: the two prefix sums advance with the
@@ -565,146 +545,6 @@ __device__ int wave_first_argmax(double v, int idx, double& vmax)
     }
     vmax = v;
     return idx;
-}
-
-__device__ bool select_kkz_wave(Work& w, WaveShared& s, int k, int lane)   // :327-386
-{
-    const int N = w.N;
-    double best = 0.0;
-    int bi = -1;
-    for (int i = lane; i < N; i += WV) {
-        const double l2 = w.X[i] * w.Y[i];
-        if (bi < 0 || l2 > best) { best = l2; bi = i; }
-    }
-    double vm;
-    const int imax = wave_first_argmax(best, bi, vm);
-    if (lane == 0) { s.px[0] = w.X[imax]; s.py[0] = w.Y[imax]; }
-    __syncthreads();
-    for (int na = 1; na < k; ++na) {
-        best = 0.0;
-        bi = -1;
-        for (int i = lane; i < N; i += WV) {
-            double md = (w.X[i] - s.px[0]) * (w.X[i] - s.px[0]) + (w.Y[i] - s.py[0]) * (w.Y[i] - s.py[0]);
-            for (int j = 1; j < na; ++j) {
-                const double dj = (w.X[i] - s.px[j]) * (w.X[i] - s.px[j]) + (w.Y[i] - s.py[j]) * (w.Y[i] - s.py[j]);
-                md = fmin(md, dj);
-            }
-            if (bi < 0 || md > best) { best = md; bi = i; }
-        }
-        const int idx = wave_first_argmax(best, bi, vm);
-        if (vm == 0.0) return false;
-        __syncthreads();
-        if (lane == 0) { s.px[na] = w.X[idx]; s.py[na] = w.Y[idx]; }
-        __syncthreads();
-    }
-    return true;
-}
-
-// ExpectationMaximization (:388-494), one wave; every lane returns the same values
-__device__ bool expectation_maximization_wave(Work& w, WaveShared& s, int K, int lane, double& ll)
-{
-    const int N = w.N;
-    MPE_T(t_init0);
-    if (K == 1 || K == N) {
-        const double v = 1.0 / K;
-        for (size_t t = lane; t < (size_t)K * N; t += WV) w.RXO[t] = v;
-    } else {
-        if (!select_kkz_wave(w, s, K, lane)) return false;
-        for (int i = lane; i < N; i += WV) { w.ka[i] = w.Y[i]; w.ka[N + i] = w.X[i]; }
-        if (lane < K) { s.c[lane] = s.py[lane]; s.c[K + lane] = s.px[lane]; }
-        __syncthreads();
-        if (lane == 0) s.ifault = kmns(w.ka, N, s.c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER);
-        __syncthreads();
-        if (s.ifault == 1 || s.ifault == 3) { w.fail = 1; return false; }
-        for (int i = lane; i < N; i += WV) {
-            const int own = w.ic1[i] - 1, ixo = w.TX[i];
-            for (int j = 0; j < K; ++j) w.RXO[(size_t)j * N + ixo] = (j == own) ? 1.0 : 0.0;
-        }
-    }
-    __syncthreads();
-    MPE_T(t_init1);
-    MPE_ADD(0, t_init0, t_init1);
-    double last = 0.0;
-    bool valid = false;
-    for (;;) {
-        // M step: component j in lane j
-        MPE_T(t_m0);
-        int rc = 0;
-        if (lane < K) {
-            double a = 0.0, b = 0.0, nk = 0.0;
-            rc = max_likelihood_stream(w, w.RXO + (size_t)lane * N, a, b, nk);
-            if (rc > 0) { s.A[lane] = a; s.B[lane] = b; }
-            s.W[lane] = nk / N;
-        }
-        if (__any(rc < 0)) { w.fail = 1; return false; }
-        if (lane == 0) s.flag = 0;
-        __syncthreads();
-        MPE_T(t_m1);
-        MPE_ADD(1, t_m0, t_m1);
-        // E step, elementwise part: exponents, exp, mixture sum, log.  EX keeps exp(EX - maxexp), kd the mixture
-        // sum, SX / SY the two terms of the log-likelihood chain.
-        bool zero = false;
-        for (int i = lane; i < N; i += WV) {
-            for (int j = 0; j < K; ++j) {
-                const double t = (s.A[j] + s.B[j] - w.X[i] - w.Y[i] - w.U[i]) / w.sd;
-                w.EX[(size_t)j * N + i] = -0.5 * (t * t) - LAMBDA * fmax(0.0, w.X[i] - s.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[j]);
-            }
-            double maxexp = w.EX[i];
-            for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, w.EX[(size_t)j * N + i]);
-            double sum = 0.0;
-            for (int j = 0; j < K; ++j) {
-                const double e = exp(w.EX[(size_t)j * N + i] - maxexp);
-                w.EX[(size_t)j * N + i] = e;
-                sum += s.W[j] * e;
-            }
-            if (sum == 0.0) zero = true;
-            w.kd[i] = sum;
-            w.SX[i] = log(sum);
-            w.SY[i] = maxexp;
-        }
-        if (zero) s.flag = 1;
-        __syncthreads();
-        MPE_T(t_e1);
-        MPE_ADD(2, t_m1, t_e1);
-        if (lane == 0) {                       // LogLikelihood :96-137, the serial chain
-            double LL = 0.0;
-            if (s.flag) LL = -DBL_MAX_;
-            else {
-                int i = 0;
-                for (; i + 4 <= N; i += 4) {
-                    double l1[4], l2[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) { l1[v] = w.SX[i + v]; l2[v] = w.SY[i + v]; }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) LL = LL + l1[v] + l2[v];
-                }
-                for (; i < N; ++i) LL = LL + w.SX[i] + w.SY[i];
-            }
-            s.like = LL;
-        }
-        __syncthreads();
-        MPE_T(t_l1);
-        MPE_ADD(3, t_e1, t_l1);
-        const double like = s.like;
-        const bool any_zero = s.flag != 0;
-        w.iters += 1;
-        if (valid && fabs(like - last) < TOLERANCE) break;
-        if (valid && like == -DBL_MAX_) return false;
-        if (valid && !(like / last < 1.0000001)) { w.fail = 1; return false; }   // DebugCheck
-        last = like;
-        valid = true;
-        if (any_zero) { w.fail = 1; return false; }                              // DebugCheck(norm != 0.0), :172
-        for (int i = lane; i < N; i += WV) {                                     // UpdateResponsibilities :139-181
-            const int ixo = w.TX[i];
-            const double norm = w.kd[i];
-            for (int j = 0; j < K; ++j) w.RXO[(size_t)j * N + ixo] = s.W[j] * w.EX[(size_t)j * N + i] / norm;
-        }
-        __syncthreads();
-        MPE_T(t_r1);
-        MPE_ADD(4, t_l1, t_r1);
-    }
-    ll = last;
-    return true;
 }
 
 // carve the workspace of a fit with up to K components and set up the sorted copies
@@ -844,64 +684,51 @@ __global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off
     atomicAdd(iters, (unsigned long long)w.iters);
 }
 
-// one (problem, K) fit, or one problem of the final pass with K = its largest K
-struct FitRef { int32_t q, K; };
+// ------------------------------------------------------------------------------------------------------
+// One wave per problem: the K = 1..kmax fits of the model selection side by side.  A wave per fit (the first wave version,
+// profiles/r01/clustermatepairs/) was bound by VALU issue with few lanes at work — its M step kept K of 64 lanes busy, its
+// log-likelihood chain one — and five such waves per SIMD already filled the issue slots.  Here lane l = K(K-1)/2 + j owns component j of the fit with K components:
+// the M steps of all ten fits of a problem are one pass of up to 55 lanes, their log-likelihood chains and their k-means
+// start-ups run in ten lanes at once, and the elementwise E steps go through the fits one after the other with all lanes.
+// A fit that has converged drops out; the wave lasts as long as the problem's slowest fit, not the sum of its fits.  The
+// KKZ seeds of a fit with K centres are the first K of the sequence for kmax (each seed depends on the earlier ones only),
+// the data-dependent arrays (XO, YO, X+Y+U, the k-means point array, the rank maps) are shared by the fits, and the refit of
+// the chosen K that the reference runs after the model selection is that fit's state, which is still there.
+constexpr int MPE_NCOMP = MPE_KMAX * (MPE_KMAX + 1) / 2;     // 55 component lanes
 
-// one wave per fit of the list (costliest first)
-__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_fit_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
-                          const FitRef* __restrict__ fits, const double* __restrict__ x, const double* __restrict__ y,
-                          const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
-                          const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
-                          int* __restrict__ wints, double* __restrict__ bic, int32_t* __restrict__ fit_state,
-                          unsigned long long* __restrict__ iters)
+struct ProblemShared {
+    double W[MPE_NCOMP], A[MPE_NCOMP], B[MPE_NCOMP];
+    double px[MPE_KMAX], py[MPE_KMAX];
+    double c[MPE_KMAX + 1][2 * MPE_KMAX];
+    double like[MPE_KMAX + 1], last[MPE_KMAX + 1];
+    int active[MPE_KMAX + 1], valid[MPE_KMAX + 1], state[MPE_KMAX + 1], zero[MPE_KMAX + 1], ifault[MPE_KMAX + 1];
+    int n_seeds, any_active;
+};
+
+struct FitArrays { double *RXO, *EX, *SX, *SY, *kd; int *ic1, *ic2; };
+
+__device__ __forceinline__ FitArrays fit_arrays(int N, int K, double* d, int* ip)
 {
-    __shared__ WaveShared s;
-    const int lane = threadIdx.x;
-    const int q = fits[blockIdx.x].q;
-    const int K = fits[blockIdx.x].K;
-    const int p = p0 + q;
-    const int64_t b = prob_off[p];
-    const int N = (int)(prob_off[p + 1] - b);
-    const int slot = q * MPE_KMAX + K - 1;
-    if (lane == 0) fit_state[slot] = 0;
-    if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
-    if (K > (N < MPE_KMAX ? N : MPE_KMAX)) return;
-    Work w;
-    init_work(w, N, K, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev, lane, WV);
-    if (lane < MPE_KMAX) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
-    __syncthreads();
-    double ll;
-    MPE_T(t_fit0);
-    const bool ok = expectation_maximization_wave(w, s, K, lane, ll);
-#ifdef MPE_PROFILE
-    if (lane == 0) {
-        const unsigned long long cyc = (unsigned long long)(clock64() - t_fit0);
-        if (atomicMax(&g_mpe_prof[5], cyc) < cyc) { g_mpe_prof[6] = N; g_mpe_prof[7] = K; g_mpe_prof[8] = w.iters; }
-        atomicAdd(&g_mpe_prof[9], cyc);
-    }
-#endif
-    if (lane == 0) {
-        if (ok) {
-            bic[slot] = -2.0 * ll + K * 2.0 * log((double)N);
-            fit_state[slot] = 1;
-        }
-        if (w.fail) fit_state[slot] = 2;
-        atomicAdd(iters, (unsigned long long)w.iters);
-    }
+    FitArrays f;
+    f.RXO = d; d += (size_t)K * N;
+    f.EX = d; d += (size_t)K * N;
+    f.SX = d; d += N;
+    f.SY = d; d += N;
+    f.kd = d;
+    f.ic1 = ip;
+    f.ic2 = ip + N;
+    return f;
 }
 
-// model selection, refit and memberships of one large problem per wave
-__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_final_wave(mpe_params prm, const int64_t* __restrict__ prob_off, int p0,
-                            const FitRef* __restrict__ fits, const double* __restrict__ x, const double* __restrict__ y,
-                            const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
-                            const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
-                            int* __restrict__ wints, const double* __restrict__ bic, const int32_t* __restrict__ fit_state,
-                            int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status,
-                            unsigned long long* __restrict__ iters)
+__global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_problem_wave(
+    mpe_params prm, const int64_t* __restrict__ prob_off, int p0, const int32_t* __restrict__ order, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
+    const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles, int* __restrict__ wints,
+    int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters)
 {
-    __shared__ WaveShared s;
+    __shared__ ProblemShared s;
     const int lane = threadIdx.x;
-    const int q = fits[blockIdx.x].q;
+    const int q = order[blockIdx.x];
     const int p = p0 + q;
     const int64_t b = prob_off[p];
     const int N = (int)(prob_off[p + 1] - b);
@@ -909,49 +736,238 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     for (int i = lane; i < N; i += WV) member[b + i] = 0;
     if ((double)N < (double)prm.min_cluster_size || N == 0) return;       // :542-545
     const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
-    double min_bic = 0.0;                                                  // :599-606, every lane the same
+    // component lane -> (fit, component)
+    int myK = 0, myJ = 0;
+    for (int K = 1, l = 0; K <= kmax; ++K)
+        for (int j = 0; j < K; ++j, ++l)
+            if (l == lane) { myK = K; myJ = j; }
+    const int myL = myK ? myK * (myK - 1) / 2 + myJ : 0;
+
+    // arrays shared by the fits live behind the largest fit's own
+    const int slot_max = q * MPE_KMAX + kmax - 1;
+    double* shared_d = wdoubles + wd_off[slot_max] + 2 * (size_t)kmax * N + 3 * (size_t)N;
+    Work w;
+    w.N = N;
+    w.X = x + b; w.Y = y + b; w.U = u + b;
+    w.ToXO = to_xo + b; w.ToYO = to_yo + b;
+    w.TX = w.ToXO;
+    w.XO = shared_d; shared_d += N;
+    w.YO = shared_d; shared_d += N;
+    double* xyu = shared_d; shared_d += N;
+    w.XYU = xyu;
+    w.ka = shared_d; shared_d += 2 * (size_t)N;
+    w.XfromY = (int*)shared_d;
+    w.sd = prm.fragment_stddev;
+    for (int i = lane; i < N; i += WV) {
+        w.XO[w.ToXO[i]] = w.X[i];
+        w.YO[w.ToYO[i]] = w.Y[i];
+        xyu[i] = w.X[i] + w.Y[i] + w.U[i];
+        w.XfromY[w.ToYO[i]] = w.ToXO[i];
+        w.ka[i] = w.Y[i];                      // both inserts are at begin(): a = [Y..., X...]
+        w.ka[N + i] = w.X[i];
+    }
+    if (lane <= MPE_KMAX) { s.active[lane] = 0; s.valid[lane] = 0; s.state[lane] = 0; s.zero[lane] = 0; s.ifault[lane] = 0; s.like[lane] = 0.0; s.last[lane] = 0.0; }
+    if (lane < MPE_NCOMP) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
+    __syncthreads();
+
+    // ---- KKZ seeds (:327-386), once for kmax; a fit needs seeds unless K == 1 or K == N
+    {
+        double best = 0.0;
+        int bi = -1;
+        for (int i = lane; i < N; i += WV) {
+            const double l2 = w.X[i] * w.Y[i];
+            if (bi < 0 || l2 > best) { best = l2; bi = i; }
+        }
+        double vm;
+        const int imax = wave_first_argmax(best, bi, vm);
+        if (lane == 0) { s.px[0] = w.X[imax]; s.py[0] = w.Y[imax]; s.n_seeds = 1; }
+        __syncthreads();
+        for (int na = 1; na < kmax; ++na) {
+            best = 0.0;
+            bi = -1;
+            for (int i = lane; i < N; i += WV) {
+                double md = (w.X[i] - s.px[0]) * (w.X[i] - s.px[0]) + (w.Y[i] - s.py[0]) * (w.Y[i] - s.py[0]);
+                for (int j = 1; j < na; ++j) {
+                    const double dj = (w.X[i] - s.px[j]) * (w.X[i] - s.px[j]) + (w.Y[i] - s.py[j]) * (w.Y[i] - s.py[j]);
+                    md = fmin(md, dj);
+                }
+                if (bi < 0 || md > best) { best = md; bi = i; }
+            }
+            const int idx = wave_first_argmax(best, bi, vm);
+            if (vm == 0.0) break;                              // SelectKKZ fails for every K > na
+            __syncthreads();
+            if (lane == 0) { s.px[na] = w.X[idx]; s.py[na] = w.Y[idx]; s.n_seeds = na + 1; }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    // ---- start-up of every fit (:388-450): uniform responsibilities, or k-means from the seeds (one fit per lane)
+    if (lane >= 1 && lane <= kmax) {
+        const int K = lane;
+        if (K == 1 || K == N) s.active[K] = 1;
+        else if (s.n_seeds >= K) {
+            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+            for (int j = 0; j < K; ++j) { s.c[K][j] = s.py[j]; s.c[K][K + j] = s.px[j]; }
+            const int ifault = kmns(w.ka, N, s.c[K], K, f.ic1, f.ic2, f.kd, KMEANS_ITER);
+            s.ifault[K] = ifault;
+            if (ifault == 1 || ifault == 3) s.state[K] = 2;    // DebugCheck(ifault != 1 / != 3)
+            else s.active[K] = 1;
+        }
+    }
+    __syncthreads();
+    for (int K = 1; K <= kmax; ++K) {
+        if (!s.active[K]) continue;
+        FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+        if (K == 1 || K == N) {
+            const double v = 1.0 / K;
+            for (size_t t = lane; t < (size_t)K * N; t += WV) f.RXO[t] = v;
+        } else {
+            for (int i = lane; i < N; i += WV) {
+                const int own = f.ic1[i] - 1, ixo = w.TX[i];
+                for (int j = 0; j < K; ++j) f.RXO[(size_t)j * N + ixo] = (j == own) ? 1.0 : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- EM of all fits
+    long long my_iters = 0;
+    for (;;) {
+        // M step: every component of every running fit
+        if (myK && s.active[myK]) {
+            double a = 0.0, bb = 0.0, nk = 0.0;
+            FitArrays f = fit_arrays(N, myK, wdoubles + wd_off[q * MPE_KMAX + myK - 1], wints + wi_off[q * MPE_KMAX + myK - 1]);
+            const int rc = max_likelihood_stream(w, f.RXO + (size_t)myJ * N, a, bb, nk);
+            if (rc < 0) s.state[myK] = 2;                      // the reference would read past the end: DebugCheck
+            if (rc > 0) { s.A[myL] = a; s.B[myL] = bb; }
+            s.W[myL] = nk / N;
+        }
+        __syncthreads();
+        if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
+        __syncthreads();
+        // E step, fit after fit: exponents, exp, mixture sum, log
+        for (int K = 1; K <= kmax; ++K) {
+            if (!s.active[K]) continue;
+            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+            const int l0 = K * (K - 1) / 2;
+            bool zero = false;
+            for (int i = lane; i < N; i += WV) {
+                for (int j = 0; j < K; ++j) {
+                    const double t = (s.A[l0 + j] + s.B[l0 + j] - w.X[i] - w.Y[i] - w.U[i]) / w.sd;
+                    f.EX[(size_t)j * N + i] = -0.5 * (t * t) - LAMBDA * fmax(0.0, w.X[i] - s.A[l0 + j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[l0 + j]);
+                }
+                double maxexp = f.EX[i];
+                for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, f.EX[(size_t)j * N + i]);
+                double sum = 0.0;
+                for (int j = 0; j < K; ++j) {
+                    const double e = exp(f.EX[(size_t)j * N + i] - maxexp);
+                    f.EX[(size_t)j * N + i] = e;
+                    sum += s.W[l0 + j] * e;
+                }
+                if (sum == 0.0) zero = true;
+                f.kd[i] = sum;
+                f.SX[i] = log(sum);
+                f.SY[i] = maxexp;
+            }
+            if (zero) s.zero[K] = 1;
+        }
+        __syncthreads();
+        // log-likelihood chains (:96-137) and the loop control of ExpectationMaximization (:455-492), one fit per lane
+        if (lane >= 1 && lane <= kmax && s.active[lane]) {
+            const int K = lane;
+            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+            double LL = 0.0;
+            if (s.zero[K]) LL = -DBL_MAX_;
+            else {
+                int i = 0;
+                for (; i + 4 <= N; i += 4) {
+                    double l1[4], l2[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { l1[v] = f.SX[i + v]; l2[v] = f.SY[i + v]; }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) LL = LL + l1[v] + l2[v];
+                }
+                for (; i < N; ++i) LL = LL + f.SX[i] + f.SY[i];
+            }
+            my_iters += 1;
+            const double like = LL, last = s.last[K];
+            const bool valid = s.valid[K] != 0;
+            if (valid && fabs(like - last) < TOLERANCE) { s.active[K] = 0; s.state[K] = 1; s.like[K] = last; }      // converged: ll = last
+            else if (valid && like == -DBL_MAX_) { s.active[K] = 0; }                                              // no likelihood, no failure
+            else if (valid && !(like / last < 1.0000001)) { s.active[K] = 0; s.state[K] = 2; }                     // DebugCheck
+            else {
+                s.last[K] = like;
+                s.valid[K] = 1;
+                if (s.zero[K]) { s.active[K] = 0; s.state[K] = 2; }                                                // DebugCheck(norm != 0.0), :172
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int any = 0;
+            for (int K = 1; K <= kmax; ++K) any |= s.active[K];
+            s.any_active = any;
+        }
+        __syncthreads();
+        if (!s.any_active) break;
+        // UpdateResponsibilities (:139-181) of the fits that go on
+        for (int K = 1; K <= kmax; ++K) {
+            if (!s.active[K]) continue;
+            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+            const int l0 = K * (K - 1) / 2;
+            for (int i = lane; i < N; i += WV) {
+                const int ixo = w.TX[i];
+                const double norm = f.kd[i];
+                for (int j = 0; j < K; ++j) f.RXO[(size_t)j * N + ixo] = s.W[l0 + j] * f.EX[(size_t)j * N + i] / norm;
+            }
+        }
+        __syncthreads();
+    }
+    const long long fit_iters = my_iters;                  // lane K: iterations of the fit with K components
+    for (int off = 32; off > 0; off >>= 1) my_iters += __shfl_xor(my_iters, off);
+
+    // ---- model selection (:599-606); a fit that tripped a DebugCheck ends the reference's run there
+    double min_bic = 0.0;
     bool have = false, failed = false;
     int k_min = 1;
     for (int K = 1; K <= kmax; ++K) {
-        const int st = fit_state[q * MPE_KMAX + K - 1];
+        const int st = s.state[K];
         if (st == 2) { failed = true; break; }
         if (st != 1) continue;
-        const double v = bic[q * MPE_KMAX + K - 1];
+        const double v = -2.0 * s.like[K] + K * 2.0 * log((double)N);
         if (!have || v < min_bic) { min_bic = v; k_min = K; have = true; }
     }
-    if (failed) { if (lane == 0) status[p] = 1; return; }
-    const int slot = q * MPE_KMAX + kmax - 1;
-    Work w;
-    init_work(w, N, kmax, b, x, y, u, to_xo, to_yo, wdoubles + wd_off[slot], wints + wi_off[slot], prm.fragment_stddev, lane, WV);
-    if (lane < MPE_KMAX) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
-    __syncthreads();
-    double ll;
-    if (expectation_maximization_wave(w, s, k_min, lane, ll)) {
+    if (failed) {
+        if (lane == 0) { status[p] = 1; atomicAdd(iters, (unsigned long long)my_iters); }
+        return;
+    }
+    // the refit of k_min (:608-615) repeats that fit exactly: its parameters are still in s.A / s.B (its iterations are
+    // counted again, as the refit's would be); a fit without a likelihood leaves no clusters.
+    my_iters += __shfl(fit_iters, k_min);
+    if (s.state[k_min] == 1) {
+        const int l0 = k_min * (k_min - 1) / 2;
+        int* flags = wints + wi_off[q * MPE_KMAX + kmax - 1];
         const double coeff = 1.0 / (w.sd * sqrt(2 * M_PI));                // normalpdf, tools/Common.cpp:61-69
         int emitted = 0;
         for (int j = 0; j < k_min; ++j) {
             int count = 0;
             for (int i = lane; i < N; i += WV) {
-                const double dist = ((s.A[j] + s.B[j] - w.X[i] - w.Y[i]) - w.U[i]) / w.sd;
+                const double dist = ((s.A[l0 + j] + s.B[l0 + j] - w.X[i] - w.Y[i]) - w.U[i]) / w.sd;
                 const double prob = coeff * exp(-0.5 * dist * dist) *
-                                    exp(-LAMBDA * fmax(0.0, w.X[i] - s.A[j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[j]));
+                                    exp(-LAMBDA * fmax(0.0, w.X[i] - s.A[l0 + j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[l0 + j]));
                 const bool in = prob > prm.min_probability;
-                w.ic1[i] = in ? 1 : 0;
+                flags[i] = in ? 1 : 0;
                 count += in ? 1 : 0;
             }
             for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
             if ((double)count >= (double)prm.min_cluster_size) {
                 for (int i = lane; i < N; i += WV)
-                    if (w.ic1[i]) member[b + i] |= (uint16_t)(1u << emitted);
+                    if (flags[i]) member[b + i] |= (uint16_t)(1u << emitted);
                 ++emitted;
             }
         }
         if (lane == 0) n_clusters[p] = emitted;
     }
-    if (lane == 0) {
-        status[p] = w.fail;
-        atomicAdd(iters, (unsigned long long)w.iters);
-    }
+    if (lane == 0) atomicAdd(iters, (unsigned long long)my_iters);
 }
 
 template <typename T>
@@ -1046,7 +1062,6 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
             return prob_off[p0 + a + 1] - prob_off[p0 + a] > prob_off[p0 + b + 1] - prob_off[p0 + b];
         });
         DBuf<int64_t> d_wd, d_wi;
-        DBuf<FitRef> d_fits;
         DBuf<int32_t> d_order, d_state;
         DBuf<double> d_work, d_bic;
         DBuf<int> d_iwork;
@@ -1064,28 +1079,10 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         t.n_wave_problems += n_large;
         MPE_HIP(hipEventRecord(e0, 0));
         MPE_HIP(hipStreamWaitEvent(s_wave, e0, 0));
-        if (n_large) {
-            // fit list of the wave kernels, costliest (N*K) first: the long fits start early and the short ones fill in
-            std::vector<FitRef> fits, fins;
-            for (int r = 0; r < n_large; ++r) {
-                const int q = order[r];
-                const int n = (int)(prob_off[p0 + q + 1] - prob_off[p0 + q]);
-                const int kmax = n < MPE_KMAX ? n : MPE_KMAX;
-                for (int K = kmax; K >= 1; --K) fits.push_back(FitRef{q, K});
-                fins.push_back(FitRef{q, kmax});
-            }
-            auto size_of = [&](const FitRef& f) { return (int64_t)(prob_off[p0 + f.q + 1] - prob_off[p0 + f.q]) * f.K; };
-            std::stable_sort(fits.begin(), fits.end(), [&](const FitRef& a, const FitRef& b) { return size_of(a) > size_of(b); });
-            const size_t n_fits = fits.size();
-            fits.insert(fits.end(), fins.begin(), fins.end());
-            MPE_HIP(d_fits.alloc(fits.size()));
-            MPE_HIP(hipMemcpy(d_fits.p, fits.data(), fits.size() * sizeof(FitRef), hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_mpe_fit_wave, dim3((unsigned)n_fits), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_fits.p, d_x.p, d_y.p,
-                               d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_iters.p);
-            hipLaunchKernelGGL(k_mpe_final_wave, dim3((unsigned)fins.size()), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_fits.p + n_fits,
-                               d_x.p, d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_bic.p, d_state.p, d_nc.p,
-                               d_member.p, d_status.p, d_iters.p);
-        }
+        if (n_large)                 // order[0 .. n_large): the problems with a wave of their own, largest first
+            hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
+                               d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
+                               d_iters.p);
         if (n_small) {
             const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
             hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_large, n_small,
@@ -1110,14 +1107,6 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     if (n_mp) MPE_HIP(hipMemcpy(member, d_member.p, n_mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
     unsigned long long it = 0;
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
-#ifdef MPE_PROFILE
-    {
-        unsigned long long pr[16];
-        MPE_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_mpe_prof), sizeof pr));
-        fprintf(stderr, "[mpe profile] cycles: init %llu  M %llu  E %llu  LL %llu  R %llu | all fits %llu | longest fit %llu cycles N=%llu K=%llu iters=%llu\n",
-                pr[0], pr[1], pr[2], pr[3], pr[4], pr[9], pr[5], pr[6], pr[7], pr[8]);
-    }
-#endif
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(e2);
