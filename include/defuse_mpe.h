@@ -7,8 +7,8 @@
  * model over the mate pairs' break coordinates is fitted by EM for K = 1..min(10,N) (k-means
  * initialisation with KKZ seeding + AS 136, tools/asa136.C), K is chosen by BIC, and every component
  * reports the mate pairs whose pair probability exceeds the precision threshold.  Everything is FP64,
- * evaluated in the reference's operation order (serial prefix sums, serial reductions): every (problem, K)
- * fit runs in one wave whose lanes share the elementwise work and run the independent serial chains side by
+ * evaluated in the reference's operation order (serial prefix sums, serial reductions): every problem runs in
+ * one wave whose lanes share the elementwise work and run the independent serial chains of its K fits side by
  * side (DEFUSE_MPE_WAVE_MIN=n sends problems of fewer than n mate pairs through the one-lane-per-fit
  * transcription the wave version is checked against); problems are independent.
  *
@@ -39,7 +39,7 @@ typedef struct mpe_timing {
     int64_t n_mate_pairs;
     int64_t em_iterations;     /* total EM iterations over all problems and all K */
     int32_t n_failed;          /* problems that hit one of the reference's DebugCheck exits */
-    int32_t n_wave_problems;   /* problems fitted a wave per fit (all, unless DEFUSE_MPE_WAVE_MIN is set) */
+    int32_t n_wave_problems;   /* problems fitted by a wave of their own (all, unless DEFUSE_MPE_WAVE_MIN is set) */
 } mpe_timing;
 
 /* Problem p owns mate pairs [prob_off[p], prob_off[p+1]).  Per mate pair: x, y = strand-remapped

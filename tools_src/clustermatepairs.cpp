@@ -566,7 +566,7 @@ int main(int argc, char* argv[])
         if (rc != 0) die(std::string("Error: mate pair clustering on the GPU failed: ") + mpe_last_error());
         if (std::getenv("DEFUSE_TIMING"))
             std::cerr << "[clustermatepairs] " << t.n_problems << " bin pairs, " << t.n_mate_pairs << " mate pairs, " << t.em_iterations
-                      << " EM iterations, " << t.n_wave_problems << " bin pairs with a wave per fit, " << devices.size() << " device share(s), kernel " << t.kernel_ms << " ms" << std::endl;
+                      << " EM iterations, " << t.n_wave_problems << " bin pairs with a wave each, " << devices.size() << " device share(s), kernel " << t.kernel_ms << " ms" << std::endl;
         for (size_t p = 0; p < problems.size(); ++p)
             if (status[p]) die("Error: a consistency check of the mate pair clusterer failed (DebugCheck in the reference)");
     }
