@@ -549,7 +549,7 @@ __device__ int wave_first_argmax(double v, int idx, double& vmax)
 
 // carve the workspace of a fit with up to K components and set up the sorted copies
 // The wave version keeps the responsibilities only in x order (R[t] = RXO[ToXO[t]], RYO[s] = RXO[XfromY[s]]) and its
-// arrays in the global workspace.  Keeping them in LDS was tried (profiles/microbench/mpe_share.sh): a fit's chains get
+// arrays in the global workspace.  Keeping them in LDS was tried (profiles/r01/clustermatepairs/mpe_lds_share.txt): a fit's chains get
 // about three times faster, but 160 KiB per CU hold a quarter of the fits the wave slots do and the kernel as a whole got
 // slower at every share of fits moved to LDS; with many fits in flight per CU the L2 hit latency is hidden well enough.
 __device__ void init_work(Work& w, int N, int K, int64_t b, const double* x, const double* y, const double* u, const int32_t* to_xo,
