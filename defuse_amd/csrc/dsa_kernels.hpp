@@ -1332,8 +1332,11 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 // TIER 0: one 25-row table per fusion, at most GMAX fusions; 1: split tables, at most GSPLIT; 2: split tables in
 // twice the LDS (two workgroups per CU), at most GSPLIT2.
 __host__ __device__ constexpr int tier_of(int n_groups) { return n_groups <= GMAX ? 0 : n_groups <= GSPLIT ? 1 : 2; }
+#ifndef DSA_FAST_WGS
+#define DSA_FAST_WGS 4        // workgroups (of four waves) per CU the table tiers 0 and 1 are compiled for
+#endif
 template <int TIER>
-__global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : 4) void k_fill_fast(const dsa_pair* __restrict__ pairs,
+__global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            const WaveInfo* __restrict__ winfo,
                                                            const WgInfo* __restrict__ wginfo,
                                                            uint32_t* __restrict__ wg_generic,

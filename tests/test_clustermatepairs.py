@@ -165,3 +165,35 @@ def test_tool_shares_bin_pairs_over_devices(built, tmp_path, gpus):
     assert n >= 5 and txt == exp
     shares = {"0,0,0": "3 device share(s)", "2": "2 device share(s)", "all": "device share(s)"}[gpus]
     assert shares in r.stderr
+
+
+@pytest.mark.gpu
+def test_tool_degenerate_bin_pairs(built, tmp_path):
+    """Bin pairs whose mate pairs coincide: the KKZ seeding runs out of distinct points (SelectKKZ returns false for every K
+    beyond the number of distinct points, tools/MatePairEM.cpp:327-386), so only some of the K fits have a likelihood."""
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = []
+    frag = 0
+    for (n, a, b) in ((9, 5000, 9000), (7, 40000, 52000)):                   # all mate pairs identical
+        for _ in range(n):
+            lines.append("%d\t0\tchr1\t+\t%d\t%d\n" % (frag, a, a + 49))
+            lines.append("%d\t1\tchr2\t-\t%d\t%d\n" % (frag, b, b + 49))
+            frag += 1
+    for k in range(12):                                                       # two distinct mate pairs, six times each
+        a, b = (80000, 91000) if k % 2 else (80030, 91010)
+        lines.append("%d\t0\tchr1\t+\t%d\t%d\n" % (frag, a, a + 49))
+        lines.append("%d\t1\tchr2\t-\t%d\t%d\n" % (frag, b, b + 49))
+        frag += 1
+    for k in range(10):                                                       # three distinct ones
+        a, b = [(120000, 131000), (120040, 131020), (120090, 131070)][k % 3]
+        lines.append("%d\t0\tchr1\t-\t%d\t%d\n" % (frag, a, a + 49))
+        lines.append("%d\t1\tchr2\t+\t%d\t%d\n" % (frag, b, b + 49))
+        frag += 1
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert n >= 3
+    for wave_min in (None, "1000000000"):
+        r, txt = run_tool(lines, tmp_path, env={"DEFUSE_MPE_WAVE_MIN": wave_min} if wave_min else None)
+        assert r.returncode == 0, r.stderr
+        assert txt == exp, "DEFUSE_MPE_WAVE_MIN=%s" % wave_min
