@@ -67,6 +67,9 @@ struct Work {
 // workspace of one fit with K components
 __host__ __device__ inline size_t work_doubles(int n, int K) { return (size_t)n * (2 + 4 * K + 2 + 12 + 4) + 16; }
 __host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
+// what the wave kernel uses of a fit's slot: RXO, EX (K*n each), SX, SY, kd; behind the largest fit's own arrays the ones
+// all fits of the problem share (XO, YO, X+Y+U, the k-means point array 2n, XfromY)
+__host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return (size_t)n * (2 * K + 3 + (largest ? 6 : 0)) + 16; }
 
 __device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
 {
@@ -1034,7 +1037,8 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     auto slot_doubles = [&](int p, int K) -> size_t {
         const int n = (int)(prob_off[p + 1] - prob_off[p]);
         const int kmax = n < MPE_KMAX ? n : MPE_KMAX;
-        return (n >= params->min_cluster_size && n > 0 && K <= kmax) ? work_doubles(n, K) : 0;
+        if (!(n >= params->min_cluster_size && n > 0 && K <= kmax)) return 0;
+        return n >= wave_min ? wave_work_doubles(n, K, K == kmax) : work_doubles(n, K);      // the lane version keeps far more per fit
     };
     int p0 = 0;
     while (p0 < n_problems) {
