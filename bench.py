@@ -5,7 +5,7 @@ A "step" is one pass of the hot path (pack -> DP fill -> combine/replay/emit) ov
 synthetic candidates that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
 (10k synthetic fusions x 100 reads, 2x76 bp => Lref 389, 1M aligns).  With N>1 ranks every rank
 holds its own batch of the same shape (fusions are independent, no data-path collective: weak
-scaling); the timed region has no collective beyond the barrier/max-reduction of the timing.  After it,
+scaling; --strong instead splits --fusions over the ranks); the timed region has no collective beyond the barrier/max-reduction of the timing.  After it,
 with N>1, the final gather of the result records on rank 0 (the path's one exchange step) is
 run and timed on its own over RCCL: HBM -> xGMI -> rank 0's HBM, reported as "gather" in the JSON line.
 
@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--lq", type=int, default=76)
     ap.add_argument("--lr", type=int, default=389)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --fusions is the whole job, every rank takes fusions/N of it (default: weak, --fusions per rank)")
     args = ap.parse_args()
 
     import numpy as np
@@ -157,7 +159,8 @@ def main():
             dist.init_process_group(backend=backend)
 
     # every rank: its own shard of candidate fusions (different seed => different data, same shape)
-    ref, fus, reads, pairs = synth.make_batch(args.fusions, args.reads, lq=args.lq, lr=args.lr, seed=2 + rank)
+    n_fus = args.fusions if not args.strong else max(1, args.fusions // world + (1 if rank < args.fusions % world else 0))
+    ref, fus, reads, pairs = synth.make_batch(n_fus, args.reads, lq=args.lq, lr=args.lr, seed=2 + rank)
     ctx = dsa.Context(local_rank)
     ctx.upload(ref, fus, reads, pairs)
 
@@ -207,7 +210,7 @@ def main():
         out = {
             "metric": "split-read DP aligns/sec", "value": total_aligns / elapsed, "unit": "aligns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "%dk synthetic candidate fusions x %d reads, 2x%d bp (Lref %d), split-read DP + split search, bit-exact"
                                    % (args.fusions // 1000, args.reads, args.lq, args.lr),
