@@ -424,8 +424,8 @@ int main(int argc, char* argv[])
         prm.min_probability = normalpdf(x, 0, fragmentStdDev);
     }
 
-    std::ofstream out(cmd.str("clusters").c_str());
-    if (!out) die("Error: unable to write to clusters file");
+    OrderedFileWriter out;
+    if (!out.open_file(cmd.str("clusters"))) die("Error: unable to write to clusters file");
 
     std::cout << "Creating clusters" << std::endl;
     // per bin pair: unpack, match fragments, drop overlapping alignments, enumerate alignment pairs (:478-545)
@@ -617,10 +617,11 @@ int main(int argc, char* argv[])
             outShare[t] = std::min(std::max(at, outShare[t - 1]), hi);
         }
         run_threads(format_share);
-        for (std::string& tbuf : texts) { out.write(tbuf.data(), (std::streamsize)tbuf.size()); tbuf.clear(); }
+        out.write_round(texts, nThreads);
+        for (std::string& tbuf : texts) tbuf.clear();
         lo = hi;
     }
-    out.close();
+    if (!out.close_file()) die("Error: failed writing the clusters file");
     stage("output");
     std::cout << "Created " << clusterID << " clusters" << std::endl;
     return 0;

@@ -220,6 +220,48 @@ struct MappedText {
     }
 };
 
+// An output file written in order by several threads: the texts of one round get consecutive ranges of the file (a prefix
+// sum of their sizes) and every thread copies its own with pwrite, so the copy into the page cache runs side by side.
+class OrderedFileWriter {
+public:
+    bool open_file(const std::string& name)
+    {
+        fd_ = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        return fd_ >= 0;
+    }
+    void write_round(const std::vector<std::string>& texts, unsigned threads)
+    {
+        std::vector<off_t> at(texts.size() + 1, pos_);
+        for (size_t k = 0; k < texts.size(); ++k) at[k + 1] = at[k] + (off_t)texts[k].size();
+        std::vector<int> bad(texts.size(), 0);
+        const unsigned n = std::min<unsigned>(std::max(1u, threads), (unsigned)std::max<size_t>(1, texts.size()));
+        run_threads(n, [&](unsigned t) {
+            for (size_t k = t; k < texts.size(); k += n) {
+                const char* p = texts[k].data();
+                size_t left = texts[k].size();
+                off_t o = at[k];
+                while (left) {
+                    const ssize_t w = pwrite(fd_, p, left, o);
+                    if (w <= 0) { bad[k] = 1; break; }
+                    p += w; left -= (size_t)w; o += w;
+                }
+            }
+        });
+        for (int b : bad) ok_ = ok_ && !b;
+        pos_ = at[texts.size()];
+    }
+    bool close_file()
+    {
+        if (fd_ >= 0 && close(fd_) != 0) ok_ = false;
+        fd_ = -1;
+        return ok_;
+    }
+private:
+    int fd_ = -1;
+    off_t pos_ = 0;
+    bool ok_ = true;
+};
+
 // decimal text of an integer appended to a buffer (what operator<< prints for an int)
 inline void append_int(std::string& buf, long long v)
 {

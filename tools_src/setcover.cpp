@@ -135,8 +135,8 @@ int main(int argc, char* argv[])
     std::cout << "Writing out clusters" << std::endl;
     // WriteClusters (tools/Parsers.cpp:86-170): copy the input lines (both ends) whose fragment was
     // assigned to the line's cluster, for clusters that kept at least minClusterSize fragments
-    std::ofstream out(outName.c_str());
-    if (!out) die("Error: unable to write to clusters file " + outName);
+    OrderedFileWriter out;
+    if (!out.open_file(outName)) die("Error: unable to write to clusters file " + outName);
     // the lines are filtered in rounds of 256 MiB of input, each cut into one piece per host thread; texts written in order
     std::vector<std::string> texts(nThreads);
     std::vector<Piece> round(nThreads);
@@ -171,11 +171,10 @@ int main(int argc, char* argv[])
         for (unsigned t = 0; t < nThreads; ++t) {
             if (round[t].errorLine) report(round[t].errorKind, lineBase + round[t].errorLine, round[t].errorText, outName);
             lineBase += round[t].lines;
-            out.write(texts[t].data(), (std::streamsize)texts[t].size());
         }
+        out.write_round(texts, nThreads);
         lo = hi;
     }
     stage("write");
-    out.close();
-    return out.good() ? 0 : 1;
+    return out.close_file() ? 0 : 1;
 }
