@@ -1,6 +1,7 @@
-"""The four drop-in tools chained as scripts/defuse_run.pl chains them (:455,476,512,521,528,542):
-clustermatepairs -> setcover -> (regions, the rule of scripts/get_align_regions.pl:14-53 restated
-here) -> dosplitalign -> sort -n -k 1 -> evalsplitalign, on the genome of the known-answer vector
+"""The drop-in tools chained as scripts/defuse_run.pl chains them (:455,461,476,506,512,521,528,542):
+clustermatepairs -> merge_clusters -> setcover -> remove_duplicates -> get_align_regions (bin/defuse_glue; the regions
+rule of scripts/get_align_regions.pl:14-53 is also restated here as a cross-check) -> dosplitalign -> sort -n -k 1 ->
+evalsplitalign, on the genome of the known-answer vector
 with spanning fragments planted around its fusion chrA:+:650 | chrB:-:1000.  The final breakpoints must
 be the planted ones (the same check SURVEY.md Appendix A records for the reference + its Perl glue)."""
 import os
@@ -52,10 +53,15 @@ def test_pipeline_recovers_planted_breakpoint(built, tmp_path):
     r = run("clustermatepairs", "-m", "5", "-p", "0.95", "-u", "300", "-s", "30", "-a", "-", "-c", d + "clusters.txt",
             input="".join(lines))
     assert "Created 1 clusters" in r.stdout                       # the 3-fragment locus is below -m 5
-    run("setcover", "-m", "5", "-c", d + "clusters.txt", "-o", d + "clusters.sc")
-    sc = open(d + "clusters.sc").read()
+    merged = run("defuse_glue", "merge_clusters", d + "clusters.txt").stdout          # one chromosome pair here: ids unchanged
+    assert merged == open(d + "clusters.txt").read()
+    (tmp_path / "clusters.all").write_text(merged)
+    run("setcover", "-m", "5", "-c", d + "clusters.all", "-o", d + "clusters.sc.all")
+    sc = run("defuse_glue", "remove_duplicates", "5", input=open(d + "clusters.sc.all").read()).stdout
     assert len(sc.splitlines()) >= 20
-    (tmp_path / "regions.txt").write_text(align_regions(sc))
+    regions = run("defuse_glue", "get_align_regions", input=sc).stdout
+    assert regions == align_regions(sc)
+    (tmp_path / "regions.txt").write_text(regions)
     common = ["-f", d + "ref.fa", "-e", d + "exons.txt", "-u", "300", "-s", "30", "-n", "50", "-x", "50", "-r", d + "regions.txt"]
     run("dosplitalign", *common, "-i", d + "improper.sam", "-1", d + "reads.1.fastq", "-2", d + "reads.2.fastq", "-a", d + "split.align")
     rows = sorted(open(d + "split.align").read().splitlines(True), key=lambda l: int(l.split("\t")[0]))
