@@ -268,3 +268,25 @@ def test_full_size_properties(gpu_ctx, ora):
     order = np.argsort(-pairs["fusion_idx"][sel], kind="stable")
     rev = gpu_ctx.align_batch(ref, fus, reads, pairs[sel][order])
     assert sorted(t[:9] for t in as_tuples(rev)) == sorted(t[:9] for t in as_tuples(exp))
+
+
+def test_full_size_every_record_against_oracle(gpu_ctx, ora):
+    """BASELINE config 2 at full size, every one of its ~1.76 M records against the CPU oracle (oracle/dsa_oracle.c runs
+    without the GIL: one thread per host core, each on a contiguous share of the pairs, about ten seconds on the box's
+    16 cores).  Set DEFUSE_TEST_FULL_ORACLE=0 to skip it on a machine with few cores."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from defuse_amd import synth
+    if os.environ.get("DEFUSE_TEST_FULL_ORACLE", "1") == "0":
+        pytest.skip("DEFUSE_TEST_FULL_ORACLE=0")
+    ref, fus, reads, pairs = synth.make_batch(10000, 100, lq=76, lr=389, seed=2)
+    got = gpu_ctx.align_batch(ref, fus, reads, pairs)
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    bounds = np.linspace(0, len(pairs), cores + 1).astype(np.int64)
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        parts = list(ex.map(lambda k: ora.align_batch(ref, fus, reads, pairs[bounds[k]:bounds[k + 1]]), range(cores)))
+    for k, part in enumerate(parts):                               # a share numbers its pairs from zero
+        part["pair_idx"] += int(bounds[k])
+    exp = np.concatenate(parts)
+    assert len(got) == len(exp) and len(exp) > 1_500_000
+    assert got.tobytes() == exp.tobytes()
