@@ -270,8 +270,10 @@ def test_full_size_properties(gpu_ctx, ora):
     assert sorted(t[:9] for t in as_tuples(rev)) == sorted(t[:9] for t in as_tuples(exp))
 
 
-def test_full_size_every_record_against_oracle(gpu_ctx, ora):
-    """BASELINE config 2 at full size, every one of its ~1.76 M records against the CPU oracle (oracle/dsa_oracle.c runs
+@pytest.mark.parametrize("F,P,lq,lr", [(10000, 100, 76, 389), (5000, 200, 100, 390)])
+def test_full_size_every_record_against_oracle(gpu_ctx, ora, F, P, lq, lr):
+    """BASELINE config 2 at full size (and one GPU's worth of config 4's shape: 200 reads per fusion, 2x100, Lref 390),
+    every one of its ~1.7 M records against the CPU oracle (oracle/dsa_oracle.c runs
     without the GIL: one thread per host core, each on a contiguous share of the pairs, about ten seconds on the box's
     16 cores).  Set DEFUSE_TEST_FULL_ORACLE=0 to skip it on a machine with few cores."""
     import os
@@ -279,7 +281,7 @@ def test_full_size_every_record_against_oracle(gpu_ctx, ora):
     from defuse_amd import synth
     if os.environ.get("DEFUSE_TEST_FULL_ORACLE", "1") == "0":
         pytest.skip("DEFUSE_TEST_FULL_ORACLE=0")
-    ref, fus, reads, pairs = synth.make_batch(10000, 100, lq=76, lr=389, seed=2)
+    ref, fus, reads, pairs = synth.make_batch(F, P, lq=lq, lr=lr, seed=2)
     got = gpu_ctx.align_batch(ref, fus, reads, pairs)
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
     bounds = np.linspace(0, len(pairs), cores + 1).astype(np.int64)
