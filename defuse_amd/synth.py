@@ -39,6 +39,9 @@ def make_batch(n_fusions, reads_per_fusion, lq=76, lr=389, seed=2, sub_rate=0.01
     first = rng.integers(lq, lr, size=F)               # prefix length of window 0 kept by the fusion
     s1 = rng.integers(0, lr - lq + 1, size=F)          # first base of window 1 kept by the fusion
     n = F * P
+    if n * lq >= 2 ** 31 or F * 2 * lr >= 2 ** 31:
+        raise ValueError("one batch holds less than 2 GiB of read bytes and of window bytes (32-bit offsets in dsa_pair / dsa_fusion, "
+                         "include/defuse_dsa.h): split %d x %d reads of %d bases into several batches, as bin/dosplitalign does" % (F, P, lq))
     fidx = np.repeat(np.arange(F, dtype=np.int64), P)
     a = rng.integers(4, lq - 4 + 1, size=n)
     k = np.arange(lq, dtype=np.int64)[None, :]
