@@ -446,8 +446,11 @@ constexpr int WV = 64;
 // walk (SX[i] = SX[i-1] + RXO[i]) and the first breakpoint with a positive derivative ends it, so neither the
 // prefix arrays nor the breakpoint list are stored.  nk receives the component's sum of responsibilities
 // (UpdateMixWeights :183-190 takes the same sum in the same order).  Return codes as max_likelihood.
-__device__ int max_likelihood_stream(const Work& w, const double* RXO, double& a, double& b, double& nk)
+__device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int stride, double& a, double& b, double& nk)
 {
+    // the component's responsibilities in x order: element r at RXO_base[r * stride] (the fits keep them component-minor,
+    // so that the lanes of a fit, which own its components, touch neighbouring words)
+    auto RXO = [&](int r) { return RXO_base[(size_t)r * stride]; };
     const int N = w.N;
     const int* TX = w.TX;
     const int* XfromY = w.XfromY;
@@ -456,12 +459,12 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO, double& a
     for (; t + 4 <= N; t += 4) {              // loads in batches so that only the additions are serial
         double r[4], q[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { r[v] = RXO[TX[t + v]]; q[v] = w.XYU[t + v]; }
+        for (int v = 0; v < 4; ++v) { r[v] = RXO(TX[t + v]); q[v] = w.XYU[t + v]; }
 #pragma unroll
         for (int v = 0; v < 4; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
     }
     for (; t < N; ++t) {
-        const double r = RXO[TX[t]];
+        const double r = RXO(TX[t]);
         NK += r;
         RXYU += r * w.XYU[t];
     }
@@ -488,10 +491,10 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO, double& a
     // the walk keeps XO[i], XO[i+1], RXO[i+1] (and the same for j) in registers: one load per advance, off the
     // critical compare; every kind of step advances through the same code so that the lanes of a wave stay together
     int i = 0, j = 0;
-    double sx = RXO[0], sy = RXO[XfromY[0]];
+    double sx = RXO(0), sy = RXO(XfromY[0]);
     double xi = w.XO[0], yj = w.YO[0];
     double xn = 0.0, yn = 0.0, rxn = 0.0, ryn = 0.0;
-    if (N > 1) { xn = w.XO[1]; yn = w.YO[1]; rxn = RXO[1]; ryn = RXO[XfromY[1]]; }
+    if (N > 1) { xn = w.XO[1]; yn = w.YO[1]; rxn = RXO(1); ryn = RXO(XfromY[1]); }
     push(xi, yj, 0.0);
     while (!found && i < N && j < N) {
         const bool hi = i + 1 < N, hj = j + 1 < N;
@@ -511,13 +514,13 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO, double& a
             ++i;
             xi = xn;
             if (i < N) sx = sx + rxn;
-            if (i + 1 < N) { xn = w.XO[i + 1]; rxn = RXO[i + 1]; }
+            if (i + 1 < N) { xn = w.XO[i + 1]; rxn = RXO(i + 1); }
         }
         if (adv_j) {
             ++j;
             yj = yn;
             if (j < N) sy = sy + ryn;
-            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO[XfromY[j + 1]]; }
+            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO(XfromY[j + 1]); }
         }
     }
     if (!found) return -1;
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         } else {
             for (int i = lane; i < N; i += WV) {
                 const int own = f.ic1[i] - 1, ixo = w.TX[i];
-                for (int j = 0; j < K; ++j) f.RXO[(size_t)j * N + ixo] = (j == own) ? 1.0 : 0.0;
+                for (int j = 0; j < K; ++j) f.RXO[(size_t)ixo * K + j] = (j == own) ? 1.0 : 0.0;
             }
         }
     }
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         if (myK && s.active[myK]) {
             double a = 0.0, bb = 0.0, nk = 0.0;
             FitArrays f = fit_arrays(N, myK, wdoubles + wd_off[q * MPE_KMAX + myK - 1], wints + wi_off[q * MPE_KMAX + myK - 1]);
-            const int rc = max_likelihood_stream(w, f.RXO + (size_t)myJ * N, a, bb, nk);
+            const int rc = max_likelihood_stream(w, f.RXO + myJ, myK, a, bb, nk);
             if (rc < 0) s.state[myK] = 2;                      // the reference would read past the end: DebugCheck
             if (rc > 0) { s.A[myL] = a; s.B[myL] = bb; }
             s.W[myL] = nk / N;
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
             for (int i = lane; i < N; i += WV) {
                 const int ixo = w.TX[i];
                 const double norm = f.kd[i];
-                for (int j = 0; j < K; ++j) f.RXO[(size_t)j * N + ixo] = s.W[l0 + j] * f.EX[(size_t)j * N + i] / norm;
+                for (int j = 0; j < K; ++j) f.RXO[(size_t)ixo * K + j] = s.W[l0 + j] * f.EX[(size_t)j * N + i] / norm;
             }
         }
         __syncthreads();
