@@ -67,9 +67,9 @@ struct Work {
 // workspace of one fit with K components
 __host__ __device__ inline size_t work_doubles(int n, int K) { return (size_t)n * (2 + 4 * K + 2 + 12 + 4) + 16; }
 __host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
-// what the wave kernel uses of a fit's slot: RXO, EX (K*n each), SX, SY, kd; behind the largest fit's own arrays the ones
-// all fits of the problem share (XO, YO, X+Y+U, the k-means point array 2n, XfromY)
-__host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return (size_t)n * (2 * K + 3 + (largest ? 6 : 0)) + 16; }
+// what the wave kernel uses of a fit's slot: RXO (K*n), SX, SY, kd; behind the largest fit's own arrays the ones all fits
+// of the problem share (XO, YO, X+Y+U, the k-means point array 2n, XfromY)
+__host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return (size_t)n * (K + 3 + (largest ? 6 : 0)) + 16; }
 
 __device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
 {
@@ -711,13 +711,12 @@ struct ProblemShared {
     int n_seeds, any_active;
 };
 
-struct FitArrays { double *RXO, *EX, *SX, *SY, *kd; int *ic1, *ic2; };
+struct FitArrays { double *RXO, *SX, *SY, *kd; int *ic1, *ic2; };
 
 __device__ __forceinline__ FitArrays fit_arrays(int N, int K, double* d, int* ip)
 {
     FitArrays f;
     f.RXO = d; d += (size_t)K * N;
-    f.EX = d; d += (size_t)K * N;
     f.SX = d; d += N;
     f.SY = d; d += N;
     f.kd = d;
@@ -751,7 +750,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
 
     // arrays shared by the fits live behind the largest fit's own
     const int slot_max = q * MPE_KMAX + kmax - 1;
-    double* shared_d = wdoubles + wd_off[slot_max] + 2 * (size_t)kmax * N + 3 * (size_t)N;
+    double* shared_d = wdoubles + wd_off[slot_max] + (size_t)kmax * N + 3 * (size_t)N;
     Work w;
     w.N = N;
     w.X = x + b; w.Y = y + b; w.U = u + b;
@@ -851,29 +850,42 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         __syncthreads();
         if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
         __syncthreads();
-        // E step, fit after fit: exponents, exp, mixture sum, log
+        // E step, fit after fit: exponents, exp, mixture sum, log — and, from the same registers, the responsibilities
+        // W_j e_j / sum of UpdateResponsibilities (:139-181).  The reference updates them after the convergence test; nothing
+        // reads them between here and the next M step, and a fit that stops in this iteration never reads them again, so
+        // writing them now is the same — without the K*N array of exponentials and the second pass over it.
         for (int K = 1; K <= kmax; ++K) {
             if (!s.active[K]) continue;
             FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
             const int l0 = K * (K - 1) / 2;
             bool zero = false;
             for (int i = lane; i < N; i += WV) {
-                for (int j = 0; j < K; ++j) {
-                    const double t = (s.A[l0 + j] + s.B[l0 + j] - w.X[i] - w.Y[i] - w.U[i]) / w.sd;
-                    f.EX[(size_t)j * N + i] = -0.5 * (t * t) - LAMBDA * fmax(0.0, w.X[i] - s.A[l0 + j]) - LAMBDA * fmax(0.0, w.Y[i] - s.B[l0 + j]);
-                }
-                double maxexp = f.EX[i];
-                for (int j = 1; j < K; ++j) maxexp = fmax(maxexp, f.EX[(size_t)j * N + i]);
+                const double xi = w.X[i], yi = w.Y[i], ui = w.U[i];
+                double ex[MPE_KMAX];
+#pragma unroll
+                for (int j = 0; j < MPE_KMAX; ++j)
+                    if (j < K) {
+                        const double t = (s.A[l0 + j] + s.B[l0 + j] - xi - yi - ui) / w.sd;
+                        ex[j] = -0.5 * (t * t) - LAMBDA * fmax(0.0, xi - s.A[l0 + j]) - LAMBDA * fmax(0.0, yi - s.B[l0 + j]);
+                    }
+                double maxexp = ex[0];
+#pragma unroll
+                for (int j = 1; j < MPE_KMAX; ++j)
+                    if (j < K) maxexp = fmax(maxexp, ex[j]);
                 double sum = 0.0;
-                for (int j = 0; j < K; ++j) {
-                    const double e = exp(f.EX[(size_t)j * N + i] - maxexp);
-                    f.EX[(size_t)j * N + i] = e;
-                    sum += s.W[l0 + j] * e;
-                }
+#pragma unroll
+                for (int j = 0; j < MPE_KMAX; ++j)
+                    if (j < K) {
+                        ex[j] = exp(ex[j] - maxexp);
+                        sum += s.W[l0 + j] * ex[j];
+                    }
                 if (sum == 0.0) zero = true;
-                f.kd[i] = sum;
                 f.SX[i] = log(sum);
                 f.SY[i] = maxexp;
+                const int ixo = w.TX[i];
+#pragma unroll
+                for (int j = 0; j < MPE_KMAX; ++j)
+                    if (j < K) f.RXO[(size_t)ixo * K + j] = s.W[l0 + j] * ex[j] / sum;
             }
             if (zero) s.zero[K] = 1;
         }
@@ -915,18 +927,6 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         }
         __syncthreads();
         if (!s.any_active) break;
-        // UpdateResponsibilities (:139-181) of the fits that go on
-        for (int K = 1; K <= kmax; ++K) {
-            if (!s.active[K]) continue;
-            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
-            const int l0 = K * (K - 1) / 2;
-            for (int i = lane; i < N; i += WV) {
-                const int ixo = w.TX[i];
-                const double norm = f.kd[i];
-                for (int j = 0; j < K; ++j) f.RXO[(size_t)ixo * K + j] = s.W[l0 + j] * f.EX[(size_t)j * N + i] / norm;
-            }
-        }
-        __syncthreads();
     }
     const long long fit_iters = my_iters;                  // lane K: iterations of the fit with K components
     for (int off = 32; off > 0; off >>= 1) my_iters += __shfl_xor(my_iters, off);
