@@ -439,7 +439,7 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
 // Results are those of the lane version operation for operation: same expressions, same order, same ocml calls.
 constexpr int WV = 64;
 #ifndef MPE_WPE
-#define MPE_WPE 4       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
+#define MPE_WPE 3       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
 #endif
 
 // MaxLikelihood (:192-325) for one component in one lane, streaming: the two prefix sums advance with the

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 D=/tmp/cmp_scale
 C=$R/defuse_amd/csrc
 python3 $R/profiles/microbench/cmp_scale.py --fragments ${1:-5000000} --out $D --keep > /dev/null || exit 1
-for n in 2 3 4 5 6 8; do
+for n in 3 4 5 6; do
   B=$R/build_var/wpe$n
   mkdir -p $B/defuse_amd $B/bin
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMPE_WPE=$n -o $B/defuse_amd/libdefuse_dsa.so $C/dsa_api.hip $C/sc_api.hip $C/mpe_api.hip $C/la_api.hip $C/hc_api.hip || exit 1
