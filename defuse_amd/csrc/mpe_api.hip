@@ -438,6 +438,9 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
 //     per fit.
 // Results are those of the lane version operation for operation: same expressions, same order, same ocml calls.
 constexpr int WV = 64;
+#ifndef MPE_CHAIN
+#define MPE_CHAIN 4     // elements the serial sums of the M step load ahead of their additions
+#endif
 #ifndef MPE_WPE
 #define MPE_WPE 3       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
 #endif
@@ -456,12 +459,15 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
     const int* XfromY = w.XfromY;
     double NK = 0.0, RXYU = 0.0;
     int t = 0;
-    for (; t + 4 <= N; t += 4) {              // loads in batches so that only the additions are serial
-        double r[4], q[4];
+    for (; t + MPE_CHAIN <= N; t += MPE_CHAIN) {      // loads in batches so that only the additions are serial
+        int ix[MPE_CHAIN];
+        double r[MPE_CHAIN], q[MPE_CHAIN];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { r[v] = RXO(TX[t + v]); q[v] = w.XYU[t + v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) { ix[v] = TX[t + v]; q[v] = w.XYU[t + v]; }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) r[v] = RXO(ix[v]);
+#pragma unroll
+        for (int v = 0; v < MPE_CHAIN; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
     }
     for (; t < N; ++t) {
         const double r = RXO(TX[t]);
