@@ -864,8 +864,6 @@ inline bool AddReads(const std::string& filename, ReadStore& reads)
     return true;
 }
 
-// One record of the improper SAM: tools/AlignmentStream.cpp:39-130
-struct RawAlignment { std::string fragment, reference; int readEnd = 0, strand = 0; Region region; };
 // One SAM line (tools/AlignmentStream.cpp:39-130).  Returns 0 = a record, 1 = nothing to return (header line, rname "*"),
 // 2.. = the reference dies: 2 empty line, 3 fewer than ten fields, 4 flag or position not an integer, 5 qname "x/y" with y
 // not 1 or 2.  read_end is left alone when neither the name nor the flag bits tell it (the reference's object keeps the
@@ -919,41 +917,5 @@ inline int ParseSamLine(const char* line, size_t len, SamFields& a, int& read_en
     if (kind == 4) die("Error: bad integer in sam line " + std::to_string(line_no));        // reference: uncaught bad_lexical_cast
     die("Error: Unable to interpret qname for alignment line " + std::to_string(line_no));
 }
-
-class SamAlignmentStream {
-public:
-    explicit SamAlignmentStream(const std::string& filename)
-    {
-        file_ = filename == "-" ? stdin : fopen(filename.c_str(), "rb");
-        if (!file_) die("Error: Unable to open sam file " + filename);
-        reader_.reset(new LineReader(file_));
-    }
-    ~SamAlignmentStream() { if (file_ && file_ != stdin) fclose(file_); }
-    SamAlignmentStream(const SamAlignmentStream&) = delete;
-    SamAlignmentStream& operator=(const SamAlignmentStream&) = delete;
-    bool GetNextAlignment(RawAlignment& a)
-    {
-        const char* line;
-        size_t len;
-        SamFields f;
-        while (reader_->next(line, len)) {
-            ++line_no_;
-            const int kind = ParseSamLine(line, len, f, a.readEnd);
-            if (kind == 1) continue;
-            if (kind) DieSamLine(kind, (size_t)line_no_);
-            a.fragment.assign(f.fragment, f.fragment_len);
-            a.reference.assign(f.reference, f.reference_len);
-            a.strand = f.strand;
-            a.region = f.region;
-            return true;
-        }
-        return false;
-    }
-
-private:
-    FILE* file_ = nullptr;
-    std::unique_ptr<LineReader> reader_;
-    int line_no_ = 0;
-};
 
 }  // namespace defuse

@@ -160,7 +160,7 @@ int main(int argc, char* argv[])
     std::vector<SamPiece> pieces(nThreads);
     std::string seq;
     size_t lineBase = 0;
-    int carryReadEnd = 0;                                                // RawAlignment's initial read end
+    int carryReadEnd = 0;                                                // the reference's RawAlignment starts with read end 0
     for (size_t lo = 0; lo < sam.size();) {
         size_t hi = std::min(sam.size(), lo + ((size_t)1 << 28));
         if (hi < sam.size()) hi = sam.line_end(hi - 1);
