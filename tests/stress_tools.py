@@ -1,6 +1,6 @@
 """Randomised parity stress of the other device paths against their CPU oracles (run by hand on a GPU box:
 `python tests/stress_tools.py [rounds] [seed0]`): set cover, mate-pair EM clustering (through the drop-in
-binary) and the localalign scorer."""
+binary), the localalign scorer and the average-linkage clusterer."""
 import os
 import subprocess
 import sys
@@ -9,11 +9,13 @@ import tempfile
 import numpy as np
 
 sys.path.insert(0, ".")
-from defuse_amd import la, sc
+from defuse_amd import hc, la, sc
 from oracle import clustermatepairs_oracle as cmp_o
+from oracle import hierarchical_oracle as hc_o
 from oracle import localalign_oracle as la_o
 from oracle import setcover_oracle as sc_o
 from tests import cmp_cases
+from tests.test_hierarchical import _random_tables
 from tests.test_localalign import random_pairs
 from tests.test_setcover import random_clusters
 
@@ -33,6 +35,10 @@ def main():
         sol, _ = sc.cover(clusters)
         exp = sc_o.set_cover(clusters)
         assert [sorted(set(s)) for s in sol] == [sorted(set(s)) for s in exp], ("setcover", seed)
+        # average-linkage clusterer (continuous distances and tables full of ties in turn)
+        tabs, thr = _random_tables(seed, count=12, nmax=int(rng.integers(5, 90)), quantised=bool(r % 2))
+        got_hc, _ = hc.cluster_batch(tabs, thr)
+        assert got_hc == [hc_o.do_clustering(t, th) for t, th in zip(tabs, thr)], ("hierarchical", seed)
         # localalign scores
         prm = [(10, -5, -5), (2, -1, -2), (5, 2, -1), (1, -3, -1), (3, -2, -2)][r % 5]
         pairs = random_pairs(seed, 400, lr=(0, int(rng.integers(50, 900))), ls=(0, int(rng.integers(20, 300))),
