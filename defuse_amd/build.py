@@ -62,10 +62,15 @@ def build_tools(force=False):
 
 
 def build_oracle(force=False):
+    """The checkers: oracle/libdsa_oracle.so, oracle/libmpe_oracle.so and - only where /root/reference is present, i.e. in
+    the build container - oracle/_ref/libasa_ref.so from the reference's own asa136.C / asa241.C (oracle/Makefile)."""
     out = os.path.join(ROOT, "oracle", "libdsa_oracle.so")
+    out2 = os.path.join(ROOT, "oracle", "libmpe_oracle.so")
     srcs = [os.path.join(ROOT, "oracle", "dsa_oracle.c"), os.path.join(ROOT, "include", "defuse_dsa.h")]
-    if force or _newer(out, srcs):
-        _run(["make", "-C", os.path.join(ROOT, "oracle"), "-B"])
+    srcs2 = [os.path.join(ROOT, "oracle", "mpe_oracle.c")]
+    ref_missing = os.path.exists("/root/reference/tools/asa136.C") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libasa_ref.so"))
+    if force or _newer(out, srcs) or _newer(out2, srcs2) or ref_missing:
+        _run(["make", "-C", os.path.join(ROOT, "oracle")] + (["-B"] if force else []))
     return out
 
 

@@ -529,8 +529,9 @@ def read_fragments(lines):
         yield cur
 
 
-def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size):
-    """Returns (output text, number of clusters)."""
+def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size, em="python"):
+    """Returns (output text, number of clusters).  em="c" runs MatePairEM::DoClustering through the C restatement
+    (oracle/mpe_oracle.c, same arithmetic, ~100x faster) instead of the Python one below; tests compare the two."""
     min_fusion_range = int(frag_mean + 10 * frag_sd)
     ref_names, ref_index = [], {}
     bin_pairs = {}
@@ -569,7 +570,8 @@ def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size):
                     e = bin_pairs.setdefault((b2, b1), ([], []))
                     e[0].extend(binned[1][b2])
                     e[1].extend(binned[0][b1])
-    em = MatePairEM(frag_mean, frag_sd, precision, min_cluster_size)
+    use_c = em == "c"
+    em_obj = MatePairEM(frag_mean, frag_sd, precision, min_cluster_size)
     out = []
     cluster_id = 0
     for (b1, b2) in sorted(bin_pairs):
@@ -616,7 +618,12 @@ def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size):
                         pairs.append((i1, i2))
         mps = [(MatePairEM.strand_remap(a1[i1]["region"], a1[i1]["strand"]),
                 MatePairEM.strand_remap(a2[i2]["region"], a2[i2]["strand"])) for (i1, i2) in pairs]
-        for cl in em.do_clustering(mps):
+        if use_c:
+            from oracle import mpe_c
+            found = mpe_c.do_clustering(frag_mean, frag_sd, em_obj.min_prob, min_cluster_size, mps)
+        else:
+            found = em_obj.do_clustering(mps)
+        for cl in found:
             if len(cl) < min_cluster_size:
                 continue
             used = set()

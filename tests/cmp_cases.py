@@ -61,3 +61,79 @@ def many_loci(seed, n_loci=12, decoys=True):
             lines.append("%d\t1\tchr3\t-\t%d\t%d\n" % (frag, p + 7010, p + 7059))
             frag += 1
     return lines
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] at any fraction: loci pairs over 24 synthetic chromosomes
+# (50-250 Mb, seed 3), support per locus ~ 1/k on 1..500 (most loci fall below -m 5), ends placed
+# U(0, mu+3sigma-2*100) upstream of each breakpoint, 2x100 bp, 5 % of the fragments multi-map one end to a second
+# locus, 10 % concordant decoys; the tool runs with -m 5 -p 0.95 -u 300 -s 30.  Vectorised (numpy + pandas).
+# ------------------------------------------------------------------------------------------------------------
+MU, SIGMA, RL = 300.0, 30.0, 100
+
+
+def config3_write(n_fragments, path, seed=3):
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    chrom_len = rng.integers(50_000_000, 250_000_001, size=24)
+    k = np.arange(1, 501)
+    pk = (1.0 / k) / (1.0 / k).sum()
+    n_disc = int(n_fragments * 0.9)
+    n_loci = max(1, int(n_disc / float((k * pk).sum())))
+    support = rng.choice(k, size=n_loci, p=pk)
+    n_disc = int(support.sum())
+    ca, cb = rng.integers(0, 24, size=n_loci), rng.integers(0, 24, size=n_loci)
+    sa, sb = rng.integers(0, 2, size=n_loci), rng.integers(0, 2, size=n_loci)          # 0 '+', 1 '-'
+    ba = (rng.random(n_loci) * (chrom_len[ca] - 20000)).astype(np.int64) + 10000
+    bb = (rng.random(n_loci) * (chrom_len[cb] - 20000)).astype(np.int64) + 10000
+    locus = np.repeat(np.arange(n_loci), support)
+    inner_max = int(MU + 3 * SIGMA) - 2 * RL
+
+    def place(strand, brk, d):
+        plus = strand == 0
+        start = np.where(plus, brk - d - RL + 1, brk + d)
+        return start, start + RL - 1
+
+    da, db = rng.integers(0, inner_max + 1, size=n_disc), rng.integers(0, inner_max + 1, size=n_disc)
+    s0, e0 = place(sa[locus], ba[locus], da)
+    s1, e1 = place(sb[locus], bb[locus], db)
+    frag = np.arange(n_disc)
+    parts = [pd.DataFrame({"f": frag, "o": 0, "e": 0, "c": ca[locus], "s": sa[locus], "a": s0, "b": e0}),
+             pd.DataFrame({"f": frag, "o": 1, "e": 1, "c": cb[locus], "s": sb[locus], "a": s1, "b": e1})]
+    # 5 %: end 2 also aligns at a second locus
+    mm = np.nonzero(rng.random(n_disc) < 0.05)[0]
+    l2 = rng.integers(0, n_loci, size=len(mm))
+    s2, e2 = place(sb[l2], bb[l2], rng.integers(0, inner_max + 1, size=len(mm)))
+    parts.append(pd.DataFrame({"f": frag[mm], "o": 2, "e": 1, "c": cb[l2], "s": sb[l2], "a": s2, "b": e2}))
+    # 10 % concordant decoys: both ends on one chromosome, a fragment length apart, opposite strands
+    n_dec = n_fragments - n_disc if n_fragments > n_disc else 0
+    cd = rng.integers(0, 24, size=n_dec)
+    p = (rng.random(n_dec) * (chrom_len[cd] - 20000)).astype(np.int64) + 10000
+    fl = np.maximum(2 * RL, rng.normal(MU, SIGMA, size=n_dec).astype(np.int64))
+    fd = n_disc + np.arange(n_dec)
+    parts.append(pd.DataFrame({"f": fd, "o": 0, "e": 0, "c": cd, "s": 0, "a": p, "b": p + RL - 1}))
+    parts.append(pd.DataFrame({"f": fd, "o": 1, "e": 1, "c": cd, "s": 1, "a": p + fl - RL, "b": p + fl - 1}))
+    df = pd.concat(parts, ignore_index=True)
+    # shuffle the fragments (the aligner's output order is by read, not by locus), keep a fragment's lines together
+    perm = rng.permutation(n_disc + n_dec)
+    df["f"] = perm[df["f"].to_numpy()]
+    df.sort_values(["f", "o"], inplace=True, kind="stable")
+    df["c"] = ("chr" + (df["c"] + 1).astype(str))
+    df["s"] = np.where(df["s"].to_numpy() == 0, "+", "-")
+    df[["f", "e", "c", "s", "a", "b"]].to_csv(path, sep="\t", header=False, index=False)
+    return n_disc + n_dec, n_loci, len(df)
+
+
+
+
+def config3_lines(n_fragments, seed=3):
+    """The same input as a list of text lines (for the Python oracle)."""
+    import os, tempfile
+    fd, path = tempfile.mkstemp(suffix=".spanning.txt")
+    os.close(fd)
+    try:
+        config3_write(n_fragments, path, seed)
+        with open(path) as f:
+            return f.readlines()
+    finally:
+        os.remove(path)

@@ -197,3 +197,77 @@ def test_tool_degenerate_bin_pairs(built, tmp_path):
         r, txt = run_tool(lines, tmp_path, env={"DEFUSE_MPE_WAVE_MIN": wave_min} if wave_min else None)
         assert r.returncode == 0, r.stderr
         assert txt == exp, "DEFUSE_MPE_WAVE_MIN=%s" % wave_min
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] (2x100 bp, Zipf support 1..500, 5 % multi-mapping, 10 % decoys)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_c_em_equals_python_em(built, seed):
+    """The two restatements of MatePairEM (oracle/mpe_oracle.c, oracle/clustermatepairs_oracle.py) give the same file."""
+    from oracle import clustermatepairs_oracle as o
+    lines = cmp_cases.many_loci(seed)
+    assert o.clustermatepairs(lines, 300, 30, 0.95, 5, em="c") == o.clustermatepairs(lines, 300, 30, 0.95, 5)
+
+
+def test_c_em_equals_python_em_on_a_config3_sample(built):
+    from oracle import clustermatepairs_oracle as o
+    lines = cmp_cases.config3_lines(2500)
+    a = o.clustermatepairs(lines, 300, 30, 0.95, 5, em="c")
+    assert a == o.clustermatepairs(lines, 300, 30, 0.95, 5) and a[1] >= 20
+
+
+@pytest.mark.gpu
+def test_config3_sample_through_clustermatepairs_and_setcover(built, tmp_path):
+    """configs[2] at 40 000 fragments (about 490 loci, bin pairs of up to 500 mate pairs, K up to 10, multi-mappers, decoys):
+    bin/clustermatepairs then bin/setcover, both files byte for byte against the oracles."""
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o, setcover_oracle as so
+    build.build_tools()
+    lines = cmp_cases.config3_lines(40000)
+    r, txt = run_tool(lines, tmp_path, env={"DEFUSE_TIMING": "1"})
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5, em="c")
+    assert n > 500 and txt == exp
+    assert "Created %d clusters" % n in r.stdout
+    sizes = {}
+    for l in exp.splitlines():
+        f = l.split("\t", 2)
+        if f[1] == "0":
+            sizes[f[0]] = sizes.get(f[0], 0) + 1
+    assert max(sizes.values()) >= 300                                   # the large loci are there
+    cl, sc = tmp_path / "clusters.txt", tmp_path / "clusters.sc"
+    r = subprocess.run([os.path.join(ROOT, "bin", "setcover"), "-c", str(cl), "-m", "5", "-o", str(sc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cover = so.setcover(str(cl), 5)
+    assert sc.read_text() == cover and len(cover.splitlines()) > 10000
+
+
+@pytest.mark.gpu
+def test_config3_one_million_fragments_em_against_the_c_oracle(built, tmp_path):
+    """configs[2] at 1 M fragments: the host stages of bin/clustermatepairs write the arrays they would hand to the device
+    (DEFUSE_CMP_DUMP_EM), then mpe_cluster_batch (HIP, through the C ABI) and the C restatement run on exactly those arrays:
+    about 9 000 bin pairs, 1 M mate pairs, 2.5 M EM iterations; every membership bit must agree.  The restatement also
+    reports how close the run came to the decisions a last-ulp difference between ocml's and glibc's exp/log could flip."""
+    from defuse_amd import build, mpe
+    from oracle import mpe_c
+    from tests.mpe_dump import read_em_dump
+    build.build_tools()
+    span, dump = tmp_path / "spanning.txt", tmp_path / "em.bin"
+    cmp_cases.config3_write(1_000_000, str(span))
+    r = subprocess.run([TOOL, "-a", str(span), "-c", str(tmp_path / "unused"), "-u", "300", "-s", "30", "-p", "0.95", "-m", "5"],
+                       capture_output=True, text=True, env=dict(os.environ, DEFUSE_CMP_DUMP_EM=str(dump)))
+    assert r.returncode == 0, r.stderr
+    d = read_em_dump(str(dump))
+    assert len(d["prob_off"]) - 1 > 5000 and len(d["x"]) > 500000
+    args = (d["mean"], d["sd"], d["min_prob"], d["min_size"], d["prob_off"], d["x"], d["y"], d["u"], d["to_xo"], d["to_yo"])
+    g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
+    o_ncl, o_member, o_status, dg, _ = mpe_c.cluster_batch(*args)
+    assert not o_status.any() and not g_status.any()
+    assert (g_ncl == o_ncl).all()
+    assert g_member.tobytes() == o_member.tobytes()
+    print("config-3 1M EM margins:", dg.as_dict(), "kernel %.1f ms, device EM iterations %d (the restatement also counts the"
+          " refit of the chosen K)" % (t.kernel_ms, t.em_iterations))
+    # the knife edges (DESIGN.md section 2): all decisions are far from a last-ulp flip on this workload
+    assert dg.nk_zero_first_iter == 0 and dg.all_k_failed == 0
+    assert dg.min_prob_margin > 1e-9 and dg.min_tol_margin > 1e-9 and dg.min_bic_gap > 1e-9

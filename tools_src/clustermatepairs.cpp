@@ -545,6 +545,17 @@ int main(int argc, char* argv[])
         for (const std::string& r : refNames) d << r << "\n";
         return 0;
     }
+    if (const char* dump = std::getenv("DEFUSE_CMP_DUMP_EM")) {            // test aid: exactly the arrays mpe_cluster_batch receives, then stop
+        std::ofstream d(dump, std::ios::binary);
+        const int64_t head[2] = {(int64_t)problems.size(), (int64_t)X.size()};
+        auto put = [&](const void* p, size_t n) { d.write((const char*)p, (std::streamsize)n); };
+        put(head, sizeof(head));
+        put(&prm, sizeof(prm));
+        put(probOff.data(), probOff.size() * sizeof(int64_t));
+        put(X.data(), X.size() * sizeof(double)); put(Y.data(), Y.size() * sizeof(double)); put(U.data(), U.size() * sizeof(double));
+        put(toXO.data(), toXO.size() * sizeof(int32_t)); put(toYO.data(), toYO.size() * sizeof(int32_t));
+        return d.good() ? 0 : 1;
+    }
     std::vector<int32_t> nClusters(problems.size(), 0), status(problems.size(), 0);
     std::vector<uint16_t> member(X.size(), 0);
     if (!problems.empty()) {
