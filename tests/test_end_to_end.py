@@ -71,3 +71,86 @@ def test_pipeline_recovers_planted_breakpoint(built, tmp_path):
     assert open(d + "out.break").read() == "0\t0\tchrA\t+\t650\n0\t1\tchrB\t-\t1000\n"
     seq = open(d + "out.seq").read().split("\t")
     assert "|" in seq[1] and int(seq[3]) >= 10
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at test size: 2x150 bp, mu = 450, sigma = 45, the four tools and
+# the glue of scripts/defuse_run.pl:455-542, EVERY intermediate file compared: tool stages with the oracles, glue
+# stages with the outputs of the reference's own Perl scripts (tests/golden/config5/, tests/golden/make_config5.py).
+# ------------------------------------------------------------------------------------------------------------
+G5 = os.path.join(ROOT, "tests", "golden", "config5")
+
+
+def _pos_pairs(lines):
+    from collections import defaultdict
+    frag = defaultdict(dict)
+    for l in lines:
+        f = l.split("\t")
+        frag[int(f[2])][f[1]] = int(f[6]) if f[5] == "+" else int(f[7])
+    return sorted((v["0"], v["1"]) for v in frag.values())
+
+
+def _by_cluster(text):
+    from collections import defaultdict
+    d = defaultdict(list)
+    for l in text.splitlines():
+        d[int(l.split("\t")[0])].append(l)
+    return d
+
+
+@pytest.mark.gpu
+def test_config5_shaped_chain_every_intermediate_file(built, tmp_path):
+    import hashlib
+    import json
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as co, setcover_oracle as so, dosplitalign_oracle as do
+    from tests import e2e_case
+    build.build_tools()
+    case = e2e_case.build(str(tmp_path / "case"))
+    digest = json.load(open(os.path.join(G5, "inputs.md5.json")))
+    for p in [case[k] for k in ("fasta", "exons", "improper", "seq1", "seq2")] + case["spanning"]:
+        assert hashlib.md5(open(p, "rb").read()).hexdigest() == digest[os.path.basename(p)], p      # the inputs the Perl fixtures were made on
+    d = str(tmp_path) + "/"
+
+    def run(tool, *args, **kw):
+        r = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, **kw)
+        assert r.returncode == 0, (tool, r.stderr)
+        return r
+
+    # clustermatepairs per chromosome pair, fed through `cat files |` as the pipeline does (-a -)
+    cl_paths, n_clusters = [], 0
+    for sp in case["spanning"]:
+        out = d + "clusters." + os.path.basename(sp).split(".", 1)[1]
+        run("clustermatepairs", "-m", "5", "-p", "0.95", "-u", "450", "-s", "45", "-a", "-", "-c", out, input=open(sp).read())
+        exp, n = co.clustermatepairs(open(sp).readlines(), 450.0, 45.0, 0.95, 5, em="c")
+        assert open(out).read() == exp, sp
+        n_clusters += n
+        cl_paths.append(out)
+    assert n_clusters >= 8
+    merged = run("defuse_glue", "merge_clusters", *cl_paths).stdout
+    assert merged == open(os.path.join(G5, "clusters.all.perl.txt")).read()                    # deterministic script: byte for byte
+    open(d + "clusters.all", "w").write(merged)
+    run("setcover", "-m", "5", "-c", d + "clusters.all", "-o", d + "clusters.sc.all")
+    assert open(d + "clusters.sc.all").read() == so.setcover(d + "clusters.all", 5)
+    sc = run("defuse_glue", "remove_duplicates", "5", input=open(d + "clusters.sc.all").read()).stdout
+    g, e = _by_cluster(sc), _by_cluster(open(os.path.join(G5, "clusters.sc.perl.txt")).read())
+    assert sorted(g) == sorted(e) and len(sc.splitlines()) < len(open(d + "clusters.sc.all").read().splitlines())   # duplicates were planted
+    for cid in g:                                                   # which duplicate stays is Perl hash order in the script
+        assert len(g[cid]) == len(e[cid]) and _pos_pairs(g[cid]) == _pos_pairs(e[cid])
+    regions = run("defuse_glue", "get_align_regions", input=sc).stdout
+    assert sorted(regions.splitlines()) == sorted(open(os.path.join(G5, "clusters.sc.regions.perl.txt")).read().splitlines())
+    open(d + "clusters.sc.regions", "w").write(regions)
+    common = ["-f", case["fasta"], "-e", case["exons"], "-u", "450", "-s", "45", "-n", "150", "-x", "150", "-r", d + "clusters.sc.regions"]
+    ocommon = (case["fasta"], case["exons"], 450.0, 45.0, 150, 150, d + "clusters.sc.regions")
+    run("dosplitalign", *common, "-i", case["improper"], "-1", case["seq1"], "-2", case["seq2"], "-a", d + "splitreads.alignments")
+    exp = do.dosplitalign(*ocommon, case["improper"], case["seq1"], case["seq2"])
+    assert open(d + "splitreads.alignments").read() == exp and len(exp.splitlines()) > 1000
+    r = subprocess.run(["sort", "-n", "-k", "1", "-s", d + "splitreads.alignments"], capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"))
+    assert r.returncode == 0
+    open(d + "splitreads.alignments.sorted", "w").write(r.stdout)
+    run("evalsplitalign", *common, "-a", d + "splitreads.alignments.sorted", "-q", d + "out.seq", "-b", d + "out.break", "-p", d + "out.predalign")
+    seq, brk, pred = do.evalsplitalign(*ocommon, d + "splitreads.alignments.sorted")
+    assert open(d + "out.seq").read() == seq and open(d + "out.break").read() == brk and open(d + "out.predalign").read() == pred
+    found = {tuple(l.split("\t")[2:5]) for l in brk.splitlines()}
+    for (ca, sa, ba, cb, sb, bb) in case["planted"][2:5]:            # the planted junctions come back (those without microhomology exactly)
+        assert (ca, sa, str(ba)) in found and (cb, sb, str(bb)) in found
