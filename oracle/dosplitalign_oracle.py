@@ -267,13 +267,16 @@ def read_align_region_pairs(path):
             fields = line.split("\t")
             if len(fields) < 5:
                 continue
-            pid, pend = lexical_cast_int(fields[0]), lexical_cast_int(fields[1])
-            assert pend in (0, 1)
-            strand = PLUS if fields[3] == "+" else MINUS
-            if fields[3] not in ("+", "-"):
-                raise SystemExit("Error: Unable to intepret strand " + fields[3])
-            loc = dict(refName=fields[2], strand=strand, start=lexical_cast_int(fields[4]),
-                       end=lexical_cast_int(fields[5]))
+            try:                                        # the catch clause of :254-258: message on stdout, exit(1)
+                pid, pend = lexical_cast_int(fields[0]), lexical_cast_int(fields[1])
+                assert pend in (0, 1)
+                strand = PLUS if fields[3] == "+" else MINUS
+                if fields[3] not in ("+", "-"):
+                    raise SystemExit("Error: Unable to intepret strand " + fields[3])
+                loc = dict(refName=fields[2], strand=strand, start=lexical_cast_int(fields[4]),
+                           end=lexical_cast_int(fields[5]))
+            except ValueError:
+                raise SystemExit("Failed to interpret region:\n" + line)
             pairs.setdefault(pid, [None, None])[pend] = loc
     return OrderedDict(sorted(pairs.items()))  # std::map<int,...> iterates ascending
 

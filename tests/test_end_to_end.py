@@ -145,7 +145,7 @@ def test_config5_shaped_chain_every_intermediate_file(built, tmp_path):
     run("dosplitalign", *common, "-i", case["improper"], "-1", case["seq1"], "-2", case["seq2"], "-a", d + "splitreads.alignments")
     exp = do.dosplitalign(*ocommon, case["improper"], case["seq1"], case["seq2"])
     assert open(d + "splitreads.alignments").read() == exp and len(exp.splitlines()) > 1000
-    r = subprocess.run(["sort", "-n", "-k", "1", "-s", d + "splitreads.alignments"], capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"))
+    r = subprocess.run(["sort", "-n", "-k", "1", d + "splitreads.alignments"], capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"))
     assert r.returncode == 0
     open(d + "splitreads.alignments.sorted", "w").write(r.stdout)
     run("evalsplitalign", *common, "-a", d + "splitreads.alignments.sorted", "-q", d + "out.seq", "-b", d + "out.break", "-p", d + "out.predalign")
