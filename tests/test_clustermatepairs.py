@@ -235,7 +235,7 @@ def test_config3_sample_through_clustermatepairs_and_setcover(built, tmp_path):
         f = l.split("\t", 2)
         if f[1] == "0":
             sizes[f[0]] = sizes.get(f[0], 0) + 1
-    assert max(sizes.values()) >= 300                                   # the large loci are there
+    assert max(sizes.values()) >= 150                                   # the large loci are there (EM splits them into components)
     cl, sc = tmp_path / "clusters.txt", tmp_path / "clusters.sc"
     r = subprocess.run([os.path.join(ROOT, "bin", "setcover"), "-c", str(cl), "-m", "5", "-o", str(sc)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
