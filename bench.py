@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — split-read DP aligns/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A "step" is one pass of the hot path (pack -> DP fill -> combine/replay/emit) over one batch of
-synthetic candidates that is already resident in HBM.  At N=1 the batch is BASELINE.json configs[1]
-(10k synthetic fusions x 100 reads, 2x76 bp => Lref 389, 1M aligns).  With N>1 ranks every rank
-holds its own batch of the same shape (fusions are independent, no data-path collective: weak
-scaling; --strong instead splits --fusions over the ranks); the timed region has no collective beyond the barrier/max-reduction of the timing.  After it,
-with N>1, the final gather of the result records on rank 0 (the path's one exchange step) is
-run and timed on its own over RCCL: HBM -> xGMI -> rank 0's HBM, reported as "gather" in the JSON line.
+A "step" is one pass of the hot path (pack -> DP fill -> combine / replay / emit) over the whole job's synthetic
+candidates, which are resident in HBM before the timed region starts.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+  N = 1   BASELINE.json configs[1]: 10k synthetic fusions x 100 reads, 2x76 bp (Lref 389), 1 M aligns, one upload.
+  N > 1   BASELINE.json configs[3], STRONG scaling: 1 M fusions x 200 reads, 2x100 bp (Lref 390), 200 M aligns in all;
+          rank r takes the contiguous fusion range [r F/N, (r+1) F/N) and keeps it resident as several uploads (one
+          dsa_ctx each: an upload addresses its read bytes with 32-bit offsets, include/defuse_dsa.h), which a step runs
+          one after the other.  Fusions are independent (tools/SplitAlignment.cpp:292), so the timed region holds no
+          collective beyond the barrier / max-reduction of the clock.  After it the path's one exchange step — the
+          gather of all result records on rank 0 — runs once over RCCL, device to device, and is
+          reported by itself ("gather"); if it fails the run fails.  Rank 0 then repeats its own share alone
+          ("one_gpu_same_share") so that the line shows what a GPU does on that share with the other ranks idle.
+  --workload config2|config4 and --fusions/--reads/--lq/--lr override the defaults (--fusions is the whole job).
+
+    python bench.py                       # N = 1
+    python bench.py --gpus 2              # starts its own 2 ranks (children, before this process touches a GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,44 +34,67 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+WORKLOADS = {"config2": dict(fusions=10000, reads=100, lq=76, lr=389),
+             "config4": dict(fusions=1000000, reads=200, lq=100, lr=390)}
+UPLOAD_FUSIONS = 50000     # fusions per upload of a multi-upload share: 10 M aligns, 1 GB of read bytes at config 4
+UPLOAD_SCRATCH = 3 << 30   # scratch planes per pipeline lane of such an upload
 
 
-def measured_traffic(args):
-    """HBM bytes per fill launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    separate runs, gfx950 correction applied) — only if they were taken on this very workload."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+def library_hash():
+    from defuse_amd import dsa
+    lib = dsa.load_library()
+    return lib.dsa_version().decode().split()[-1]
+
+
+def profile_block(name, workload, lib_hash):
+    """A committed rocprofv3 counter summary (profiles/r02/<name>), only if it was taken on this workload AND on the
+    kernels that are running now (same hash of defuse_amd/csrc + flags as the loaded library reports)."""
+    path = os.path.join(PROFILE_DIR, name)
     try:
         d = json.load(open(path))
-    except OSError:
-        return None, None
+    except (OSError, ValueError):
+        return None, "no %s" % os.path.relpath(path, ROOT)
     w = d.get("workload", {})
-    if (w.get("fusions"), w.get("reads"), w.get("lq"), w.get("lr")) != (args.fusions, args.reads, args.lq, args.lr):
-        return None, None
-    return d["hbm_bytes_per_launch"], "profiles/r01/pmc_traffic.json"
+    if tuple(w.get(k) for k in ("fusions", "reads", "lq", "lr")) != tuple(workload[k] for k in ("fusions", "reads", "lq", "lr")):
+        return None, "%s was taken on another workload" % os.path.relpath(path, ROOT)
+    if d.get("source_hash") != lib_hash:
+        return None, "%s was taken on other kernels (source hash %s, library %s): re-profile" % (
+            os.path.relpath(path, ROOT), d.get("source_hash"), lib_hash)
+    return d, os.path.relpath(path, ROOT)
 
 
-def valu_issue(args, launch_ms):
-    """The roofline that binds this integer kernel (not HBM, not MFMA): VALU issue.  Wave instructions per
-    launch come from the committed SQ counter passes of this very workload (SQ_INSTS_VALU, profiles/r01/pmc_sq.json: one
-    quad-cycle of issue per wave instruction whatever its kind); the duration is the live HIP-event time of this run; the
-    peak is 256 CUs x 4 SIMDs x one wave instruction per 4 cycles at the 2.4 GHz nominal clock."""
-    if (args.fusions, args.reads, args.lq, args.lr) != (10000, 100, 76, 389):
-        return None
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_sq.json")))
-    except OSError:
-        return None
-    instr = d["pass1"]["SQ_INSTS_VALU"] / d["launches"]
-    peak = 256 * 4 * 2.4e9 / 4
-    achieved = instr / (launch_ms * 1e-3)
-    return {"achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": achieved / peak,
-            "valu_instructions_per_launch": instr, "source": "profiles/r01/pmc_sq.json (SQ_INSTS_VALU) / live kernel_ms"}
+def valu_issue(workload, lib_hash, launch_ms):
+    """The unit that binds this integer kernel (not HBM, not MFMA) is VALU issue.  Wave instructions per launch
+    by kind come from the SQ counter passes of this build (pmc_sq.json); the duration is this run's HIP-event time; the
+    peak prices every kind at its measured issue rate (profiles/microbench/valu_rate*.hip: 2 cycles per wave for
+    v_add_u32 / v_sub / v_xor and the other plain VOP2 integer ops, 4 for VOP3P and max3), per SIMD, at the nominal 2.4 GHz."""
+    d, src = profile_block("pmc_sq.json", workload, lib_hash)
+    if d is None:
+        return None, src
+    n = d["launches"]
+    instr = d["pass1"]["SQ_INSTS_VALU"] / n
+    busy_quads = d["pass1"].get("SQ_ACTIVE_INST_VALU", 0) / n            # quad-cycles in which a SIMD issued VALU
+    simds = 256 * 4
+    kernel_cycles = launch_ms * 1e-3 * 2.4e9
+    out = {"valu_instructions_per_launch": instr,
+           "issue_cycles_flat4": 4.0 * instr / simds, "kernel_cycles_nominal": kernel_cycles,
+           "frac_flat4": 4.0 * instr / simds / kernel_cycles,
+           "measured_busy_frac": (4.0 * busy_quads / simds / kernel_cycles) if busy_quads else None,
+           "unit": "cycles per SIMD at 2.4 GHz nominal", "source": src}
+    mix = d.get("mix")             # {"two_cycle": share, "four_cycle": share} of the kernel's VALU instructions (ISA dump)
+    if mix:
+        per = 2.0 * mix["two_cycle"] + 4.0 * mix["four_cycle"]
+        out["issue_cycles_priced"] = per * instr / simds
+        out["frac_priced"] = per * instr / simds / kernel_cycles
+        out["mix"] = mix
+    return out, src
 
 
 def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
-    """Times the CPU oracle (a literal port of the reference's algorithm, oracle/dsa_oracle.c) on a
-    bounded sample of the same workload: one thread per host core this process may use (the way deFuse
-    itself scales: one dosplitalign per read chunk), each on its own contiguous share of the sample."""
+    """Times the CPU oracle (a literal port of the reference's algorithm, oracle/dsa_oracle.c) on a bounded sample of the
+    same workload: one thread per host core this process may use (the way deFuse itself scales: one dosplitalign per read
+    chunk), each on its own contiguous share of the sample.  Returns the block and the records of the first share."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import dosplitalign_oracle as ora
     n = 256
@@ -79,62 +111,146 @@ def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
     chunks = [c for c in chunks if len(c)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=len(chunks)) as ex:      # the C oracle runs without the GIL
-        list(ex.map(lambda c: ora.align_batch(ref, fus, reads, c), chunks))
+        res = list(ex.map(lambda c: ora.align_batch(ref, fus, reads, c), chunks))
     dt = time.perf_counter() - t0
     total = sum(len(c) for c in chunks)
     return {"value": total / dt, "unit": "aligns/s", "cores": len(chunks), "kind": "port",
             "sample": "first %d aligns of the same batch in %d shares, oracle/dsa_oracle.c, one thread per share, %.1f s "
-                      "(one thread alone: %.0f aligns/s)" % (total, len(chunks), dt, 1.0 / per)}
+                      "(one thread alone: %.0f aligns/s)" % (total, len(chunks), dt, 1.0 / per)}, res[0], len(chunks[0])
 
 
-def gather_leg(ctx, n_rec, n_pairs, rank, world, backend, barrier, reps=5):
-    """The final gather of one step's records on rank 0 (defuse_amd/shard.py:gather_records), timed by itself:
-    records go device -> device; max over ranks by construction (rank 0 waits for every peer)."""
+class Share:
+    """One rank's part of the job: its fusion range, resident as one or several uploads."""
+
+    def __init__(self, dsa, synth, device_index, workload, f_lo, f_hi, seed_base, on_device, log, upload_fusions=UPLOAD_FUSIONS, keep_batches=False):
+        import numpy as np
+        self.ctxs, self.n_pairs, self.pair_base = [], [], []
+        self.first_batch = None
+        self.batches = [] if keep_batches else None
+        n_up = 1 if not on_device else max(1, -(-(f_hi - f_lo) // upload_fusions))
+        per = -(-(f_hi - f_lo) // n_up)
+        lo = f_lo
+        while lo < f_hi:
+            hi = min(f_hi, lo + per)
+            t0 = time.perf_counter()
+            if on_device:
+                b = synth.make_batch_device(hi - lo, workload["reads"], workload["lq"], workload["lr"], seed_base + lo,
+                                            "cuda:%d" % device_index, fusion_id_base=lo)
+            else:
+                b = synth.make_batch(hi - lo, workload["reads"], lq=workload["lq"], lr=workload["lr"], seed=seed_base)
+            ctx = dsa.Context(device_index)
+            if n_up > 1:
+                ctx.set_scratch_budget(UPLOAD_SCRATCH)
+            ctx.upload(*b)
+            self.ctxs.append(ctx)
+            self.n_pairs.append(len(b[3]))
+            self.pair_base.append(lo * workload["reads"])
+            if self.first_batch is None:
+                self.first_batch = b
+            if keep_batches:
+                self.batches.append(b)
+            log("fusions [%d, %d): %d aligns generated and uploaded in %.1f s" % (lo, hi, len(b[3]), time.perf_counter() - t0))
+            lo = hi
+        self.total_pairs = int(np.sum(self.n_pairs))
+
+    def run(self):
+        """One step over the share; returns (records, per-upload timings)."""
+        n, ts = 0, []
+        for ctx in self.ctxs:
+            n += ctx.run()                     # synchronous: returns after the upload's last kernel finished
+            ts.append(ctx.timing())
+        return n, ts
+
+    def close(self):
+        for ctx in self.ctxs:
+            ctx.close()
+
+
+def gather_job(share, rank, world, backend, barrier):
+    """The final gather of the job's records on rank 0 (defuse_amd/shard.py:gather_records), once, after the timed steps:
+    every upload's records are copied device -> device into one tensor per rank (pair numbers made job-wide), then one
+    all_gather of the counts and one group of exact-size isend/irecv.  Any failure propagates (non-zero exit)."""
     import torch
     from defuse_amd import shard
-    try:
-        buf = torch.empty((max(n_rec, 1), shard.RECORD_WORDS), dtype=torch.int32, device="cuda")
-        got = ctx.records_to_device(buf.data_ptr(), buf.shape[0])
-        rows = buf[:got] if backend == "nccl" else buf[:got].cpu()      # gloo rehearsal: host tensors
-        base = rank * n_pairs
-        out, counts = shard.gather_records(rows, pair_base=base)       # untimed first call (communicator set-up)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out, counts = shard.gather_records(rows, pair_base=base)
-        barrier()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        if rank != 0:
-            return None
-        total = sum(counts)
-        ok = out.shape[0] == total
-        lo = 0
-        for r, c in enumerate(counts):             # every rank's records arrived in its slot, renumbered job-wide
-            if c:
-                col = out[lo:lo + c, shard.RECORD_WORDS - 1]
-                ok = ok and int(col.min()) >= r * n_pairs and int(col.max()) < (r + 1) * n_pairs
-            lo += c
-        nbytes = (total - counts[0]) * shard.RECORD_WORDS * 4
-        return {"ms": ms, "records": total, "bytes_moved": nbytes, "GB/s": nbytes / (ms * 1e-3) / 1e9, "verified": bool(ok),
-                "backend": "rccl" if backend == "nccl" else backend, "included_in_value": False,
-                "pattern": "all_gather of counts + grouped isend/irecv, exact sizes, peers -> rank 0"}
-    except Exception as e:                          # the throughput line must survive a failed gather
-        return {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+    n_rec = [int(c.timing().n_records) for c in share.ctxs]
+    buf = torch.empty((max(sum(n_rec), 1), shard.RECORD_WORDS), dtype=torch.int32, device="cuda")
+    at = 0
+    for ctx, n, base in zip(share.ctxs, n_rec, share.pair_base):
+        got = ctx.records_to_device(buf[at:].data_ptr(), buf.shape[0] - at)
+        assert got == n
+        buf[at:at + n, shard.RECORD_WORDS - 1] += base
+        at += n
+    rows = buf[:at] if backend == "nccl" else buf[:at].cpu()      # gloo rehearsal: host tensors
+    pair_lo, pair_hi = share.pair_base[0], share.pair_base[-1] + share.n_pairs[-1]
+    barrier()
+    t0 = time.perf_counter()
+    out, counts = shard.gather_records(rows)
+    barrier()
+    ms = (time.perf_counter() - t0) * 1e3
+    bounds = torch.tensor([pair_lo, pair_hi], dtype=torch.int64, device=rows.device)
+    allb = torch.zeros(2 * world, dtype=torch.int64, device=rows.device)
+    torch.distributed.all_gather_into_tensor(allb, bounds)
+    if rank != 0:
+        return None
+    total = sum(counts)
+    if out.shape[0] != total:
+        raise RuntimeError("gather: %d records arrived, %d announced" % (out.shape[0], total))
+    lo = 0
+    for r, c in enumerate(counts):             # every rank's records arrived in its slot with its own pair numbers
+        if c:
+            col = out[lo:lo + c, shard.RECORD_WORDS - 1]
+            if int(col.min()) < int(allb[2 * r]) or int(col.max()) >= int(allb[2 * r + 1]):
+                raise RuntimeError("gather: records of rank %d carry pair numbers outside its share" % r)
+        lo += c
+    nbytes = (total - counts[0]) * shard.RECORD_WORDS * 4
+    return {"ms": ms, "records": total, "bytes_moved": nbytes, "GB/s": nbytes / (ms * 1e-3) / 1e9, "verified": True,
+            "backend": "rccl" if backend == "nccl" else backend, "included_in_value": False, "times_per_job": 1,
+            "pattern": "all_gather of counts + grouped isend/irecv, exact sizes, peers -> rank 0"}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children (before this process touches a GPU) with
+    the environment torch.distributed.run would give them, relay rank 0's line, fail if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="default 100 at config 2, 20 at config 4")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--fusions", type=int, default=10000)
-    ap.add_argument("--reads", type=int, default=100)
-    ap.add_argument("--lq", type=int, default=76)
-    ap.add_argument("--lr", type=int, default=389)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None, help="default: config2 at N = 1, config4 (strong scaling) at N > 1")
+    ap.add_argument("--fusions", type=int, default=None, help="fusions of the WHOLE job")
+    ap.add_argument("--reads", type=int, default=None)
+    ap.add_argument("--lq", type=int, default=None)
+    ap.add_argument("--lr", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --fusions is the whole job, every rank takes fusions/N of it (default: weak, --fusions per rank)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        spawn_ranks(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; start it as\n  python bench.py --gpus %d\nor\n  python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d\n"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
@@ -142,12 +258,17 @@ def main():
 
     from defuse_amd import dsa, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    name = args.workload or ("config2" if world == 1 else "config4")
+    workload = dict(WORKLOADS[name])
+    for k in ("fusions", "reads", "lq", "lr"):
+        if getattr(args, k) is not None:
+            workload[k] = getattr(args, k)
+    custom = workload != WORKLOADS[name]
+    steps = args.steps if args.steps is not None else (100 if workload["fusions"] * workload["reads"] <= 4_000_000 else 20)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # one process per GPU; DEFUSE_BENCH_BACKEND=gloo lets two ranks share one card for a rehearsal
+    # one process per GPU; DEFUSE_BENCH_BACKEND=gloo lets several ranks share one card for a rehearsal
     backend = os.environ.get("DEFUSE_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -158,11 +279,15 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    # every rank: its own shard of candidate fusions (different seed => different data, same shape)
-    n_fus = args.fusions if not args.strong else max(1, args.fusions // world + (1 if rank < args.fusions % world else 0))
-    ref, fus, reads, pairs = synth.make_batch(n_fus, args.reads, lq=args.lq, lr=args.lr, seed=2 + rank)
-    ctx = dsa.Context(local_rank)
-    ctx.upload(ref, fus, reads, pairs)
+    def log(msg):
+        sys.stderr.write("[bench rank %d] %s\n" % (rank, msg))
+        sys.stderr.flush()
+
+    # this rank's contiguous fusion range of the job
+    F = workload["fusions"]
+    f_lo, f_hi = F * rank // world, F * (rank + 1) // world
+    multi = world > 1 or (f_hi - f_lo) * workload["reads"] * workload["lq"] >= 2 ** 31 - 2 ** 20 or (f_hi - f_lo) > 2 * UPLOAD_FUSIONS
+    share = Share(dsa, synth, local_rank, workload, f_lo, f_hi, seed_base=2 if not multi else 1000, on_device=multi, log=log)
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,71 +297,104 @@ def main():
 
     n_rec = 0
     for _ in range(args.warmup):
-        n_rec = ctx.run()
+        n_rec, _ = share.run()
     barrier()
-    fill_ms, pack_ms, finish_ms = [], [], []
+    fill_ms, pack_ms, finish_ms, launches = [], [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_rec = ctx.run()                      # synchronous: returns after the last kernel finished
-        t = ctx.timing()
-        fill_ms.append(t.fill_ms / max(1, t.fill_launches))
-        pack_ms.append(t.pack_ms)
-        finish_ms.append(t.finish_ms)
+    for _ in range(steps):
+        n_rec, ts = share.run()
+        fill_ms.append(sum(t.fill_ms for t in ts))
+        launches.append(sum(t.fill_launches for t in ts))
+        pack_ms.append(sum(t.pack_ms for t in ts))
+        finish_ms.append(sum(t.finish_ms for t in ts))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        nn = torch.tensor([len(pairs) * args.steps, n_rec], dtype=torch.int64, device=red_dev)
+        nn = torch.tensor([share.total_pairs * steps, n_rec], dtype=torch.int64, device=red_dev)
         dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        total_aligns = int(nn[0].item())
+        total_aligns, job_records = int(nn[0].item()), int(nn[1].item())
     else:
-        total_aligns = len(pairs) * args.steps
+        total_aligns, job_records = share.total_pairs * steps, n_rec
 
     gather = None
-    if world > 1 and os.environ.get("DEFUSE_BENCH_GATHER", "1") != "0":
-        gather = gather_leg(ctx, n_rec, len(pairs), rank, world, backend, barrier)
+    alone = None
+    if world > 1:
+        if os.environ.get("DEFUSE_BENCH_GATHER", "1") != "0":
+            gather = gather_job(share, rank, world, backend, barrier)       # raises on failure: the run fails
+        # rank 0 alone on its share, the other ranks idle at the barrier
+        if rank == 0:
+            k = max(3, steps // 4)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                share.run()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            rate = share.total_pairs * k / dt
+            alone = {"aligns_per_s": rate, "steps": k, "aligns_per_step": share.total_pairs,
+                     "efficiency_vs_this": (total_aligns / elapsed) / (world * rate),
+                     "note": "rank 0 repeats its own share with the other ranks idle; efficiency = value / (n_gpus x this)"}
+        barrier()
 
     if rank == 0:
-        t = ctx.timing()
-        rec_per_align = n_rec / len(pairs)
-        bytes_per_align = synth.algorithmic_bytes_per_align(args.lq, args.lr, args.reads, rec_per_align)
-        launch_ms = float(np.mean(fill_ms))
-        aligns_per_launch = len(pairs) / max(1, t.fill_launches)
+        lib_hash = library_hash()
+        t = share.ctxs[0].timing()
+        rec_per_align = n_rec / share.total_pairs
+        bytes_per_align = synth.algorithmic_bytes_per_align(workload["lq"], workload["lr"], workload["reads"], rec_per_align)
+        n_launch = float(np.mean(launches))
+        launch_ms = float(np.mean(fill_ms)) / max(1.0, n_launch)
+        aligns_per_launch = share.total_pairs / max(1.0, n_launch)
         achieved = bytes_per_align * aligns_per_launch / (launch_ms * 1e-3) / 1e9
-        cells = synth.cells_per_align(args.lq, args.lr)
-        traffic, traffic_src = measured_traffic(args)
+        cells = synth.cells_per_align(workload["lq"], workload["lr"])
+        tr, tr_src = profile_block("pmc_traffic.json", workload, lib_hash)
+        traffic = tr["hbm_bytes_per_launch"] if tr else None
+        vi, vi_src = valu_issue(workload, lib_hash, launch_ms)
         out = {
             "metric": "split-read DP aligns/sec", "value": total_aligns / elapsed, "unit": "aligns/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "%dk synthetic candidate fusions x %d reads, 2x%d bp (Lref %d), split-read DP + split search, bit-exact"
-                                   % (args.fusions // 1000, args.reads, args.lq, args.lr),
-                       "aligns_per_step_per_gpu": len(pairs), "cells_per_align": cells,
-                       "records_per_align": round(rec_per_align, 4), "parallelism": "fusion-sharded x%d" % world},
+            "config": {"workload": "BASELINE %s%s: %s synthetic candidate fusions x %d reads, 2x%d bp (Lref %d), split-read DP + split search, "
+                                   "bit-exact; whole job = %d aligns per step" % (
+                                       "configs[1]" if name == "config2" else "configs[3]", " (custom sizes)" if custom else "",
+                                       ("%dk" % (F // 1000)) if F < 1000000 else ("%gM" % (F / 1e6)), workload["reads"], workload["lq"],
+                                       workload["lr"], F * workload["reads"]),
+                       "aligns_per_step_this_gpu": share.total_pairs, "uploads_this_gpu": len(share.ctxs), "cells_per_align": cells,
+                       "records_per_align": round(rec_per_align, 4), "job_records": job_records,
+                       "parallelism": "contiguous fusion ranges over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_fill_fast", "kernel_ms": launch_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tr_src,
+                         "traffic_over_algorithmic": (traffic / (bytes_per_align * aligns_per_launch)) if traffic else None,
+                         "kernel": "k_fill_fast", "kernel_ms": launch_ms, "launches_per_step": n_launch,
                          "algorithmic_bytes_per_align": round(bytes_per_align, 2),
                          "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
-                         "valu_issue": valu_issue(args, launch_ms),
-                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)): "
-                                 "profiles/r01/pmc_sq.json has the kernel at 0.81 of the VALU issue slots of a nominal 2.4 GHz clock; "
-                                 "traffic >> algorithmic bytes because tile checkpoints and tile maxima "
-                                 "(needed for exact tie enumeration) stream through HBM, see DESIGN.md 5"},
-            "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)) * max(1, t.fill_launches),
-                         "finish": float(np.mean(finish_ms))},
-            "replay_tiles_per_align": round(t.n_replay_tasks / len(pairs), 4),
-            "generic_replay_tiles_per_align": round(t.n_generic_tasks / len(pairs), 4),
+                         "valu_issue": vi, "valu_issue_source": vi_src, "library_source_hash": lib_hash,
+                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)); traffic >> algorithmic "
+                                 "bytes because tile checkpoints and tile maxima (needed for exact tie enumeration) stream through HBM, "
+                                 "see DESIGN.md 5; traffic / valu_issue are null unless the committed counters carry this library's source hash"},
+            "stage_ms": {"pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)), "finish": float(np.mean(finish_ms))},
+            "replay_tiles_per_align": round(t.n_replay_tasks / max(1, share.n_pairs[0]), 4),
+            "generic_replay_tiles_per_align": round(t.n_generic_tasks / max(1, share.n_pairs[0]), 4),
         }
         if gather is not None:
             out["gather"] = gather
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ref, fus, reads, pairs)
+            out["job_aligns_per_s_with_one_gather"] = total_aligns / (elapsed + steps * gather["ms"] * 1e-3)
+        if alone is not None:
+            out["one_gpu_same_share"] = alone
+        if world == 1 and not args.no_cpu_baseline:
+            ref, fus, reads, pairs = share.first_batch
+            base, ora_recs, n_checked = cpu_baseline(ref, fus, reads, pairs)
+            got = share.ctxs[0].download()
+            got = got[got["pair_idx"] < n_checked]
+            base["gpu_records_equal_on_first_share"] = bool(got.tobytes() == ora_recs.tobytes())
+            if not base["gpu_records_equal_on_first_share"]:
+                raise SystemExit("bench.py: GPU records differ from the oracle on the sample")
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    ctx.close()
+    share.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,11 +29,31 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_lib(force=False):
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
+LIB_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def lib_sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
            [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h")]
+
+
+def source_hash(extra_flags=()):
+    """12 hex digits over the library's sources and compile flags.  Compiled into the library (dsa_version()) and written
+    into every profile JSON (profiles/microbench/*.sh), so that bench.py can tell whether committed counters were taken on
+    the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in lib_sources():
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    h.update(" ".join(LIB_FLAGS + list(extra_flags)).encode())
+    return h.hexdigest()[:12]
+
+
+def build_lib(force=False):
+    srcs = lib_sources()
     if force or _newer(LIB, srcs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+        _run([HIPCC] + LIB_FLAGS + ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(),
               "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip"),
               os.path.join(CSRC, "la_api.hip"), os.path.join(CSRC, "hc_api.hip")])
     return LIB

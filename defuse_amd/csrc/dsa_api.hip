@@ -4,6 +4,8 @@
 // reference) for whole batches.  There is deliberately no CPU fallback in this file: without a HIP
 // device dsa_create fails and every other entry point needs a ctx.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/file.h>
 #include <unistd.h>
 #include <hipcub/hipcub.hpp>
 
@@ -576,7 +578,12 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
 
 extern "C" {
 
-const char* dsa_version(void) { return "defuse_amd dsa 0.1 (gfx950)"; }
+#ifndef DSA_BUILD_HASH
+#define DSA_BUILD_HASH "unknown"
+#endif
+// the last word is the hash of the sources and flags this library was built from (defuse_amd/build.py): profiles carry the
+// same hash, so a bench line can tell whether committed counters belong to the kernels that are running
+const char* dsa_version(void) { return "defuse_amd dsa 0.2 (gfx950) src " DSA_BUILD_HASH; }
 
 int dsa_device_count(void)
 {
@@ -584,11 +591,38 @@ int dsa_device_count(void)
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+// Among n devices: the first one, counting from pid mod n, whose lock file this process can take (held until the
+// process ends, released by the kernel even after a crash); with all n taken, pid mod n.  So up to n tool processes
+// started side by side (scripts/defuse_run.pl --parallel) land on n different GPUs instead of colliding at random.
+int dsa_pick_device_among(int n)
+{
+    if (n <= 1) return 0;
+    const int start = (int)((unsigned long)getpid() % (unsigned long)n);
+    const char* dir = getenv("DEFUSE_GPU_LOCK_DIR");
+    if (!dir) dir = "/tmp";
+    for (int k = 0; k < n; ++k) {
+        const int d = (start + k) % n;
+        char path[512];
+        snprintf(path, sizeof path, "%s/defuse_gpu.%d.lock", dir, d);
+        const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd < 0) continue;
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) return d;        // fd stays open on purpose: it is the claim
+        close(fd);
+    }
+    return start;
+}
+
 int dsa_pick_device(void)
 {
     if (const char* e = getenv("DEFUSE_GPU")) return atoi(e);
-    const int n = dsa_device_count();
-    return n > 1 ? (int)((unsigned long)getpid() % (unsigned long)n) : 0;
+    return dsa_pick_device_among(dsa_device_count());
+}
+
+int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes)
+{
+    if (!ctx || bytes <= 0) return DSA_E_ARG;
+    ctx->scratch_budget = (size_t)bytes;
+    return DSA_OK;
 }
 
 int dsa_create(dsa_ctx** out, int device)

@@ -81,3 +81,61 @@ def algorithmic_bytes_per_align(lq, lr, reads_per_fusion, records_per_align):
     c4 = lambda x: -(-x // 4)
     c8 = lambda x: -(-x // 8)
     return c4(lq) + c8(lq) + 2.0 * (c4(lr) + c8(lr)) / reads_per_fusion + 12 + 36.0 * records_per_align
+
+
+def make_batch_device(n_fusions, reads_per_fusion, lq, lr, seed, device, fusion_id_base=0, sub_rate=0.01, n_rate=0.005):
+    """The same recipe as make_batch, drawn on the GPU with torch (plumbing: a share of BASELINE configs[3] is tens of
+    millions of reads, which numpy index arrays would take minutes and tens of GB of host memory to build), returned as
+    host numpy arrays in the C-ABI layout.  Not bit-identical to make_batch (different generator); deterministic in
+    (seed, sizes).  Reads are drawn in chunks so the index tensors stay small."""
+    import torch
+    F, P = int(n_fusions), int(reads_per_fusion)
+    n = F * P
+    if n * lq >= 2 ** 31 or F * 2 * lr >= 2 ** 31:
+        raise ValueError("one upload holds less than 2 GiB of read bytes and of window bytes (32-bit offsets, include/defuse_dsa.h)")
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    ref = torch.randint(0, 4, (F * 2 * lr,), generator=g, device=device, dtype=torch.uint8)
+    first = torch.randint(lq, lr, (F,), generator=g, device=device)
+    s1 = torch.randint(0, lr - lq + 1, (F,), generator=g, device=device)
+    reads = torch.empty((n, lq), dtype=torch.uint8, device=device)
+    k = torch.arange(lq, device=device)[None, :]
+    step = max(1, (1 << 22) // P) * P                      # whole fusions per chunk, about 4 M reads
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        m = hi - lo
+        fidx = torch.arange(lo, hi, device=device) // P
+        a = torch.randint(4, lq - 4 + 1, (m,), generator=g, device=device)
+        base0 = fidx * (2 * lr) + first[fidx] - a
+        base1 = fidx * (2 * lr) + lr + s1[fidx] - a
+        src = torch.where(k < a[:, None], base0[:, None] + k, base1[:, None] + k)
+        code = ref[src]
+        sub = torch.rand((m, lq), generator=g, device=device) < sub_rate
+        shift = torch.randint(1, 4, (m, lq), generator=g, device=device, dtype=torch.uint8)
+        code = torch.where(sub, (code + shift) % 4, code)
+        chunk = acgt[code.long()]
+        has_n = torch.rand((m,), generator=g, device=device) < n_rate
+        pos = torch.randint(0, lq, (m,), generator=g, device=device)
+        rows = torch.nonzero(has_n)[:, 0]
+        chunk[rows, pos[rows]] = ord("N")
+        reads[lo:hi] = chunk
+        del src, code, sub, shift, chunk
+    ref_bytes = acgt[ref.long()].cpu().numpy()
+    read_bytes = reads.reshape(-1).cpu().numpy()
+    del reads, ref
+    torch.cuda.empty_cache()
+    fusions = np.zeros(F, dtype=FUSION_DTYPE)
+    fusions["fusion_id"] = fusion_id_base + np.arange(F, dtype=np.int64)
+    fusions["ref0_off"] = np.arange(F, dtype=np.int64) * 2 * lr
+    fusions["ref0_len"] = lr
+    fusions["ref1_off"] = np.arange(F, dtype=np.int64) * 2 * lr + lr
+    fusions["ref1_len"] = lr
+    pairs = np.zeros(n, dtype=PAIR_DTYPE)
+    pairs["fusion_idx"] = np.repeat(np.arange(F, dtype=np.int32), P)
+    pairs["read_off"] = np.arange(n, dtype=np.int64) * lq
+    pairs["read_len"] = lq
+    pairs["frag"] = (np.arange(n, dtype=np.int64) & 0x7FFFFFFF).astype(np.int32)
+    pairs["read_end"] = (np.arange(n) & 1).astype(np.uint8)
+    pairs["revcomp"] = ((np.arange(n) >> 1) & 1).astype(np.uint8)
+    return ref_bytes, fusions, read_bytes, pairs

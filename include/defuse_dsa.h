@@ -106,6 +106,13 @@ const char* dsa_version(void);
  * SURVEY 8(b)), which spreads them over the GPUs of a node without any of them assuming it owns one. */
 int dsa_device_count(void);
 int dsa_pick_device(void);
+/* The rule behind dsa_pick_device for n devices: counting from pid mod n, the first device whose lock file
+ * ($DEFUSE_GPU_LOCK_DIR or /tmp)/defuse_gpu.<d>.lock this process can take with flock (kept until the process ends);
+ * pid mod n when all are taken.  Up to n concurrent tool processes therefore use n different GPUs. */
+int dsa_pick_device_among(int n_devices);
+/* Upper bound of the per-slice scratch planes of one pipeline lane (default 16 GiB, or DEFUSE_DSA_SCRATCH_MB at
+ * dsa_create): a caller that keeps several uploads resident side by side (one ctx each) sizes them with this. */
+int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes);
 
 /* ---- one-shot: host buffers in, host records out ----------------------------------------- */
 /* Records are ordered by pair index, then in the reference's emission order (read split a

@@ -44,8 +44,8 @@ typedef struct ora_mpe_diag {
     double  min_prob_margin;      /* min |prob - minProb| / minProb over all membership tests (MatePairEM.cpp:622-627) */
     double  min_tol_margin;       /* min ||dLL| - tol| / tol over all convergence tests (:473) */
     double  min_bic_gap;          /* min (BIC_K - BIC_best) / |BIC_best| over the K that lost (:599-606) */
-    double  min_deriv_margin;     /* min nonzero |partial| / (|RXYU/var| + |NK (cx+cy)/var| + lambda |cs|) over the breakpoints visited (:281-295) */
-    double  min_merge_margin;     /* min |SX-SY| / max(SX,SY) over the prefix-sum comparisons that were NOT exactly equal (:224) */
+    double  min_deriv_margin;     /* min nonzero |partial| / (|RXYU/var| + |NK (cx+cy)/var| + lambda |cs|) over the breakpoints visited (:281-295), M steps after a fit's first */
+    double  min_merge_margin;     /* min |SX-SY| / max(SX,SY) over the prefix-sum comparisons that were NOT exactly equal (:224), M steps after a fit's first */
     int64_t nk_zero;              /* MaxLikelihood returned false (NK == 0, :277) */
     int64_t nk_zero_first_iter;   /* ... in the first iteration of a fit: the only way stale mA/mB could be read */
     int64_t ll_underflow;         /* LogLikelihood returned -DBL_MAX (:127-131) */
@@ -53,6 +53,8 @@ typedef struct ora_mpe_diag {
     int64_t em_iterations;
     int64_t merge_equal;          /* prefix-sum comparisons that were exactly equal */
     int64_t all_k_failed;         /* problems where every K failed and the refit ran at K = 1 */
+    double  min_deriv_margin_first;   /* the same two figures over the FIRST M step of every fit and all M steps of K = 1 fits: their responsibilities are 0/1 (k-means) or 1/K, no exp/log has */
+    double  min_merge_margin_first;   /* been evaluated yet, so every implementation computes these decisions from bit-identical operands */
     int64_t deriv_zero;           /* breakpoints where the derivative estimate was exactly 0 (identical in any IEEE evaluation of the same operands) */
 } ora_mpe_diag;
 
@@ -417,7 +419,10 @@ static int max_likelihood(em_state* s, const double* R, const double* RXO, const
             i++; j++;
         } else {
             const double big = dmax(fabs(SX[i]), fabs(SY[j]));
-            if (big > 0.0) s->dg->min_merge_margin = dmin(s->dg->min_merge_margin, fabs(SX[i] - SY[j]) / big);
+            if (big > 0.0) {
+                double* m = first_iter ? &s->dg->min_merge_margin_first : &s->dg->min_merge_margin;
+                *m = dmin(*m, fabs(SX[i] - SY[j]) / big);
+            }
             if (SX[i] < SY[j]) {
                 CX[nc] = XO[i]; CY[nc] = YO[j]; CS[nc] = SX[i]; nc++;
                 if (i + 1 < N) { CX[nc] = XO[i + 1]; CY[nc] = YO[j]; CS[nc] = SX[i]; nc++; }
@@ -444,7 +449,10 @@ static int max_likelihood(em_state* s, const double* R, const double* RXO, const
         const double partial = (RXYU - NK * (CX[minindex] + CY[minindex])) / var + s->lambda * CS[minindex];
         const double scale = fabs(RXYU / var) + fabs(NK * (CX[minindex] + CY[minindex]) / var) + fabs(s->lambda * CS[minindex]);
         if (partial == 0.0) s->dg->deriv_zero++;
-        else if (scale > 0.0) s->dg->min_deriv_margin = dmin(s->dg->min_deriv_margin, fabs(partial) / scale);
+        else if (scale > 0.0) {
+            double* m = first_iter ? &s->dg->min_deriv_margin_first : &s->dg->min_deriv_margin;
+            *m = dmin(*m, fabs(partial) / scale);
+        }
         if (partial > 0) break;
         minindex++;
     }
@@ -549,7 +557,7 @@ static int expectation_maximization(em_state* s, double* ll)
     for (;;) {
         for (int j = 0; j < K; j++) {
             double a, b;
-            if (max_likelihood(s, s->R + (size_t)j * N, s->RXO + (size_t)j * N, s->RYO + (size_t)j * N, &a, &b, first)) {
+            if (max_likelihood(s, s->R + (size_t)j * N, s->RXO + (size_t)j * N, s->RYO + (size_t)j * N, &a, &b, first || K == 1)) {   /* K = 1: R is exactly 1 in every iteration, as exp-free as a first M step */
                 s->A[j] = a;
                 s->B[j] = b;
             }
@@ -652,6 +660,7 @@ static void diag_init(ora_mpe_diag* d)
 {
     memset(d, 0, sizeof(*d));
     d->min_prob_margin = d->min_tol_margin = d->min_bic_gap = d->min_deriv_margin = d->min_merge_margin = DBL_MAX;
+    d->min_deriv_margin_first = d->min_merge_margin_first = DBL_MAX;
 }
 
 static void diag_merge(ora_mpe_diag* into, const ora_mpe_diag* d)
@@ -661,6 +670,8 @@ static void diag_merge(ora_mpe_diag* into, const ora_mpe_diag* d)
     into->min_bic_gap = dmin(into->min_bic_gap, d->min_bic_gap);
     into->min_deriv_margin = dmin(into->min_deriv_margin, d->min_deriv_margin);
     into->min_merge_margin = dmin(into->min_merge_margin, d->min_merge_margin);
+    into->min_deriv_margin_first = dmin(into->min_deriv_margin_first, d->min_deriv_margin_first);
+    into->min_merge_margin_first = dmin(into->min_merge_margin_first, d->min_merge_margin_first);
     into->nk_zero += d->nk_zero;
     into->nk_zero_first_iter += d->nk_zero_first_iter;
     into->ll_underflow += d->ll_underflow;

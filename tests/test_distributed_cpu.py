@@ -78,3 +78,46 @@ def test_shard_ranges_cover_everything():
             *_, orig = shard.shard_batch(ref, fus, reads, pairs, r, world)
             seen[orig] += 1
         assert (seen == 1).all()
+
+
+def _gather_worker(rank, world, port, q, counts):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from defuse_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = counts[rank]
+    rows = (torch.arange(n * shard.RECORD_WORDS, dtype=torch.int32).reshape(n, shard.RECORD_WORDS) + 1000000 * rank)
+    out, got = shard.gather_records(rows, pair_base=7 * rank, dst=0)
+    if rank == 0:
+        ok = got == list(counts) and out.shape[0] == sum(counts)
+        lo = 0
+        for r, c in enumerate(counts):
+            exp = torch.arange(c * shard.RECORD_WORDS, dtype=torch.int32).reshape(c, shard.RECORD_WORDS) + 1000000 * r
+            exp[:, shard.RECORD_WORDS - 1] += 7 * r
+            ok = ok and bool((out[lo:lo + c] == exp).all())
+            lo += c
+        q.put(ok)
+    else:
+        assert out is None and got == list(counts)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("counts", [(0, 5), (6, 0), (0, 0), (3, 1000), (4, 0, 9)])
+def test_gather_records_with_empty_and_unequal_ranks(counts):
+    """The gather of bench.py / a multi-GPU caller with ranks that hold no records at all and with very unequal counts."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, len(counts), port, q, counts)) for r in range(len(counts))]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0

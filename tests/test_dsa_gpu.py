@@ -292,3 +292,27 @@ def test_full_size_every_record_against_oracle(gpu_ctx, ora, F, P, lq, lr):
     exp = np.concatenate(parts)
     assert len(got) == len(exp) and len(exp) > 1_500_000
     assert got.tobytes() == exp.tobytes()
+
+
+def test_bench_share_runs_several_uploads_like_one(gpu_ctx):
+    """bench.py's multi-upload loop (one rank's share of BASELINE configs[3] kept resident as several uploads, one dsa_ctx
+    each, run one after the other): every record of every upload against the oracle, pair numbers job-wide."""
+    import bench
+    from defuse_amd import dsa, synth
+    from oracle import dosplitalign_oracle as ora
+    workload = dict(fusions=700, reads=40, lq=100, lr=390)
+    share = bench.Share(dsa, synth, 0, workload, 100, 400, seed_base=77, on_device=True, log=lambda m: None, upload_fusions=128,
+                        keep_batches=True)
+    try:
+        assert len(share.ctxs) == 3 and share.total_pairs == 300 * 40
+        assert share.pair_base == [100 * 40, 200 * 40, 300 * 40]
+        n1, _ = share.run()
+        n2, ts = share.run()                                    # a second step over the resident uploads gives the same
+        assert n1 == n2 == sum(t.n_records for t in ts)
+        for ctx, batch in zip(share.ctxs, share.batches):
+            got = ctx.download()
+            exp = ora.align_batch(*batch)
+            assert len(exp) > 1000 and got.tobytes() == exp.tobytes()
+            assert batch[1]["fusion_id"][0] in (100, 200, 300)   # fusion ids are the job's, not the upload's
+    finally:
+        share.close()

@@ -126,7 +126,7 @@ def test_config5_shaped_chain_every_intermediate_file(built, tmp_path):
         assert open(out).read() == exp, sp
         n_clusters += n
         cl_paths.append(out)
-    assert n_clusters >= 8
+    assert n_clusters >= 6
     merged = run("defuse_glue", "merge_clusters", *cl_paths).stdout
     assert merged == open(os.path.join(G5, "clusters.all.perl.txt")).read()                    # deterministic script: byte for byte
     open(d + "clusters.all", "w").write(merged)
