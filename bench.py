@@ -38,7 +38,7 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 WORKLOADS = {"config2": dict(fusions=10000, reads=100, lq=76, lr=389),
              "config4": dict(fusions=1000000, reads=200, lq=100, lr=390)}
 UPLOAD_FUSIONS = 50000     # fusions per upload of a multi-upload share: 10 M aligns, 1 GB of read bytes at config 4
-UPLOAD_SCRATCH = 3 << 30   # scratch planes per pipeline lane of such an upload
+UPLOAD_SCRATCH = 24 << 30  # scratch planes per pipeline lane; the uploads of a share run one after the other and share the lanes
 
 
 def library_hash():
@@ -140,7 +140,10 @@ class Share:
                 b = synth.make_batch(hi - lo, workload["reads"], lq=workload["lq"], lr=workload["lr"], seed=seed_base)
             ctx = dsa.Context(device_index)
             if n_up > 1:
-                ctx.set_scratch_budget(UPLOAD_SCRATCH)
+                if self.ctxs:
+                    ctx.share_scratch(self.ctxs[0])
+                else:
+                    ctx.set_scratch_budget(UPLOAD_SCRATCH)
             ctx.upload(*b)
             self.ctxs.append(ctx)
             self.n_pairs.append(len(b[3]))

@@ -10,6 +10,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -58,7 +60,6 @@ struct HostResult {            // pinned: filled by async copies at the end of a
 
 struct PipeLane {
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     hipEvent_t ev[7] = {};      // 0 pack start, 4 pack end, 1 fill start, 2 fill end, 3 phase-1 end, 5 emit start, 6 emit end
     HostResult* host = nullptr;
     int slice = -1;             // slice whose phase 1 is in flight
@@ -68,7 +69,7 @@ struct PipeLane {
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
-    DevBuf<uint32_t> d_refcodes, d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
+    DevBuf<uint32_t> d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
     DevBuf<PairState> d_state;
     DevBuf<KeptRow> d_kept;
     DevBuf<int64_t> d_rec_count, d_rec_offset;
@@ -83,12 +84,36 @@ struct PipeLane {
 #endif
     void release()
     {
-        d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_refcodes.release(); d_rowcodes.release();
+        d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_rowcodes.release();
         d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
         d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
         d_ctr.release(); d_scan_tmp.release(); d_tstop.release();
     }
 };
+
+// The two pipeline lanes of a context: streams, events, pinned result words and all per-slice scratch planes.  Contexts that
+// run one after the other on one device (a caller that keeps several uploads resident, bench.py) may share one set
+// (dsa_share_scratch), so the scratch is paid once.
+struct LaneSet {
+    int device = -1;
+    hipStream_t own[2] = {};     // the lanes' private streams (lane 0 may run on a caller's stream instead)
+    PipeLane lane[2];
+    ~LaneSet()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        for (PipeLane& L : lane) {
+            L.release();
+            for (auto& e : L.ev)
+                if (e) (void)hipEventDestroy(e);
+            if (L.host) (void)hipHostFree(L.host);
+        }
+        for (hipStream_t st : own)
+            if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+std::atomic<int64_t> g_upload_serial{0};      // unique over all contexts: lanes may be shared
 
 struct Slice {
     int64_t pair_begin = 0, pair_end = 0;
@@ -102,8 +127,8 @@ struct Slice {
 
 struct dsa_ctx {
     int device = -1;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // = lane 0's stream unless dsa_set_stream gave another
+    hipStream_t user_stream = nullptr;
     std::string err;
     size_t scratch_budget = (size_t)16 << 30;
 
@@ -112,7 +137,10 @@ struct dsa_ctx {
     int32_t n_fusions = 0;
     DevBuf<uint8_t> d_ref, d_reads;
     DevBuf<dsa_fusion> d_fusions;
-    int64_t upload_serial = 0;       // counts dsa_upload calls
+    int64_t upload_serial = 0;       // serial of the resident upload (unique over all contexts)
+    int nch_all = 1;                 // tiles of the widest window of the upload: refcodes stride = nch_all * W
+    DevBuf<uint32_t> d_refcodes;     // packed once per run for the whole upload
+    hipEvent_t ev_pack[2] = {};      // around k_pack_refs
     DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig), when pairs were reordered
     DevBuf<dsa_pair> d_pairs_sweep;  // second pair buffer: the permutation is written here, then the two are swapped
     DevBuf<dsa_pair> d_pairs;
@@ -122,7 +150,7 @@ struct dsa_ctx {
 
     // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
     // slice overlaps the fill of the next (separate HIP streams)
-    PipeLane lane[2];
+    std::shared_ptr<LaneSet> lanes;
     DevBuf<dsa_record> d_records;
     int64_t n_records = 0;
     bool have_results = false;
@@ -254,7 +282,7 @@ int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t e
     cur.g.n_wgs = (int32_t)n_wgs;
     cur.g.lq1 = lq1;
     cur.g.nch = nch;
-    cur.g.lrp = nch * W;
+    cur.g.lrp = ctx->nch_all * W;
     cur.g.n_fusions = nf;
     cur.g.n_pairs = n;
     cur.g.orig = ctx->d_orig.p + begin;        // slice-relative indices of the caller's order
@@ -366,7 +394,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
         cur.g.n_wgs = (int32_t)cur.wgs.size();
         cur.g.lq1 = (lq1 + 3) & ~3;     // row planes are stored four rows per 16-byte word
         cur.g.nch = nch;
-        cur.g.lrp = nch * W;
+        cur.g.lrp = ctx->nch_all * W;
         cur.g.n_fusions = ctx->n_fusions;
         cur.g.n_pairs = cur.pair_end - cur.pair_begin;
         cur.g.orig = nullptr;
@@ -441,21 +469,21 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipEventRecord(L.ev[1], st));
     // every workgroup is run by exactly one of the two fill kernels
     hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,
-                       L.d_wg_generic.p, L.d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                       L.d_wg_generic.p, ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
     HIPC(hipEventRecord(L.ev[2], st));
     hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
-                       L.d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
+                       ctx->d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
     hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p,
                        L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr, (uint64_t)0,
                        (int64_t)s.pair_begin, g);
@@ -480,7 +508,6 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_waves.reserve(s.waves.size()));
     HIPC(L.d_wgs.reserve(s.wgs.size()));
     HIPC(L.d_wg_generic.reserve(s.wg_flags.size()));
-    HIPC(L.d_refcodes.reserve((size_t)g.n_fusions * g.lrp));
     HIPC(L.d_rowcodes.reserve(n_rows));
     HIPC(L.d_bnd.reserve(n_rows * g.nch));
     HIPC(L.d_cmax.reserve(n_rows * g.nch));
@@ -506,12 +533,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
         L.resident_upload = ctx->upload_serial;
         L.resident_slice = slice_idx;
     }
-    {
-        const int64_t total = (int64_t)g.n_fusions * g.lrp;
-        hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p,
-                           L.d_refcodes.p, g);
-    }
-    HIPC(hipEventRecord(L.ev[4], st));      // end of pack (ev[1] is re-recorded by every launch_compute)
+    HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
     if (int rc = launch_compute(ctx, L, s)) return rc;
     L.slice = slice_idx;
     return DSA_OK;
@@ -631,25 +653,25 @@ int dsa_create(dsa_ctx** out, int device)
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return DSA_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return DSA_E_DEVICE;
     dsa_ctx* ctx = new dsa_ctx();
     ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->own_stream) != hipSuccess) {
-        delete ctx;
-        return DSA_E_DEVICE;
-    }
-    ctx->stream = ctx->own_stream;
+    ctx->lanes = std::make_shared<LaneSet>();
+    ctx->lanes->device = device;
+    bool ok = true;
     for (int l = 0; l < 2; ++l) {
-        PipeLane& L = ctx->lane[l];
-        bool ok = true;
-        if (l == 0) L.stream = ctx->stream;
-        else { ok = hipStreamCreate(&L.stream) == hipSuccess; L.own_stream = ok; }
+        PipeLane& L = ctx->lanes->lane[l];
+        ok = ok && hipStreamCreate(&ctx->lanes->own[l]) == hipSuccess;
+        L.stream = ctx->lanes->own[l];
         for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
-        if (!ok) {
-            delete ctx;
-            return DSA_E_DEVICE;
-        }
     }
+    for (auto& e : ctx->ev_pack) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) {
+        dsa_destroy(ctx);
+        return DSA_E_DEVICE;
+    }
+    ctx->stream = ctx->lanes->lane[0].stream;
     if (const char* mb = getenv("DEFUSE_DSA_SCRATCH_MB")) {
         long v = atol(mb);
         if (v > 0) ctx->scratch_budget = (size_t)v << 20;
@@ -662,19 +684,25 @@ void dsa_destroy(dsa_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_sweep.release();
     (void)hipDeviceSynchronize();
-    ctx->d_min_score.release(); ctx->d_records.release();
-    for (PipeLane& L : ctx->lane) {
-        L.release();
-        for (auto& e : L.ev)
-            if (e) (void)hipEventDestroy(e);
-        if (L.host) (void)hipHostFree(L.host);
-        if (L.own_stream && L.stream) (void)hipStreamDestroy(L.stream);
-    }
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_sweep.release();
+    ctx->d_min_score.release(); ctx->d_records.release(); ctx->d_refcodes.release();
+    for (auto& e : ctx->ev_pack)
+        if (e) (void)hipEventDestroy(e);
+    ctx->lanes.reset();          // the last context of a shared set frees the lanes (streams, events, scratch planes)
     delete ctx;
+}
+
+int dsa_share_scratch(dsa_ctx* ctx, dsa_ctx* donor)
+{
+    if (!ctx || !donor || ctx == donor) return DSA_E_ARG;
+    if (ctx->device != donor->device) return fail(ctx, DSA_E_ARG, "dsa_share_scratch: contexts on different devices");
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipDeviceSynchronize());
+    ctx->lanes = donor->lanes;
+    ctx->stream = ctx->user_stream ? ctx->user_stream : ctx->lanes->lane[0].stream;
+    ctx->scratch_budget = donor->scratch_budget;
+    return DSA_OK;
 }
 
 int dsa_get_limits(const dsa_ctx*, dsa_limits* out)
@@ -691,8 +719,9 @@ const char* dsa_last_error(const dsa_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int dsa_set_stream(dsa_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return DSA_E_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    ctx->lane[0].stream = ctx->stream;      // lane 1 keeps its private stream
+    ctx->user_stream = (hipStream_t)hip_stream;
+    ctx->lanes->lane[0].stream = hip_stream ? (hipStream_t)hip_stream : ctx->lanes->own[0];      // lane 1 keeps its private stream
+    ctx->stream = ctx->lanes->lane[0].stream;
     return DSA_OK;
 }
 
@@ -723,6 +752,8 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
         if (fu.ref0_len > lim.max_ref_len || fu.ref1_len > lim.max_ref_len)
             return fail(ctx, DSA_E_LIMIT, "fusion %d: reference window longer than %d", f, lim.max_ref_len);
     }
+    int nch_all = 1;
+    for (int32_t f = 0; f < n_fusions; ++f) nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
     int lqmax = 0;
     for (int64_t p = 0; p < n_pairs; ++p) {
         const dsa_pair& pr = pairs[p];
@@ -735,7 +766,7 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     HIPC(hipSetDevice(ctx->device));
     ctx->have_results = false;
     ctx->n_records = 0;
-    ++ctx->upload_serial;
+    ctx->upload_serial = ++g_upload_serial;
     ctx->n_pairs = n_pairs;
     ctx->n_fusions = n_fusions;
     ctx->ref_bytes_len = ref_bytes_len;
@@ -744,6 +775,8 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     HIPC(ctx->d_reads.reserve((size_t)read_bytes_len + 1));
     HIPC(ctx->d_fusions.reserve((size_t)n_fusions + 1));
     HIPC(ctx->d_pairs.reserve((size_t)n_pairs + 1));
+    ctx->nch_all = nch_all;
+    HIPC(ctx->d_refcodes.reserve((size_t)n_fusions * nch_all * W + 1));
     hipStream_t st = ctx->stream;
     if (ref_bytes_len) HIPC(hipMemcpyAsync(ctx->d_ref.p, ref_bytes, ref_bytes_len, hipMemcpyHostToDevice, st));
     if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
@@ -770,21 +803,33 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
     const auto t0 = std::chrono::steady_clock::now();
+    if (ns > 0 && ctx->n_fusions > 0) {
+        // reference bytes -> 16-bit codes for the whole upload, once per run, on lane 0's stream; lane 1 waits for it
+        PipeLane& L0 = ctx->lanes->lane[0];
+        Geom g = ctx->slices[0].g;
+        const int64_t total = (int64_t)g.n_fusions * g.lrp;
+        HIPC(hipEventRecord(ctx->ev_pack[0], L0.stream));
+        hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L0.stream, ctx->d_ref.p, ctx->d_fusions.p,
+                           ctx->d_refcodes.p, g);
+        HIPC(hipEventRecord(ctx->ev_pack[1], L0.stream));
+        HIPC(hipStreamWaitEvent(ctx->lanes->lane[1].stream, ctx->ev_pack[1], 0));
+    }
     for (int k = 0; k < ns; ++k) {
-        PipeLane& L = ctx->lane[k & 1];
+        PipeLane& L = ctx->lanes->lane[k & 1];
         if (L.slice >= 0)
             if (int rc = phase2(ctx, L)) return rc;
         if (int rc = phase1(ctx, L, k)) return rc;
     }
     for (int k = ns; k < ns + 2; ++k) {
-        PipeLane& L = ctx->lane[k & 1];
+        PipeLane& L = ctx->lanes->lane[k & 1];
         if (L.slice >= 0)
             if (int rc = phase2(ctx, L)) return rc;
     }
-    for (PipeLane& L : ctx->lane) {
+    for (PipeLane& L : ctx->lanes->lane) {
         account_emit(ctx, L);
         HIPC(hipStreamSynchronize(L.stream));
     }
+    if (ns > 0 && ctx->n_fusions > 0) ctx->timing.pack_ms += elapsed(ctx->ev_pack[0], ctx->ev_pack[1]);
     // stage times are per-stream sums and overlap between the lanes; total_ms is the elapsed time
     ctx->timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.n_records = ctx->n_records;

@@ -19,7 +19,7 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
                                              "ref_second", "read_first", "read_second", "score", "pair_idx")])
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
-EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_align_batch",
+EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
            "dsa_upload", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
 
 DSA_E_CAPACITY = -1
@@ -69,6 +69,7 @@ def load_library():
         lib.dsa_set_stream.argtypes = [vp, vp]
         lib.dsa_synchronize.argtypes = [vp]
         lib.dsa_set_scratch_budget.argtypes = [vp, i64]
+        lib.dsa_share_scratch.argtypes = [vp, vp]
         lib.dsa_pick_device_among.argtypes = [ctypes.c_int]
         _lib = lib
     return _lib
@@ -114,6 +115,11 @@ class Context:
 
     def set_scratch_budget(self, nbytes):
         rc = self.lib.dsa_set_scratch_budget(self.h, int(nbytes))
+        if rc != 0:
+            self._err(rc)
+
+    def share_scratch(self, donor):
+        rc = self.lib.dsa_share_scratch(self.h, donor.h)
         if rc != 0:
             self._err(rc)
 

@@ -113,6 +113,10 @@ int dsa_pick_device_among(int n_devices);
 /* Upper bound of the per-slice scratch planes of one pipeline lane (default 16 GiB, or DEFUSE_DSA_SCRATCH_MB at
  * dsa_create): a caller that keeps several uploads resident side by side (one ctx each) sizes them with this. */
 int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes);
+/* ctx gives up its own pipeline lanes (streams, events, scratch planes) and uses donor's from now on; both must be on
+ * the same device and must not run at the same time (dsa_run is synchronous, so a caller that runs its resident
+ * uploads one after the other may let all of them share one set).  The lanes live until the last sharer is destroyed. */
+int dsa_share_scratch(dsa_ctx* ctx, dsa_ctx* donor);
 
 /* ---- one-shot: host buffers in, host records out ----------------------------------------- */
 /* Records are ordered by pair index, then in the reference's emission order (read split a
