@@ -122,7 +122,7 @@ def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
 class Share:
     """One rank's part of the job: its fusion range, resident as one or several uploads."""
 
-    def __init__(self, dsa, synth, device_index, workload, f_lo, f_hi, seed_base, on_device, log, upload_fusions=UPLOAD_FUSIONS, keep_batches=False):
+    def __init__(self, dsa, synth, device_index, workload, f_lo, f_hi, seed_base, on_device, log, upload_fusions=UPLOAD_FUSIONS, keep_batches=False, gen_device=None):
         import numpy as np
         self.ctxs, self.n_pairs, self.pair_base = [], [], []
         self.first_batch = None
@@ -135,7 +135,7 @@ class Share:
             t0 = time.perf_counter()
             if on_device:
                 b = synth.make_batch_device(hi - lo, workload["reads"], workload["lq"], workload["lr"], seed_base + lo,
-                                            "cuda:%d" % device_index, fusion_id_base=lo)
+                                            gen_device or "cuda:%d" % device_index, fusion_id_base=lo)
             else:
                 b = synth.make_batch(hi - lo, workload["reads"], lq=workload["lq"], lr=workload["lr"], seed=seed_base)
             ctx = dsa.Context(device_index)

@@ -307,8 +307,10 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     const int lq1 = (lqmax + 1 + 3) & ~3;
     const size_t per_wg = slice_scratch_bytes(WG_WAVES, lq1, nch_all);
     int64_t chunk = (int64_t)std::min<size_t>((size_t)1 << 40, ctx->scratch_budget / std::max<size_t>(per_wg, 1)) * WG_LANES;
-    // (cutting a batch that fits into two slices, so that the finish kernels of the first overlap the fill of the
-    // second, measured between -0.4 % and -2 % per step: not done, one fill launch per batch is easier to reason about)
+    // A batch that fits one slice but is large is cut in two, so that the latency-bound finish kernels of the first half run
+    // beside the fill of the second on the other lane (+2 % aligns/s on BASELINE configs[1], 4.01 against 4.09 ms per
+    // step; four or eight slices lose: 4.66 and 5.61 ms, the concurrent fill launches slow each other down).
+    if (chunk >= n_pairs && n_pairs >= ((int64_t)1 << 19)) chunk = ((n_pairs + 1) / 2 + WG_LANES - 1) / WG_LANES * WG_LANES;
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
     if (chunk < 2 * WG_LANES) return 0;
     DevBuf<FusionStat> d_stat;

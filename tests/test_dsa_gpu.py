@@ -302,7 +302,7 @@ def test_bench_share_runs_several_uploads_like_one(gpu_ctx):
     from oracle import dosplitalign_oracle as ora
     workload = dict(fusions=700, reads=40, lq=100, lr=390)
     share = bench.Share(dsa, synth, 0, workload, 100, 400, seed_base=77, on_device=True, log=lambda m: None, upload_fusions=128,
-                        keep_batches=True)
+                        keep_batches=True, gen_device="cpu")   # torch's own HIP runtime cannot start after the library's has (one process)
     try:
         assert len(share.ctxs) == 3 and share.total_pairs == 300 * 40
         assert share.pair_base == [100 * 40, 200 * 40, 300 * 40]
