@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cctype>
 #include <cmath>
 #include <cstdint>
@@ -227,25 +228,24 @@ public:
     bool open_file(const std::string& name)
     {
         fd_ = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        return fd_ >= 0;
+        if (fd_ < 0) return false;
+        struct stat st;
+        seekable_ = fstat(fd_, &st) == 0 && S_ISREG(st.st_mode);      // /dev/stdout, FIFOs, process substitution: plain ordered writes
+        return true;
     }
     void write_round(const std::vector<std::string>& texts, unsigned threads)
     {
+        if (!seekable_) {
+            for (const std::string& t : texts) ok_ = ok_ && write_all(t.data(), t.size(), -1);
+            return;
+        }
         std::vector<off_t> at(texts.size() + 1, pos_);
         for (size_t k = 0; k < texts.size(); ++k) at[k + 1] = at[k] + (off_t)texts[k].size();
         std::vector<int> bad(texts.size(), 0);
         const unsigned n = std::min<unsigned>(std::max(1u, threads), (unsigned)std::max<size_t>(1, texts.size()));
         run_threads(n, [&](unsigned t) {
-            for (size_t k = t; k < texts.size(); k += n) {
-                const char* p = texts[k].data();
-                size_t left = texts[k].size();
-                off_t o = at[k];
-                while (left) {
-                    const ssize_t w = pwrite(fd_, p, left, o);
-                    if (w <= 0) { bad[k] = 1; break; }
-                    p += w; left -= (size_t)w; o += w;
-                }
-            }
+            for (size_t k = t; k < texts.size(); k += n)
+                if (!write_all(texts[k].data(), texts[k].size(), at[k])) bad[k] = 1;
         });
         for (int b : bad) ok_ = ok_ && !b;
         pos_ = at[texts.size()];
@@ -257,9 +257,56 @@ public:
         return ok_;
     }
 private:
+    // at >= 0: pwrite at that offset; at < 0: write at the file position.  Short writes continue, EINTR retries.
+    bool write_all(const char* p, size_t left, off_t at)
+    {
+        while (left) {
+            const ssize_t w = at >= 0 ? pwrite(fd_, p, left, at) : write(fd_, p, left);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) return false;
+            p += w; left -= (size_t)w;
+            if (at >= 0) at += w;
+        }
+        return true;
+    }
     int fd_ = -1;
     off_t pos_ = 0;
-    bool ok_ = true;
+    bool ok_ = true, seekable_ = true;
+};
+
+// A set of 64-bit keys for the hot de-duplication loops: open addressing, linear probing, grows at half full.
+// insert() returns true when the key was new.  ~0 is reserved as the empty marker.
+class FlatSet64 {
+public:
+    explicit FlatSet64(size_t cap_pow2 = 1024) : slots_(cap_pow2, EMPTY), mask_(cap_pow2 - 1) {}
+    bool insert(uint64_t key)
+    {
+        if ((n_ + 1) * 2 > slots_.size()) grow();
+        size_t i = hash(key) & mask_;
+        for (;; i = (i + 1) & mask_) {
+            if (slots_[i] == key) return false;
+            if (slots_[i] == EMPTY) { slots_[i] = key; ++n_; return true; }
+        }
+    }
+    static uint64_t hash(uint64_t x)
+    {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    }
+    size_t size() const { return n_; }
+private:
+    static constexpr uint64_t EMPTY = ~(uint64_t)0;
+    void grow()
+    {
+        std::vector<uint64_t> old(slots_.size() * 2, EMPTY);
+        old.swap(slots_);
+        mask_ = slots_.size() - 1;
+        n_ = 0;
+        for (uint64_t k : old)
+            if (k != EMPTY) insert(k);
+    }
+    std::vector<uint64_t> slots_;
+    size_t mask_, n_ = 0;
 };
 
 // decimal text of an integer appended to a buffer (what operator<< prints for an int)
@@ -408,6 +455,10 @@ class FastaIndex {
 public:
     void Open(const std::string& fasta)
     {
+        // samtools 0.1.8's faidx also reads RAZF-compressed FASTA (<fasta>.rz with its own index, faidx.c:260-303); deFuse's
+        // pipeline never produces one (scripts/defuse_create_ref.pl writes plain FASTA) and this reader does not support it
+        if (fasta.size() > 3 && fasta.compare(fasta.size() - 3, 3, ".rz") == 0)
+            die("Error: RAZF-compressed FASTA (" + fasta + ") is not supported, give the plain FASTA file");
         const std::string fai = fasta + ".fai";
         std::ifstream in(fai.c_str(), std::ios::binary);
         if (!in.good()) {
@@ -425,9 +476,13 @@ public:
             rest >> en.len >> en.offset >> en.line_blen >> en.line_len;
             index_[line.substr(0, e)] = en;
         }
-        file_.open(fasta.c_str(), std::ios::binary);
-        if (!file_.good()) die("[fai_load] fail to open FASTA file.");
+        fd_ = open(fasta.c_str(), O_RDONLY);
+        if (fd_ < 0) die("[fai_load] fail to open FASTA file.");
     }
+    ~FastaIndex() { if (fd_ >= 0) close(fd_); }
+    FastaIndex() = default;
+    FastaIndex(const FastaIndex&) = delete;
+    FastaIndex& operator=(const FastaIndex&) = delete;
 
     // FastaIndex::Get: start/length are in-out (tools/FastaIndex.h:24): clipped values flow back.
     void Get(const std::string& reference, int strand, int& start, int& length, std::string& sequence) const
@@ -445,12 +500,23 @@ public:
         if (beg > e) beg = e;
         sequence.clear();
         if (e > beg && en.line_blen > 0) {
-            file_.clear();
-            file_.seekg(en.offset + beg / en.line_blen * en.line_len + beg % en.line_blen, std::ios::beg);
+            // one pread of the span that holds the wanted bases (thread-safe: tasks are set up side by side), then the
+            // non-graph bytes (line ends) are dropped as fai_fetch does
+            const long long first = en.offset + beg / en.line_blen * en.line_len + beg % en.line_blen;
+            const long long extra = std::max(1, en.line_len - en.line_blen);
+            long long span = (e - beg) + ((e - beg) / en.line_blen + 2) * extra;
             sequence.reserve((size_t)(e - beg));
-            char c;
-            while ((long long)sequence.size() < e - beg && file_.get(c))
-                if (std::isgraph((unsigned char)c)) sequence.push_back(c);
+            std::vector<char> buf;
+            long long at = first;
+            while ((long long)sequence.size() < e - beg) {
+                buf.resize((size_t)span);
+                const ssize_t got = pread(fd_, buf.data(), buf.size(), (off_t)at);
+                if (got <= 0) break;                                  // end of file: a truncated FASTA gives a short sequence, as there
+                for (ssize_t k = 0; k < got && (long long)sequence.size() < e - beg; ++k)
+                    if (std::isgraph((unsigned char)buf[(size_t)k])) sequence.push_back(buf[(size_t)k]);
+                at += got;
+                span = std::max<long long>(4096, e - beg - (long long)sequence.size() + 64);
+            }
         }
         length = (int)sequence.size();
         if (strand == MinusStrand) ReverseComplement(sequence);
@@ -492,7 +558,7 @@ private:
         flush();
     }
     std::unordered_map<std::string, Entry> index_;
-    mutable std::ifstream file_;
+    int fd_ = -1;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -746,7 +812,18 @@ inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, c
     std::ifstream ef(exonsFile.c_str());
     if (!ef.good() || !exons.Read(ef)) die("Error: Unable to read exon regions file " + exonsFile);
     std::map<int, SplitAlignmentTask> tasks;   // canonical iteration order: ascending fusion id
-    for (const auto& kv : regions) tasks[kv.first].Initialize(kv.first, kv.second, reference, exons, fragMean, fragStdDev, minRead, maxRead);
+    std::vector<std::pair<SplitAlignmentTask*, const std::vector<Location>*>> work;
+    std::vector<int> ids;
+    for (const auto& kv : regions) {
+        work.emplace_back(&tasks[kv.first], &kv.second);
+        ids.push_back(kv.first);
+    }
+    // the fusions are independent and everything they read (index, exon tables, the FASTA through pread) is read-only
+    const unsigned n = work.size() < 64 ? 1u : host_threads();
+    run_threads(n, [&](unsigned t) {
+        for (size_t i = t; i < work.size(); i += n)
+            work[i].first->Initialize(ids[i], *work[i].second, reference, exons, fragMean, fragStdDev, minRead, maxRead);
+    });
     return tasks;
 }
 

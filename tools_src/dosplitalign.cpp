@@ -11,6 +11,7 @@
 // pipeline runs side by side spread over a node's GPUs; with HIP_VISIBLE_DEVICES the
 // ordinal is relative to the visible set).
 #include <chrono>
+#include <mutex>
 #include <numeric>
 
 #include "../include/defuse_dsa.h"
@@ -60,112 +61,142 @@ int main(int argc, char* argv[])
     }
 
     stage("reads");
-    // the GPU batch: one dsa_fusion per task that gets at least one candidate
-    std::vector<uint8_t> ref_bytes, read_bytes;
-    std::vector<dsa_fusion> fusions;
-    std::vector<dsa_pair> cand;                    // candidates in the reference's visiting order
-    std::unordered_map<int, int> fusion_index;     // fusion id -> index into fusions
-    std::unordered_set<uint64_t> candidate_unique;   // (fusion, read id, revComp) seen (:268, :292)
+    // One GPU batch: the candidates of a run of SAM records, in the reference's visiting order.
+    struct Batch {
+        std::vector<uint8_t> ref_bytes, read_bytes;
+        std::vector<dsa_fusion> fusions;
+        std::vector<dsa_pair> cand;
+        void clear() { ref_bytes.clear(); read_bytes.clear(); fusions.clear(); cand.clear(); }
+    };
 
-    std::ofstream out(cmd.str("align").c_str());
-    if (!out.good()) die("Error: Unable to open " + cmd.str("align"));
+    OrderedFileWriter out;
+    if (!out.open_file(cmd.str("align"))) die("Error: Unable to open " + cmd.str("align"));
 
-    // Candidates go to the GPU in batches (DEFUSE_DSA_BATCH_PAIRS, default 4 M) and their lines are
-    // written in the reference's visiting order, so a run of any size streams through.
+    // Candidates go to the GPU in batches (DEFUSE_DSA_BATCH_PAIRS, default 4 M) and their lines are written in the
+    // reference's visiting order, so a run of any size streams through.  A batch is aligned, formatted and written by a
+    // helper thread while the main thread enumerates the next one.
     dsa_ctx* ctx = nullptr;
     size_t batch_pairs = (size_t)4 << 20;
     if (const char* e = std::getenv("DEFUSE_DSA_BATCH_PAIRS")) batch_pairs = std::max<size_t>(1, (size_t)std::atoll(e));
-    auto flush = [&]() {
+    const unsigned nThreads = host_threads();
+    std::mutex time_mutex;
+    auto run_batch = [&](Batch& B) {
+        std::vector<dsa_pair>& cand = B.cand;
         if (cand.empty()) return;
-        // group by fusion for the kernels, fusions with many candidates first: the table-driven kernels take
-        // workgroups (256 consecutive pairs) of at most four fusions, so the small fusions are kept together
-        // at the end instead of dragging their big neighbours onto the generic path (stable: keeps the
-        // visiting order inside a fusion)
-        std::vector<int64_t> per_fusion(fusions.size(), 0);
+        const double t_g0 = now();
+        // Grouped by fusion for the kernels, fusions with many candidates first: the table-driven kernels take workgroups
+        // (256 consecutive pairs) of at most four fusions, so the small fusions are kept together at the end instead of
+        // dragging their big neighbours onto the generic path.  A counting sort: stable, so the visiting order inside a
+        // fusion is kept.
+        const size_t nf = B.fusions.size(), nc = cand.size();
+        std::vector<int64_t> per_fusion(nf, 0);
         for (const dsa_pair& c : cand) ++per_fusion[c.fusion_idx];
-        std::vector<int64_t> order(cand.size());
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
-            const int fa = cand[a].fusion_idx, fb = cand[b].fusion_idx;
-            if (per_fusion[fa] != per_fusion[fb]) return per_fusion[fa] > per_fusion[fb];
-            return fa < fb;
-        });
-        std::vector<dsa_pair> pairs(cand.size());
-        for (size_t k = 0; k < order.size(); ++k) pairs[k] = cand[order[k]];
-
+        std::vector<int32_t> forder(nf);
+        std::iota(forder.begin(), forder.end(), 0);
+        std::stable_sort(forder.begin(), forder.end(), [&](int32_t x, int32_t y) { return per_fusion[x] > per_fusion[y]; });
+        std::vector<int64_t> start(nf + 1, 0);
+        {
+            int64_t at = 0;
+            for (int32_t f : forder) { start[f] = at; at += per_fusion[f]; }
+        }
+        std::vector<int64_t> slot_of(nc);
+        std::vector<dsa_pair> pairs(nc);
+        {
+            std::vector<int64_t> cur(start.begin(), start.begin() + (std::ptrdiff_t)nf);
+            for (size_t c = 0; c < nc; ++c) {
+                const int64_t k = cur[cand[c].fusion_idx]++;
+                slot_of[c] = k;
+                pairs[(size_t)k] = cand[c];
+            }
+        }
         if (!ctx) {
             if (dsa_create(&ctx, dsa_pick_device()) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
         }
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
         int64_t n = 0;
-        const double t_g0 = now();
-        int rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
-                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
+        int rc = dsa_align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
+                                 B.read_bytes.data(), (int64_t)B.read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
                                  (int64_t)recs.size(), &n);
         if (rc == DSA_E_CAPACITY) {
             recs.resize((size_t)n);
-            rc = dsa_align_batch(ctx, ref_bytes.data(), (int64_t)ref_bytes.size(), fusions.data(), (int32_t)fusions.size(),
-                                 read_bytes.data(), (int64_t)read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
+            rc = dsa_align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
+                                 B.read_bytes.data(), (int64_t)B.read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
                                  recs.data(), (int64_t)recs.size(), &n);
         }
         if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
         const double t_g1 = now();
-        t_gpu += t_g1 - t_g0;
 
-        // back to the visiting order: records arrive grouped by batch pair index
-        std::vector<int64_t> first(pairs.size() + 1, 0);
-        for (int64_t k = 0; k < n; ++k) ++first[recs[k].pair_idx + 1];
-        for (size_t k = 0; k < pairs.size(); ++k) first[k + 1] += first[k];
-        std::vector<int64_t> slot_of(cand.size());
-        for (size_t k = 0; k < order.size(); ++k) slot_of[order[k]] = (int64_t)k;
-        std::string buf;
-        for (size_t c = 0; c < cand.size(); ++c) {
-            const int64_t k = slot_of[c];
-            for (int64_t r = first[k]; r < first[k + 1]; ++r) {
-                const dsa_record& a = recs[r];
-                // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
-                for (int v : {a.fusion_id, a.frag, a.read_end, a.revcomp, a.ref_first, a.ref_second, a.read_first, a.read_second, a.score}) {
-                    append_int(buf, v);
-                    buf += '\t';
+        // back to the visiting order: records arrive grouped by batch pair index; contiguous shares of the candidates are
+        // formatted side by side and written in order
+        std::vector<int64_t> first(nc + 1, 0);
+        for (int64_t k = 0; k < n; ++k) ++first[(size_t)recs[(size_t)k].pair_idx + 1];
+        for (size_t k = 0; k < nc; ++k) first[k + 1] += first[k];
+        const unsigned nt = nc < 4096 ? 1u : nThreads;
+        std::vector<std::string> texts(nt);
+        run_threads(nt, [&](unsigned t) {
+            std::string& buf = texts[t];
+            const size_t lo = nc * t / nt, hi = nc * (t + 1) / nt;
+            for (size_t c = lo; c < hi; ++c) {
+                const size_t k = (size_t)slot_of[c];
+                for (int64_t r = first[k]; r < first[k + 1]; ++r) {
+                    const dsa_record& a = recs[(size_t)r];
+                    // SplitAlignment::WriteAlignment (tools/SplitAlignment.cpp:305-317): nine fields, each followed by a tab
+                    for (int v : {a.fusion_id, a.frag, a.read_end, a.revcomp, a.ref_first, a.ref_second, a.read_first, a.read_second, a.score}) {
+                        append_int(buf, v);
+                        buf += '\t';
+                    }
+                    buf += '\n';
                 }
-                buf += '\n';
             }
-            if (buf.size() > (1u << 20)) { out << buf; buf.clear(); }
-        }
-        out << buf;
+        });
+        out.write_round(texts, nt);
+        std::lock_guard<std::mutex> lk(time_mutex);
+        t_gpu += t_g1 - t_g0;
         t_write += now() - t_g1;
-        ref_bytes.clear();
-        read_bytes.clear();
-        fusions.clear();
-        cand.clear();
-        fusion_index.clear();
+    };
+    Batch batch[2];
+    int cur = 0;
+    std::thread worker;
+    auto flush = [&]() {                       // hand the current batch to the helper, continue in the other one
+        if (worker.joinable()) worker.join();
+        if (batch[cur].cand.empty()) return;
+        Batch* b = &batch[cur];
+        worker = std::thread([&run_batch, b] { run_batch(*b); b->clear(); });
+        cur ^= 1;
     };
 
     // SplitReadRealigner::DoAlignment (tools/SplitAlignment.cpp:266-303).  The SAM text is mapped and taken in rounds of
-    // 256 MiB, each cut into one piece per host thread: the pieces parse their records and look up the mate regions they
-    // overlap side by side; the candidates are then taken up in file order by one thread (the seen-set, the batches and the
-    // output are sequential by nature).
+    // 256 MiB, each cut into one piece per host thread.  Per round: (1) the pieces parse their records and look up the mate
+    // regions they overlap, side by side; (2) the de-duplication on (fusion, read, revComp) (:268, :292: first come, first
+    // kept) runs with the keys shared out over the threads by hash — every thread walks all candidates of the round in
+    // file order and keeps the seen-set of its own keys; (3) one thread takes the kept candidates up in file order
+    // (fusion table, offsets, batch cuts: cheap); (4) the reads are copied and reverse-complemented side by side.
     MappedText sam;
     sam.load(cmd.str("improper"), "Error: Unable to open sam file ");
-    unsigned nThreads = host_threads();
-    if (sam.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nThreads = 1;
+    unsigned nPieces = nThreads;
+    if (sam.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nPieces = 1;
     struct Hit { int frag, readEnd; uint32_t first, count; };           // readEnd -1: inherited from before the piece
     struct SamPiece {
         std::vector<Hit> hits;
         std::vector<int> ids;
+        std::vector<uint8_t> keep;                                       // per id: first occurrence of its key
         size_t lines = 0, errorLine = 0;
-        int errorKind = 0, lastReadEnd = -2;                             // -2: no record of the piece set the read end
+        int errorKind = 0, lastReadEnd = -2, carryIn = 0;                // -2: no record of the piece set the read end
         std::string errorText;
     };
-    std::vector<SamPiece> pieces(nThreads);
-    std::string seq;
+    std::vector<SamPiece> pieces(nPieces);
+    std::vector<FlatSet64> seen(nPieces, FlatSet64(1 << 12));            // (fusion, read id, revComp) seen, by key hash
+    std::unordered_map<int, int> fusion_index[2];                        // fusion id -> index into the batch's fusions
     size_t lineBase = 0;
     int carryReadEnd = 0;                                                // the reference's RawAlignment starts with read end 0
+    auto key_of = [](int fusion_id, int rid, int revcomp) {
+        return ((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp;
+    };
     for (size_t lo = 0; lo < sam.size();) {
         size_t hi = std::min(sam.size(), lo + ((size_t)1 << 28));
         if (hi < sam.size()) hi = sam.line_end(hi - 1);
-        const std::vector<size_t> cut = sam.cut_lines(lo, hi, nThreads);
-        run_threads(nThreads, [&](unsigned t) {
+        const std::vector<size_t> cut = sam.cut_lines(lo, hi, nPieces);
+        run_threads(nPieces, [&](unsigned t) {
             SamPiece& pc = pieces[t];
             pc = SamPiece();
             std::vector<int> overlapping;
@@ -198,64 +229,112 @@ int main(int argc, char* argv[])
             if (readEnd >= 0) pc.lastReadEnd = readEnd;
         });
         stage("  sam records + overlaps of a round");
+        for (SamPiece& pc : pieces) {                                    // read end a piece's first records inherit
+            pc.carryIn = carryReadEnd;
+            if (pc.lastReadEnd != -2) carryReadEnd = pc.lastReadEnd;
+            pc.keep.assign(pc.ids.size(), 0);
+        }
+        run_threads(nPieces, [&](unsigned t) {                           // (2)
+            FlatSet64& mine = seen[t];
+            for (SamPiece& pc : pieces)
+                for (const Hit& h : pc.hits) {
+                    const int mateReadEnd = h.readEnd < 0 ? pc.carryIn : h.readEnd;
+                    const int rid = pack_id(h.frag, (mateReadEnd == 0) ? 1 : 0);
+                    for (uint32_t k = 0; k < h.count; ++k) {
+                        const int cid = pc.ids[h.first + k];
+                        const uint64_t key = key_of(cid & 0x7FFFFFFF, rid, cid < 0 ? 0 : 1);
+                        if (FlatSet64::hash(key ^ 0x9e3779b97f4a7c15ULL) % nPieces != t) continue;
+                        if (mine.insert(key)) pc.keep[h.first + k] = 1;
+                    }
+                }
+        });
+        stage("  de-duplication of a round");
+        // (3) + (4): the kept candidates of the round, batch by batch
+        struct Pending { const char* src; size_t len; size_t dst; bool revcomp; };
+        std::vector<Pending> copies;
+        auto fill_reads = [&](Batch& B) {
+            if (copies.empty()) return;
+            const unsigned nt = copies.size() < 4096 ? 1u : nThreads;
+            run_threads(nt, [&](unsigned t) {
+                std::string tmp;
+                for (size_t k = copies.size() * t / nt; k < copies.size() * (t + 1) / nt; ++k) {
+                    const Pending& c = copies[k];
+                    if (!c.revcomp) { std::memcpy(B.read_bytes.data() + c.dst, c.src, c.len); continue; }
+                    tmp.assign(c.src, c.len);
+                    ReverseComplement(tmp);                               // the one definition of the complement (tools/Common.cpp)
+                    std::memcpy(B.read_bytes.data() + c.dst, tmp.data(), c.len);
+                }
+            });
+            copies.clear();
+        };
         for (SamPiece& pc : pieces) {
             for (const Hit& h : pc.hits) {
-                const int mateReadEnd = h.readEnd < 0 ? carryReadEnd : h.readEnd;
+                Batch& B = batch[cur];
+                const int mateReadEnd = h.readEnd < 0 ? pc.carryIn : h.readEnd;
                 const int frag = h.frag;
+                const int read_end = (mateReadEnd == 0) ? 1 : 0;
                 for (uint32_t k = 0; k < h.count; ++k) {
+                    if (!pc.keep[h.first + k]) continue;
                     const int cid = pc.ids[h.first + k];
                     const int cluster_end = cid < 0 ? 1 : 0;
                     const int fusion_id = cid & 0x7FFFFFFF;
-                    const int read_end = (mateReadEnd == 0) ? 1 : 0;
                     const int revcomp = (cluster_end == 0) ? 1 : 0;
-                    const int rid = pack_id(frag, read_end);
-                    if (!candidate_unique.insert(((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp).second) continue;
                     const char* rs = nullptr;              // a missing read aligns as the empty string (operator[] in the reference, :286)
                     size_t rn = 0;
-                    if (reads.get(frag, read_end, rs, rn)) seq.assign(rs, rn); else seq.clear();
-                    if (revcomp) ReverseComplement(seq);
-                    auto fi = fusion_index.find(fusion_id);
-                    if (fi == fusion_index.end()) {
+                    if (!reads.get(frag, read_end, rs, rn)) rn = 0;
+                    auto fi = fusion_index[cur].find(fusion_id);
+                    if (fi == fusion_index[cur].end()) {
                         const SplitAlignmentTask& t = tasks[fusion_id];
                         dsa_fusion f;
                         f.fusion_id = fusion_id;
-                        f.ref0_off = (int32_t)ref_bytes.size();
+                        f.ref0_off = (int32_t)B.ref_bytes.size();
                         f.ref0_len = (int32_t)t.mSplitAlignSeq[0].size();
-                        ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
-                        f.ref1_off = (int32_t)ref_bytes.size();
+                        B.ref_bytes.insert(B.ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
+                        f.ref1_off = (int32_t)B.ref_bytes.size();
                         f.ref1_len = (int32_t)t.mSplitAlignSeq[1].size();
-                        ref_bytes.insert(ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
-                        fi = fusion_index.emplace(fusion_id, (int)fusions.size()).first;
-                        fusions.push_back(f);
+                        B.ref_bytes.insert(B.ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
+                        fi = fusion_index[cur].emplace(fusion_id, (int)B.fusions.size()).first;
+                        B.fusions.push_back(f);
                     }
                     dsa_pair p{};
                     p.fusion_idx = fi->second;
-                    p.read_off = (int32_t)read_bytes.size();
-                    p.read_len = (int32_t)seq.size();
+                    p.read_off = (int32_t)B.read_bytes.size();
+                    p.read_len = (int32_t)rn;
                     p.frag = frag;
                     p.read_end = (uint8_t)read_end;
                     p.revcomp = (uint8_t)revcomp;
-                    read_bytes.insert(read_bytes.end(), seq.begin(), seq.end());
-                    cand.push_back(p);
+                    copies.push_back(Pending{rs, rn, B.read_bytes.size(), revcomp != 0});
+                    B.read_bytes.resize(B.read_bytes.size() + rn);
+                    B.cand.push_back(p);
                 }
                 // between two SAM records: a batch never splits the candidates of one record
-                if (cand.size() >= batch_pairs || read_bytes.size() > ((size_t)1 << 30) || ref_bytes.size() > ((size_t)1 << 30)) flush();
+                if (B.cand.size() >= batch_pairs || B.read_bytes.size() > ((size_t)1 << 30) || B.ref_bytes.size() > ((size_t)1 << 30)) {
+                    fill_reads(B);
+                    fusion_index[cur].clear();
+                    flush();
+                }
             }
             if (pc.errorLine) {                                         // the records before the bad line were taken up, as a serial reader does
+                fill_reads(batch[cur]);
+                fusion_index[cur].clear();
                 flush();
+                if (worker.joinable()) worker.join();
+                out.close_file();
                 if (pc.errorKind == 6) die("Error: bad integer '" + pc.errorText + "' as fragment name");
                 DieSamLine(pc.errorKind, lineBase + pc.errorLine);
             }
             lineBase += pc.lines;
-            if (pc.lastReadEnd != -2) carryReadEnd = pc.lastReadEnd;
         }
+        fill_reads(batch[cur]);            // the round's SAM text stays mapped, but the copies list is per round
+        stage("  candidates of a round");
         lo = hi;
     }
+    fusion_index[cur].clear();
     flush();
+    if (worker.joinable()) worker.join();
     stage("candidates + alignment + output");
     if (timing) std::cerr << "[dosplitalign] of which GPU calls " << t_gpu << " s, formatting and writing " << t_write << " s" << std::endl;
     if (ctx) dsa_destroy(ctx);
-    out.close();
-    if (!out.good()) die("Error: failed writing " + cmd.str("align"));
+    if (!out.close_file()) die("Error: failed writing " + cmd.str("align"));
     return 0;
 }
