@@ -142,3 +142,57 @@ def test_evalsplitalign_matches_oracle(tools, tmp_path, seed):
     assert open(out + ".break").read() == exp[1]
     assert open(out + ".predalign").read() == exp[2]
     assert len(exp[1].splitlines()) >= 6
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "16"])
+def test_evalsplitalign_pieces_give_the_same_files(tools, tmp_path, threads):
+    """The alignment file is evaluated in one piece per host thread, cut at changes of the fusion id: any thread count
+    gives the oracle's three files (more threads than groups included)."""
+    from oracle import dosplitalign_oracle as ora
+    case = pipeline_case.build(str(tmp_path / "case"), seed=11, n_fusions=9, reads_per_fusion=25)
+    txt = ora.dosplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                           case["regions"], case["improper"], case["seq1"], case["seq2"])
+    lines = sorted(txt.splitlines(True), key=lambda l: int(l.split("\t")[0]))
+    align = tmp_path / "sorted.align"
+    align.write_text("".join(lines))
+    exp = ora.evalsplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                             case["regions"], str(align))
+    out = str(tmp_path / "pred")
+    r = subprocess.run([EVAL] + eval_args(case, str(align), out), capture_output=True, text=True, env=dict(os.environ, DEFUSE_THREADS=threads))
+    assert r.returncode == 0, r.stderr
+    assert (open(out + ".seq").read(), open(out + ".break").read(), open(out + ".predalign").read()) == exp
+    assert len(exp[1].splitlines()) >= 6
+
+
+def test_evalsplitalign_malformed_lines_end_the_run_like_the_reference(tools, tmp_path):
+    """ReadSortedAlignments (tools/SplitAlignment.cpp:319-369) reads one line ahead: a malformed line that still opens a new
+    group (seven fields, readable id) lets the running group out first; a malformed line inside a group, or one whose id
+    cannot be read, ends the run before the running group is evaluated."""
+    from oracle import dosplitalign_oracle as ora
+    case = pipeline_case.build(str(tmp_path / "case"), seed=12, n_fusions=6, reads_per_fusion=20)
+    txt = ora.dosplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                           case["regions"], case["improper"], case["seq1"], case["seq2"])
+    lines = sorted(txt.splitlines(True), key=lambda l: int(l.split("\t")[0]))
+    ids = [int(l.split("\t")[0]) for l in lines]
+    groups = sorted(set(ids))
+    assert len(groups) >= 3
+    second = ids.index(groups[1])                              # first line of the second group
+    third = ids.index(groups[2])
+
+    def run(mutated):
+        align = tmp_path / "bad.align"
+        align.write_text("".join(mutated))
+        out = str(tmp_path / "bad")
+        r = subprocess.run([EVAL] + eval_args(case, str(align), out), capture_output=True, text=True, env=dict(os.environ, DEFUSE_THREADS="4"))
+        return r, [int(l.split("\t")[0]) for l in open(out + ".seq")]
+
+    bad = lines[third].split("\t")
+    bad[5] = "x7"                                              # opens group three with a readable id: group two is written first
+    r, done = run(lines[:third] + ["\t".join(bad)] + lines[third + 1:])
+    assert r.returncode == 1 and "bad integer 'x7'" in r.stderr and done == groups[:2]
+    bad = lines[second + 1].split("\t")
+    bad[5] = "x7"                                              # inside group two: only group one is written
+    r, done = run(lines[:second + 1] + ["\t".join(bad)] + lines[second + 2:])
+    assert r.returncode == 1 and done == groups[:1]
+    r, done = run(lines[:third] + ["short\tline\n"] + lines[third:])     # fewer than seven fields at a group change
+    assert r.returncode == 1 and "Format error for candidate reads line" in r.stderr and done == groups[:1]

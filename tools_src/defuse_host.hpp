@@ -904,6 +904,11 @@ private:
     std::unordered_map<int, uint64_t> sparse_;
 };
 
+struct ReadStorePair {
+    ReadStore file[2];
+    bool get(int frag, int end, const char*& s, size_t& n) const { return file[1].get(frag, end, s, n) || file[0].get(frag, end, s, n); }
+};
+
 // FASTQ: tools/ReadStream.cpp:18-32 (extension check), :57-104 (record parsing), AddReads SplitAlignment.cpp:253-264
 inline bool AddReads(const std::string& filename, ReadStore& reads)
 {

@@ -43,21 +43,41 @@ int main(int argc, char* argv[])
         t_stage = t;
     };
 
+    // The HIP runtime and the context come up on a helper thread while the text inputs are read (a tenth of a second that
+    // would otherwise sit in front of the first batch).  A run without candidates never needs the result.
+    dsa_ctx* ctx = nullptr;
+    int ctx_rc = DSA_OK;
+    std::thread ctx_thread([&] { ctx_rc = dsa_create(&ctx, dsa_pick_device()); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } ctx_joiner{ctx_thread};
+
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
                                                          cmd.integer("minread"), cmd.integer("maxread"), regions);
 
     // SplitReadRealigner::AddTask (tools/SplitAlignment.cpp:236-251): 2000 bp bins over the mate regions
+    // The ids in the bins are task ORDINALS (position in ascending fusion id order) rather than fusion ids: they sort the
+    // same way, and per-batch tables indexed by them replace hash lookups in the take-up loop.
     BinnedLocations binned(2000);
-    for (const auto& kv : tasks)
+    std::vector<const SplitAlignmentTask*> task_of;
+    for (const auto& kv : tasks) {
+        if (kv.first < 0) die("Error: negative fusion id " + std::to_string(kv.first));
         for (int ce = 0; ce <= 1; ++ce)
-            for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id(kv.first, ce), loc);
+            for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id((int)task_of.size(), ce), loc);
+        task_of.push_back(&kv.second);
+    }
 
     stage("regions + windows");
-    ReadStore reads;
-    if (!AddReads(cmd.str("seq1"), reads) || !AddReads(cmd.str("seq2"), reads)) {
-        std::cout << "Error: unable to read sequences" << std::endl;
-        return 1;
+    // the two FASTQ files are read side by side into stores of their own; a lookup asks the second file's first, so a read
+    // id that both files hold resolves to the later one as `reads[id] = sequence` does (tools/SplitAlignment.cpp:253-264)
+    ReadStorePair reads;
+    {
+        bool ok[2] = {false, false};
+        const std::string names[2] = {cmd.str("seq1"), cmd.str("seq2")};
+        run_threads(2, [&](unsigned t) { ok[t] = AddReads(names[t], reads.file[t]); });
+        if (!ok[0] || !ok[1]) {
+            std::cout << "Error: unable to read sequences" << std::endl;
+            return 1;
+        }
     }
 
     stage("reads");
@@ -75,7 +95,6 @@ int main(int argc, char* argv[])
     // Candidates go to the GPU in batches (DEFUSE_DSA_BATCH_PAIRS, default 4 M) and their lines are written in the
     // reference's visiting order, so a run of any size streams through.  A batch is aligned, formatted and written by a
     // helper thread while the main thread enumerates the next one.
-    dsa_ctx* ctx = nullptr;
     size_t batch_pairs = (size_t)4 << 20;
     if (const char* e = std::getenv("DEFUSE_DSA_BATCH_PAIRS")) batch_pairs = std::max<size_t>(1, (size_t)std::atoll(e));
     const unsigned nThreads = host_threads();
@@ -109,9 +128,8 @@ int main(int argc, char* argv[])
                 pairs[(size_t)k] = cand[c];
             }
         }
-        if (!ctx) {
-            if (dsa_create(&ctx, dsa_pick_device()) != DSA_OK) die("Error: no usable MI355X/HIP device (dsa_create failed)");
-        }
+        if (ctx_thread.joinable()) ctx_thread.join();
+        if (ctx_rc != DSA_OK || !ctx) die("Error: no usable MI355X/HIP device (dsa_create failed)");
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
         int64_t n = 0;
         int rc = dsa_align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
@@ -186,9 +204,14 @@ int main(int argc, char* argv[])
     };
     std::vector<SamPiece> pieces(nPieces);
     std::vector<FlatSet64> seen(nPieces, FlatSet64(1 << 12));            // (fusion, read id, revComp) seen, by key hash
-    std::unordered_map<int, int> fusion_index[2];                        // fusion id -> index into the batch's fusions
+    std::vector<int> fusion_slot(task_of.size(), -1);                    // task ordinal -> index into the current batch's fusions
+    std::vector<int> slots_used;
     size_t lineBase = 0;
     int carryReadEnd = 0;                                                // the reference's RawAlignment starts with read end 0
+    auto new_batch = [&] {
+        for (int o : slots_used) fusion_slot[(size_t)o] = -1;
+        slots_used.clear();
+    };
     auto key_of = [](int fusion_id, int rid, int revcomp) {
         return ((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp;
     };
@@ -242,7 +265,7 @@ int main(int argc, char* argv[])
                     const int rid = pack_id(h.frag, (mateReadEnd == 0) ? 1 : 0);
                     for (uint32_t k = 0; k < h.count; ++k) {
                         const int cid = pc.ids[h.first + k];
-                        const uint64_t key = key_of(cid & 0x7FFFFFFF, rid, cid < 0 ? 0 : 1);
+                        const uint64_t key = key_of(task_of[(size_t)(cid & 0x7FFFFFFF)]->mFusionID, rid, cid < 0 ? 0 : 1);
                         if (FlatSet64::hash(key ^ 0x9e3779b97f4a7c15ULL) % nPieces != t) continue;
                         if (mine.insert(key)) pc.keep[h.first + k] = 1;
                     }
@@ -277,27 +300,27 @@ int main(int argc, char* argv[])
                     if (!pc.keep[h.first + k]) continue;
                     const int cid = pc.ids[h.first + k];
                     const int cluster_end = cid < 0 ? 1 : 0;
-                    const int fusion_id = cid & 0x7FFFFFFF;
+                    const int ordinal = cid & 0x7FFFFFFF;
                     const int revcomp = (cluster_end == 0) ? 1 : 0;
                     const char* rs = nullptr;              // a missing read aligns as the empty string (operator[] in the reference, :286)
                     size_t rn = 0;
                     if (!reads.get(frag, read_end, rs, rn)) rn = 0;
-                    auto fi = fusion_index[cur].find(fusion_id);
-                    if (fi == fusion_index[cur].end()) {
-                        const SplitAlignmentTask& t = tasks[fusion_id];
+                    if (fusion_slot[(size_t)ordinal] < 0) {
+                        const SplitAlignmentTask& t = *task_of[(size_t)ordinal];
                         dsa_fusion f;
-                        f.fusion_id = fusion_id;
+                        f.fusion_id = t.mFusionID;
                         f.ref0_off = (int32_t)B.ref_bytes.size();
                         f.ref0_len = (int32_t)t.mSplitAlignSeq[0].size();
                         B.ref_bytes.insert(B.ref_bytes.end(), t.mSplitAlignSeq[0].begin(), t.mSplitAlignSeq[0].end());
                         f.ref1_off = (int32_t)B.ref_bytes.size();
                         f.ref1_len = (int32_t)t.mSplitAlignSeq[1].size();
                         B.ref_bytes.insert(B.ref_bytes.end(), t.mSplitAlignSeq[1].begin(), t.mSplitAlignSeq[1].end());
-                        fi = fusion_index[cur].emplace(fusion_id, (int)B.fusions.size()).first;
+                        fusion_slot[(size_t)ordinal] = (int)B.fusions.size();
+                        slots_used.push_back(ordinal);
                         B.fusions.push_back(f);
                     }
                     dsa_pair p{};
-                    p.fusion_idx = fi->second;
+                    p.fusion_idx = fusion_slot[(size_t)ordinal];
                     p.read_off = (int32_t)B.read_bytes.size();
                     p.read_len = (int32_t)rn;
                     p.frag = frag;
@@ -310,13 +333,13 @@ int main(int argc, char* argv[])
                 // between two SAM records: a batch never splits the candidates of one record
                 if (B.cand.size() >= batch_pairs || B.read_bytes.size() > ((size_t)1 << 30) || B.ref_bytes.size() > ((size_t)1 << 30)) {
                     fill_reads(B);
-                    fusion_index[cur].clear();
+                    new_batch();
                     flush();
                 }
             }
             if (pc.errorLine) {                                         // the records before the bad line were taken up, as a serial reader does
                 fill_reads(batch[cur]);
-                fusion_index[cur].clear();
+                new_batch();
                 flush();
                 if (worker.joinable()) worker.join();
                 out.close_file();
@@ -329,11 +352,12 @@ int main(int argc, char* argv[])
         stage("  candidates of a round");
         lo = hi;
     }
-    fusion_index[cur].clear();
+    new_batch();
     flush();
     if (worker.joinable()) worker.join();
     stage("candidates + alignment + output");
     if (timing) std::cerr << "[dosplitalign] of which GPU calls " << t_gpu << " s, formatting and writing " << t_write << " s" << std::endl;
+    if (ctx_thread.joinable()) ctx_thread.join();
     if (ctx) dsa_destroy(ctx);
     if (!out.close_file()) die("Error: failed writing " + cmd.str("align"));
     return 0;

@@ -16,10 +16,13 @@ struct SplitAlignment {
     int fusionID = 0, fragmentIndex = 0, readEnd = 0, revComp = 0;
     std::pair<int, int> refSplit, readSplit;
     int score = 0;
-    void Write(std::ostream& out) const   // tools/SplitAlignment.cpp:305-317
+    void Write(std::string& out) const    // tools/SplitAlignment.cpp:305-317
     {
-        out << fusionID << "\t" << fragmentIndex << "\t" << readEnd << "\t" << revComp << "\t" << refSplit.first << "\t"
-            << refSplit.second << "\t" << readSplit.first << "\t" << readSplit.second << "\t" << score << "\t" << std::endl;
+        for (int v : {fusionID, fragmentIndex, readEnd, revComp, refSplit.first, refSplit.second, readSplit.first, readSplit.second, score}) {
+            append_int(out, v);
+            out += '\t';
+        }
+        out += '\n';
     }
 };
 
@@ -29,50 +32,48 @@ struct SplitAlignment {
     std::exit(1);
 }
 
-// SplitAlignment::ReadSortedAlignments (tools/SplitAlignment.cpp:319-369) with one line of look-ahead
-// instead of tellg/seekg.
-class SortedAlignmentReader {
-public:
-    explicit SortedAlignmentReader(std::istream& in) : in_(in) {}
-    bool NextGroup(std::vector<SplitAlignment>& group)
-    {
-        group.clear();
-        SplitAlignment a;
-        while (have_ || ReadOne()) {
-            have_ = true;
-            if (!group.empty() && pending_.fusionID != group.front().fusionID) return true;
-            group.push_back(pending_);
-            have_ = false;
-        }
-        return !group.empty();
+// One line of the sorted alignment file (SplitAlignment::ReadSortedAlignments, tools/SplitAlignment.cpp:319-369), parsed in
+// place.  Returns an error text (empty = fine); the messages are the reference's.
+std::string parse_line(const char* line, size_t len, SplitAlignment& a, bool& id_read)
+{
+    id_read = false;
+    const char* fs[16];
+    int nf = 0;
+    fs[nf++] = line;
+    const char* end = line + len;
+    for (const char* p = line; nf < 15;) {
+        const char* tab = (const char*)memchr(p, '\t', (size_t)(end - p));
+        if (!tab) break;
+        fs[nf++] = p = tab + 1;
     }
+    fs[nf] = end + 1;                                   // field k is [fs[k], fs[k+1] - 1)
+    const std::string text(line, len);
+    // what the reference's look-ahead checks before it decides that a line opens the next group: seven fields and the id
+    if (nf >= 7 && field_int(fs[0], (size_t)(fs[1] - 1 - fs[0]), a.fusionID)) id_read = true;
+    if (nf < 9) return "Error: Format error for candidate reads line:\n" + text;      // < 7 in the reference, which then indexes [8]
+    int v[9];
+    for (int k = 0; k < 9; ++k) {
+        const size_t n = (size_t)(fs[k + 1] - 1 - fs[k]);
+        if (k == 3) {
+            if (n != 1 || (fs[k][0] != '0' && fs[k][0] != '1'))
+                return "Error: bad boolean '" + std::string(fs[k], n) + "' in candidate reads line: " + text;   // lexical_cast<bool>
+            v[k] = fs[k][0] == '1';
+        } else if (!field_int(fs[k], n, v[k])) {
+            return "Error: bad integer '" + std::string(fs[k], n) + "' in candidate reads line: " + text;
+        }
+    }
+    a.fusionID = v[0]; a.fragmentIndex = v[1]; a.readEnd = v[2]; a.revComp = v[3];
+    a.refSplit = std::make_pair(v[4], v[5]);
+    a.readSplit = std::make_pair(v[6], v[7]);
+    a.score = v[8];
+    return std::string();
+}
 
-private:
-    bool ReadOne()
-    {
-        std::string line;
-        if (!std::getline(in_, line)) return false;
-        std::vector<std::string> f = split_tabs(line);
-        if (f.size() < 7) {
-            std::cerr << "Error: Format error for candidate reads line:" << std::endl << line << std::endl;
-            std::exit(1);
-        }
-        if (f.size() < 9) die("Error: Format error for candidate reads line:\n" + line);   // the reference indexes [8]
-        auto num = [&](int k) { return lexical_int_or_die(f[k], "in candidate reads line: " + line); };
-        pending_.fusionID = num(0);
-        pending_.fragmentIndex = num(1);
-        pending_.readEnd = num(2);
-        if (f[3] != "0" && f[3] != "1") die("Error: bad boolean '" + f[3] + "' in candidate reads line: " + line);   // lexical_cast<bool>
-        pending_.revComp = f[3] == "1";
-        pending_.refSplit = std::make_pair(num(4), num(5));
-        pending_.readSplit = std::make_pair(num(6), num(7));
-        pending_.score = num(8);
-        return true;
-    }
-    std::istream& in_;
-    SplitAlignment pending_;
-    bool have_ = false;
-};
+void append_double(std::string& buf, double x)          // operator<<(double) at the stream's default precision: %g
+{
+    char tmp[40];
+    buf.append(tmp, (size_t)snprintf(tmp, sizeof tmp, "%g", x));
+}
 
 }  // namespace
 
@@ -96,63 +97,153 @@ int main(int argc, char* argv[])
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
                                                          cmd.integer("minread"), cmd.integer("maxread"), regions);
 
-    std::ifstream alignFile(cmd.str("align").c_str());
-    std::ofstream seqFile(cmd.str("seq").c_str()), breakFile(cmd.str("break").c_str()), predFile(cmd.str("predalign").c_str());
-    if (!alignFile.good()) die("Error: Unable to open " + cmd.str("align"));
-    if (!seqFile.good()) die("Error: Unable to open " + cmd.str("seq"));
-    if (!breakFile.good()) die("Error: Unable to open " + cmd.str("break"));
-    if (!predFile.good()) die("Error: Unable to open " + cmd.str("predalign"));
+    // The alignment file is mapped and cut into one piece per host thread at group boundaries (a group = a run of lines
+    // with one fusion id, as ReadSortedAlignments forms them); the pieces are evaluated side by side and their three texts
+    // written in order.  A malformed line ends the run as in the reference: everything before it is written, then the
+    // message.
+    MappedText text;
+    text.load(cmd.str("align"), "Error: Unable to open ");
+    OrderedFileWriter seqFile, breakFile, predFile;
+    if (!seqFile.open_file(cmd.str("seq"))) die("Error: Unable to open " + cmd.str("seq"));
+    if (!breakFile.open_file(cmd.str("break"))) die("Error: Unable to open " + cmd.str("break"));
+    if (!predFile.open_file(cmd.str("predalign"))) die("Error: Unable to open " + cmd.str("predalign"));
+    const SplitAlignmentTask emptyTask;                  // operator[] of the reference: an unknown id evaluates against an empty task
 
-    SortedAlignmentReader reader(alignFile);
-    std::vector<SplitAlignment> alignments;
-    while (reader.NextGroup(alignments)) {
-        const int fusionID = alignments.front().fusionID;
-        const SplitAlignmentTask& task = tasks[fusionID];   // operator[]: an unknown id evaluates against an empty task
-
-        // Evaluate (tools/SplitAlignment.cpp:484-594)
-        std::map<std::pair<int, int>, int> splitScore;
-        for (const SplitAlignment& a : alignments) splitScore[a.refSplit] += a.score;
-        int maxScore = -1;
-        std::pair<int, int> best;
-        for (const auto& kv : splitScore)
-            if (kv.second > maxScore) { best = kv.first; maxScore = kv.second; }
-        std::string sequence = "N";
-        int breakPos[2] = {0, 0}, count = 0;
-        double posAvg = -1.0, minAvg = -1.0;
-        std::vector<const SplitAlignment*> kept;
-        if (maxScore == -1) {
-            std::cerr << "Error: Unable to find max score split" << std::endl;
-        } else {
-            for (const SplitAlignment& a : alignments)
-                if (a.refSplit == best) kept.push_back(&a);
-            if (!(best.first <= (int)task.mSplitAlignSeq[0].length())) debug_check_failed("bestSplit.first <= mSplitAlignSeq[0].length()");
-            if (!(best.second + 1 < (int)task.mSplitAlignSeq[1].length())) debug_check_failed("bestSplit.second + 1 < mSplitAlignSeq[1].length()");
-            sequence = task.mSplitRemainderSeq[0] + task.mSplitAlignSeq[0].substr(0, best.first) + "|" +
-                       task.mSplitAlignSeq[1].substr(best.second + 1) + task.mSplitRemainderSeq[1];
-            breakPos[0] = task.mSplitSeqStrand[0] == PlusStrand ? task.mSplitAlignSeqStart[0] + best.first - 1
-                                                                 : task.mSplitAlignSeqStart[0] + task.mSplitAlignSeqLength[0] - best.first;
-            breakPos[1] = task.mSplitSeqStrand[1] == PlusStrand ? task.mSplitAlignSeqStart[1] + best.second + 1
-                                                                 : task.mSplitAlignSeqStart[1] + task.mSplitAlignSeqLength[1] - best.second - 2;
-            double posSum = 0.0, minSum = 0.0;
-            for (const SplitAlignment* a : kept) {
-                const int left = a->readSplit.first, right = a->readSplit.second;
-                const double posRange = (double)(left + right - 2 * minAnchor);
-                const double posValue = std::max(0, left - minAnchor);
-                const double minRange = std::floor(0.5 * (double)(left + right - 2 * minAnchor));
-                const double minValue = std::max(0, std::min(left - minAnchor, right - minAnchor));
-                posSum += posValue / posRange;
-                minSum += minValue / minRange;
-            }
-            count = (int)kept.size();
-            posAvg = posSum / (double)kept.size();
-            minAvg = minSum / kept.size();
+    unsigned nPieces = host_threads();
+    if (text.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nPieces = 1;
+    auto first_field = [&](size_t pos, size_t& n) {       // the fusion id column of the line at pos, as text
+        const size_t e = text.line_end(pos);
+        const char* tab = (const char*)memchr(text.data() + pos, '\t', e - pos);
+        n = tab ? (size_t)(tab - (text.data() + pos)) : e - pos - ((e > pos && text[e - 1] == '\n') ? 1 : 0);
+        return text.data() + pos;
+    };
+    std::vector<size_t> cut = text.cut_lines(0, text.size(), nPieces);
+    for (unsigned t = 1; t < nPieces; ++t) {              // move every cut forward to the next change of the fusion id column
+        size_t pos = std::max(cut[t], cut[t - 1]);
+        while (pos > 0 && pos < text.size()) {
+            size_t prev = pos - 1;                        // start of the previous line
+            while (prev > 0 && text[prev - 1] != '\n') --prev;
+            size_t na, nb;
+            const char* a = first_field(prev, na);
+            const char* b = first_field(pos, nb);
+            int ia, ib;                                       // compared as the integers the reader casts them to ("013" continues group 13)
+            if (!field_int(a, na, ia) || !field_int(b, nb, ib) || ia != ib) break;
+            pos = text.line_end(pos);
         }
-        // WriteSequence / WriteBreak / WriteAlignments (:596-624)
-        seqFile << fusionID << "\t" << sequence << "\t" << "0" << "\t" << count << "\t" << posAvg << "\t" << minAvg << std::endl;
-        for (int ce = 0; ce <= 1; ++ce)
-            breakFile << fusionID << "\t" << ce << "\t" << task.mAlignRefName[ce] << "\t"
-                      << (task.mAlignStrand[ce] == PlusStrand ? "+" : "-") << "\t" << breakPos[ce] << std::endl;
-        for (const SplitAlignment* a : kept) a->Write(predFile);
+        cut[t] = pos;
     }
+    struct Piece {
+        std::string seq, brk, pred, error;
+        size_t last_seq = 0, last_brk = 0, last_pred = 0;   // where the texts of the piece's last group begin
+        bool cancels_previous = false;                      // its FIRST line is malformed in a way that ends the run inside the previous group's look-ahead
+        bool empty = true;
+    };
+    std::vector<Piece> pieces(nPieces);
+    run_threads(nPieces, [&](unsigned t) {
+        Piece& out = pieces[t];
+        std::vector<SplitAlignment> alignments;
+        std::vector<const SplitAlignment*> kept;
+        std::map<std::pair<int, int>, int> splitScore;
+        SplitAlignment pending;
+        auto evaluate = [&]() {
+            const int fusionID = alignments.front().fusionID;
+            out.last_seq = out.seq.size(); out.last_brk = out.brk.size(); out.last_pred = out.pred.size();
+            auto ti = tasks.find(fusionID);
+            const SplitAlignmentTask& task = ti == tasks.end() ? emptyTask : ti->second;
+
+            // Evaluate (tools/SplitAlignment.cpp:484-594)
+            splitScore.clear();
+            for (const SplitAlignment& a : alignments) splitScore[a.refSplit] += a.score;
+            int maxScore = -1;
+            std::pair<int, int> best;
+            for (const auto& kv : splitScore)
+                if (kv.second > maxScore) { best = kv.first; maxScore = kv.second; }
+            std::string sequence = "N";
+            int breakPos[2] = {0, 0}, count = 0;
+            double posAvg = -1.0, minAvg = -1.0;
+            kept.clear();
+            if (maxScore == -1) {
+                std::cerr << "Error: Unable to find max score split" << std::endl;
+            } else {
+                for (const SplitAlignment& a : alignments)
+                    if (a.refSplit == best) kept.push_back(&a);
+                if (!(best.first <= (int)task.mSplitAlignSeq[0].length())) debug_check_failed("bestSplit.first <= mSplitAlignSeq[0].length()");
+                if (!(best.second + 1 < (int)task.mSplitAlignSeq[1].length())) debug_check_failed("bestSplit.second + 1 < mSplitAlignSeq[1].length()");
+                sequence = task.mSplitRemainderSeq[0] + task.mSplitAlignSeq[0].substr(0, best.first) + "|" +
+                           task.mSplitAlignSeq[1].substr(best.second + 1) + task.mSplitRemainderSeq[1];
+                breakPos[0] = task.mSplitSeqStrand[0] == PlusStrand ? task.mSplitAlignSeqStart[0] + best.first - 1
+                                                                     : task.mSplitAlignSeqStart[0] + task.mSplitAlignSeqLength[0] - best.first;
+                breakPos[1] = task.mSplitSeqStrand[1] == PlusStrand ? task.mSplitAlignSeqStart[1] + best.second + 1
+                                                                     : task.mSplitAlignSeqStart[1] + task.mSplitAlignSeqLength[1] - best.second - 2;
+                double posSum = 0.0, minSum = 0.0;
+                for (const SplitAlignment* a : kept) {
+                    const int left = a->readSplit.first, right = a->readSplit.second;
+                    const double posRange = (double)(left + right - 2 * minAnchor);
+                    const double posValue = std::max(0, left - minAnchor);
+                    const double minRange = std::floor(0.5 * (double)(left + right - 2 * minAnchor));
+                    const double minValue = std::max(0, std::min(left - minAnchor, right - minAnchor));
+                    posSum += posValue / posRange;
+                    minSum += minValue / minRange;
+                }
+                count = (int)kept.size();
+                posAvg = posSum / (double)kept.size();
+                minAvg = minSum / kept.size();
+            }
+            // WriteSequence / WriteBreak / WriteAlignments (:596-624)
+            append_int(out.seq, fusionID);
+            out.seq += '\t'; out.seq += sequence; out.seq += "\t0\t";
+            append_int(out.seq, count);
+            out.seq += '\t'; append_double(out.seq, posAvg);
+            out.seq += '\t'; append_double(out.seq, minAvg);
+            out.seq += '\n';
+            for (int ce = 0; ce <= 1; ++ce) {
+                append_int(out.brk, fusionID);
+                out.brk += '\t'; append_int(out.brk, ce);
+                out.brk += '\t'; out.brk += task.mAlignRefName[ce];
+                out.brk += (task.mAlignStrand[ce] == PlusStrand ? "\t+\t" : "\t-\t");
+                append_int(out.brk, breakPos[ce]);
+                out.brk += '\n';
+            }
+            for (const SplitAlignment* a : kept) a->Write(out.pred);
+            alignments.clear();
+        };
+        for (size_t pos = cut[t]; pos < cut[t + 1];) {
+            const size_t e = text.line_end(pos);
+            const size_t len = (e > pos && text[e - 1] == '\n') ? e - 1 - pos : e - pos;
+            bool id_read = false;
+            out.error = parse_line(text.data() + pos, len, pending, id_read);
+            pos = e;
+            const bool first_line = out.empty;
+            out.empty = false;
+            if (!out.error.empty()) {
+                if (first_line && !id_read) out.cancels_previous = true;
+                // the reference reads one line ahead: a malformed line that at least opens a new group (seven fields, a
+                // readable id different from the running group's) lets the running group through first; any other malformed
+                // line ends the run inside the reader, before the running group is evaluated
+                if (!(id_read && !alignments.empty() && pending.fusionID != alignments.front().fusionID)) alignments.clear();
+                break;
+            }
+            if (!alignments.empty() && pending.fusionID != alignments.front().fusionID) evaluate();
+            alignments.push_back(pending);
+        }
+        if (!alignments.empty()) evaluate();
+    });
+    for (unsigned t = 0; t < nPieces; ++t) {
+        for (unsigned u = t + 1; u < nPieces; ++u) {          // the next piece that holds lines
+            if (pieces[u].empty) continue;
+            if (pieces[u].cancels_previous) {                 // a sequential reader meets that line while it still collects this piece's last group
+                pieces[t].seq.resize(pieces[t].last_seq); pieces[t].brk.resize(pieces[t].last_brk); pieces[t].pred.resize(pieces[t].last_pred);
+            }
+            break;
+        }
+        seqFile.write_round({pieces[t].seq}, 1);
+        breakFile.write_round({pieces[t].brk}, 1);
+        predFile.write_round({pieces[t].pred}, 1);
+        if (!pieces[t].error.empty()) {
+            seqFile.close_file(); breakFile.close_file(); predFile.close_file();
+            die(pieces[t].error);
+        }
+    }
+    if (!seqFile.close_file() || !breakFile.close_file() || !predFile.close_file()) die("Error: failed writing the predictions");
     return 0;
 }
