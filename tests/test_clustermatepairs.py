@@ -271,3 +271,19 @@ def test_config3_one_million_fragments_em_against_the_c_oracle(built, tmp_path):
     # the knife edges: all decisions are far from a last-ulp flip on this workload
     assert dg.nk_zero_first_iter == 0 and dg.all_k_failed == 0
     assert dg.min_prob_margin > 1e-9 and dg.min_tol_margin > 1e-9 and dg.min_bic_gap > 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunks", ["1", "3", "50"])
+def test_tool_chunks_give_the_same_file(built, tmp_path, chunks):
+    """DEFUSE_CMP_CHUNKS: the bin pairs go through build -> GPU -> write in chunks whose stages overlap; cluster ids are a
+    running count over the chunks, so any number of chunks (more than bin pairs included) gives the oracle's file."""
+    from defuse_amd import build
+    from oracle import clustermatepairs_oracle as o
+    build.build_tools()
+    lines = cmp_cases.many_loci(10)
+    r, txt = run_tool(lines, tmp_path, env={"DEFUSE_CMP_CHUNKS": chunks, "DEFUSE_TIMING": "1"})
+    assert r.returncode == 0, r.stderr
+    exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
+    assert n >= 5 and txt == exp
+    assert "chunk(s), stages overlapped" in r.stderr

@@ -5,6 +5,8 @@
 // all bin pairs runs on the GPU in one batch through include/defuse_mpe.h (no CPU fallback).
 // Iteration orders the reference leaves to boost::unordered_map are the canonical ascending-key
 // orders of SURVEY.md 8(c).
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <numeric>
 
@@ -432,34 +434,57 @@ int main(int argc, char* argv[])
     std::vector<uint32_t> bpOrder(binPairKey.size());
     std::iota(bpOrder.begin(), bpOrder.end(), 0u);
     std::sort(bpOrder.begin(), bpOrder.end(), [&](uint32_t a, uint32_t b) { return binPairKey[a] < binPairKey[b]; });
-    // bin pairs are independent: every host thread takes a contiguous share of them (balanced by alignment count), the
-    // shares are joined in order
+    // Bin pairs are independent.  They are taken in canonical order in a few CHUNKS (contiguous ranges of about equal
+    // alignment count); a chunk goes through three stages — (1) its problems are built, every host thread on a contiguous
+    // share of the chunk's bin pairs; (2) the mate pair EM of the chunk runs on the GPU; (3) its cluster lines are formatted
+    // and written — and the stages of consecutive chunks overlap: while the GPU clusters chunk c, the host builds chunk
+    // c+1 and writes chunk c-1.  Cluster ids are a running count over the chunks in order, so the file does not depend on
+    // the cut.  DEFUSE_CMP_CHUNKS sets the number of chunks (default: 1 below 8 M alignments in bin pairs, else 4).
     struct PartOut {
         std::vector<Problem> problems;
         std::vector<int64_t> sizes;
         std::vector<double> X, Y, U;
         std::vector<int32_t> toXO, toYO;
     };
-    std::vector<PartOut> parts(nThreads);
-    std::vector<size_t> share(nThreads + 1, bpOrder.size());
-    {
+    struct Chunk {
+        std::vector<Problem> problems;
+        std::vector<int64_t> probOff;
+        std::vector<double> X, Y, U;
+        std::vector<int32_t> toXO, toYO, nClusters;
+        std::vector<uint16_t> member;
+    };
+    size_t totalAlignments = 0;
+    for (const PackedPair& pp : binPairStore) totalAlignments += pp.first.size() + pp.second.size();
+    const bool dumping = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS") || std::getenv("DEFUSE_CMP_DUMP_EM");
+    unsigned nChunks = totalAlignments >= ((size_t)8 << 20) ? 4u : 1u;
+    if (const char* e = std::getenv("DEFUSE_CMP_CHUNKS")) nChunks = (unsigned)std::max(1, std::atoi(e));
+    if (dumping || bpOrder.empty()) nChunks = 1;
+    nChunks = (unsigned)std::min<size_t>(nChunks, std::max<size_t>(1, bpOrder.size()));
+    auto cut_by_alignments = [&](size_t lo, size_t hi, unsigned parts_n) {     // [lo, hi) of bpOrder into parts of about equal alignment count
+        std::vector<size_t> cutAt(parts_n + 1, hi);
+        cutAt[0] = lo;
         size_t total = 0;
-        for (const PackedPair& pp : binPairStore) total += pp.first.size() + pp.second.size();
+        for (size_t oi = lo; oi < hi; ++oi) total += binPairStore[bpOrder[oi]].first.size() + binPairStore[bpOrder[oi]].second.size();
         size_t acc = 0;
         unsigned t = 1;
-        share[0] = 0;
-        for (size_t oi = 0; oi < bpOrder.size() && t < nThreads; ++oi) {
+        for (size_t oi = lo; oi < hi && t < parts_n; ++oi) {
             acc += binPairStore[bpOrder[oi]].first.size() + binPairStore[bpOrder[oi]].second.size();
-            if (acc >= total / nThreads * t) share[t++] = oi + 1;
+            while (t < parts_n && acc >= total / parts_n * t) cutAt[t++] = oi + 1;
         }
-    }
+        return cutAt;
+    };
+    const std::vector<size_t> chunkCut = cut_by_alignments(0, bpOrder.size(), nChunks);
+
+    auto build_chunk = [&](size_t cLo, size_t cHi, Chunk& ck) {
+    std::vector<PartOut> parts(nThreads);
+    const std::vector<size_t> share = cut_by_alignments(cLo, cHi, nThreads);
     auto build_share = [&](unsigned t) {
         PartOut& o = parts[t];
         const size_t lo = share[t], hi = share[t + 1];
         FragmentGroups fr1, fr2, fr2all;
         for (size_t oi = lo; oi < hi; ++oi) {
         const uint32_t bpi = bpOrder[oi];
-        const PackedPair& pp = binPairStore[bpi];
+        PackedPair& pp = binPairStore[bpi];
         if ((int)pp.first.size() < minClusterSize || (int)pp.second.size() < minClusterSize) continue;
         Problem prob;
         auto unpack = [&](unsigned id, const std::vector<AlignmentPacked>& packed, std::vector<CompactAlignment>& al) {
@@ -508,44 +533,134 @@ int main(int argc, char* argv[])
         for (size_t r = 0; r < n; ++r) o.toYO[base + ord[r]] = (int32_t)r;
         o.sizes.push_back((int64_t)n);
         o.problems.push_back(std::move(prob));
+        PackedPair().swap(pp);                              // the packed lists of this bin pair are not needed again
     }
     };
     run_threads(build_share);
-    std::vector<Problem> problems;
-    std::vector<int64_t> probOff(1, 0);
-    std::vector<double> X, Y, U;
-    std::vector<int32_t> toXO, toYO;
+    ck.probOff.assign(1, 0);
     for (PartOut& o : parts) {
         for (size_t k = 0; k < o.problems.size(); ++k) {
-            problems.push_back(std::move(o.problems[k]));
-            probOff.push_back(probOff.back() + o.sizes[k]);
+            ck.problems.push_back(std::move(o.problems[k]));
+            ck.probOff.push_back(ck.probOff.back() + o.sizes[k]);
         }
-        X.insert(X.end(), o.X.begin(), o.X.end());
-        Y.insert(Y.end(), o.Y.begin(), o.Y.end());
-        U.insert(U.end(), o.U.begin(), o.U.end());
-        toXO.insert(toXO.end(), o.toXO.begin(), o.toXO.end());
-        toYO.insert(toYO.end(), o.toYO.begin(), o.toYO.end());
+        ck.X.insert(ck.X.end(), o.X.begin(), o.X.end());
+        ck.Y.insert(ck.Y.end(), o.Y.begin(), o.Y.end());
+        ck.U.insert(ck.U.end(), o.U.begin(), o.U.end());
+        ck.toXO.insert(ck.toXO.end(), o.toXO.begin(), o.toXO.end());
+        ck.toYO.insert(ck.toYO.end(), o.toYO.begin(), o.toYO.end());
         o = PartOut();
     }
-    binPairStore.clear();
-    binPairStore.shrink_to_fit();
+    };
 
-    stage("problems");
-    if (const char* dump = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS")) {      // regression aid: the host stages' result, no GPU needed
-        std::ofstream d(dump, std::ios::binary);
-        auto put = [&](const void* p, size_t n) { d.write((const char*)p, (std::streamsize)n); };
-        put(probOff.data(), probOff.size() * sizeof(int64_t));
-        put(X.data(), X.size() * sizeof(double)); put(Y.data(), Y.size() * sizeof(double)); put(U.data(), U.size() * sizeof(double));
-        put(toXO.data(), toXO.size() * sizeof(int32_t)); put(toYO.data(), toYO.size() * sizeof(int32_t));
-        for (const Problem& pr : problems) {
-            put(pr.alignments1.data(), pr.alignments1.size() * sizeof(CompactAlignment));
-            put(pr.alignments2.data(), pr.alignments2.size() * sizeof(CompactAlignment));
-            put(pr.alignPairs.data(), pr.alignPairs.size() * sizeof(std::pair<int, int>));
+    // DEFUSE_GPUS = "all", a count, or a list of device ordinals: the bin pairs are shared out over those GPUs
+    // (bin pairs are independent); otherwise one GPU as for every tool (DEFUSE_GPU / lock files)
+    std::vector<int> devices;
+    mpe_timing tsum{};
+    auto cluster_chunk = [&](Chunk& ck) {
+        ck.nClusters.assign(ck.problems.size(), 0);
+        ck.member.assign(ck.X.size(), 0);
+        if (ck.problems.empty()) return;
+        if (devices.empty()) {
+            if (const char* g = std::getenv("DEFUSE_GPUS")) {
+                const std::string spec = g;
+                const int have = dsa_device_count();
+                if (spec == "all") for (int d = 0; d < have; ++d) devices.push_back(d);
+                else if (spec.find(',') != std::string::npos) for (const std::string& f : split_tabs(spec, ',')) devices.push_back(std::atoi(f.c_str()));
+                else for (int d = 0; d < std::atoi(spec.c_str()); ++d) devices.push_back(have > 0 ? d % have : d);
+            }
+            if (devices.empty()) devices.push_back(dsa_pick_device());
         }
-        for (const std::string& r : refNames) d << r << "\n";
-        return 0;
-    }
-    if (const char* dump = std::getenv("DEFUSE_CMP_DUMP_EM")) {            // test aid: exactly the arrays mpe_cluster_batch receives, then stop
+        std::vector<int32_t> status(ck.problems.size(), 0);
+        mpe_timing t;
+        const int rc = mpe_cluster_batch_sharded(devices.data(), (int32_t)devices.size(), &prm, ck.probOff.data(), (int32_t)ck.problems.size(),
+                                                 ck.X.data(), ck.Y.data(), ck.U.data(), ck.toXO.data(), ck.toYO.data(), ck.nClusters.data(),
+                                                 ck.member.data(), status.data(), &t);
+        if (rc != 0) die(std::string("Error: mate pair clustering on the GPU failed: ") + mpe_last_error());
+        tsum.kernel_ms += t.kernel_ms; tsum.n_problems += t.n_problems; tsum.n_mate_pairs += t.n_mate_pairs;
+        tsum.em_iterations += t.em_iterations; tsum.n_wave_problems += t.n_wave_problems;
+        for (size_t p = 0; p < ck.problems.size(); ++p)
+            if (status[p]) die("Error: a consistency check of the mate pair clusterer failed (DebugCheck in the reference)");
+    };
+
+    // output (:549-583): per emitted cluster one alignment pair per distinct fragment, in mate pair order; every host thread
+    // formats a contiguous share of the problems (cluster ids from a prefix sum of the emitted clusters), the texts are
+    // written in order
+    int clusterID = 0;
+    auto write_chunk = [&](Chunk& ck) {
+        const std::vector<Problem>& problems = ck.problems;
+        const std::vector<int64_t>& probOff = ck.probOff;
+        std::vector<int> firstCluster(problems.size() + 1, clusterID);
+        for (size_t p = 0; p < problems.size(); ++p) firstCluster[p + 1] = firstCluster[p] + ck.nClusters[p];
+        clusterID = firstCluster[problems.size()];
+        std::vector<size_t> outShare(nThreads + 1, 0);
+        std::vector<std::string> texts(nThreads);
+        auto format_share = [&](unsigned t) {
+            std::string& buf = texts[t];
+            std::vector<int> usedFragments;
+            auto put_int = [&](long long v) { append_int(buf, v); };
+            for (size_t p = outShare[t]; p < outShare[t + 1]; ++p) {
+                const Problem& prob = problems[p];
+                const int64_t base = probOff[p];
+                for (int j = 0; j < ck.nClusters[p]; ++j) {
+                    const int id = firstCluster[p] + j;
+                    usedFragments.clear();
+                    for (size_t k = 0; k < prob.alignPairs.size(); ++k) {
+                        if (!((ck.member[base + k] >> j) & 1)) continue;
+                        const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
+                        const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
+                        // mate pairs are listed fragment by fragment, so a fragment seen before is the last one used
+                        if (!usedFragments.empty() && usedFragments.back() == a1.fragmentIndex) continue;
+                        usedFragments.push_back(a1.fragmentIndex);
+                        for (int ce = 0; ce <= 1; ++ce) {
+                            const CompactAlignment& a = ce ? a2 : a1;
+                            put_int(id); buf += '\t'; put_int(ce); buf += '\t'; put_int(a.fragmentIndex); buf += '\t'; put_int(a.readEnd);
+                            buf += '\t'; buf += refNames[a.referenceIndex]; buf += '\t'; buf += (a.strand == PlusStrand ? '+' : '-'); buf += '\t';
+                            put_int(a.region.start); buf += '\t'; put_int(a.region.end); buf += '\n';
+                        }
+                    }
+                }
+            }
+        };
+        for (size_t lo = 0; lo < problems.size();) {              // rounds of about four million mate pairs bound the text held in memory
+            size_t hi = lo;
+            while (hi < problems.size() && probOff[hi] - probOff[lo] < (1 << 22)) ++hi;
+            outShare[0] = lo;
+            for (unsigned t = 1; t <= nThreads; ++t) {
+                const int64_t want = probOff[lo] + (probOff[hi] - probOff[lo]) / nThreads * t;
+                size_t at = t == nThreads ? hi : (size_t)(std::lower_bound(probOff.begin() + lo, probOff.begin() + hi, want) - probOff.begin());
+                outShare[t] = std::min(std::max(at, outShare[t - 1]), hi);
+            }
+            run_threads(format_share);
+            out.write_round(texts, nThreads);
+            for (std::string& tbuf : texts) tbuf.clear();
+            lo = hi;
+        }
+    };
+
+    std::vector<Chunk> chunks(nChunks);
+    if (dumping) {
+        Chunk& ck = chunks[0];
+        build_chunk(0, bpOrder.size(), ck);
+        stage("problems");
+        const std::vector<Problem>& problems = ck.problems;
+        const std::vector<int64_t>& probOff = ck.probOff;
+        const std::vector<double>&X = ck.X, &Y = ck.Y, &U = ck.U;
+        const std::vector<int32_t>&toXO = ck.toXO, &toYO = ck.toYO;
+        if (const char* dump = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS")) {      // regression aid: the host stages' result, no GPU needed
+            std::ofstream d(dump, std::ios::binary);
+            auto put = [&](const void* p, size_t n) { d.write((const char*)p, (std::streamsize)n); };
+            put(probOff.data(), probOff.size() * sizeof(int64_t));
+            put(X.data(), X.size() * sizeof(double)); put(Y.data(), Y.size() * sizeof(double)); put(U.data(), U.size() * sizeof(double));
+            put(toXO.data(), toXO.size() * sizeof(int32_t)); put(toYO.data(), toYO.size() * sizeof(int32_t));
+            for (const Problem& pr : problems) {
+                put(pr.alignments1.data(), pr.alignments1.size() * sizeof(CompactAlignment));
+                put(pr.alignments2.data(), pr.alignments2.size() * sizeof(CompactAlignment));
+                put(pr.alignPairs.data(), pr.alignPairs.size() * sizeof(std::pair<int, int>));
+            }
+            for (const std::string& r : refNames) d << r << "\n";
+            return 0;
+        }
+        const char* dump = std::getenv("DEFUSE_CMP_DUMP_EM");                  // test aid: exactly the arrays mpe_cluster_batch receives, then stop
         std::ofstream d(dump, std::ios::binary);
         const int64_t head[2] = {(int64_t)problems.size(), (int64_t)X.size()};
         auto put = [&](const void* p, size_t n) { d.write((const char*)p, (std::streamsize)n); };
@@ -556,84 +671,56 @@ int main(int argc, char* argv[])
         put(toXO.data(), toXO.size() * sizeof(int32_t)); put(toYO.data(), toYO.size() * sizeof(int32_t));
         return d.good() ? 0 : 1;
     }
-    std::vector<int32_t> nClusters(problems.size(), 0), status(problems.size(), 0);
-    std::vector<uint16_t> member(X.size(), 0);
-    if (!problems.empty()) {
-        mpe_timing t;
-        // DEFUSE_GPUS = "all", a count, or a list of device ordinals: the bin pairs are shared out over those GPUs
-        // (bin pairs are independent); otherwise one GPU as for every tool (DEFUSE_GPU / pid mod count)
-        std::vector<int> devices;
-        if (const char* g = std::getenv("DEFUSE_GPUS")) {
-            const std::string spec = g;
-            const int have = dsa_device_count();
-            if (spec == "all") for (int d = 0; d < have; ++d) devices.push_back(d);
-            else if (spec.find(',') != std::string::npos) for (const std::string& f : split_tabs(spec, ',')) devices.push_back(std::atoi(f.c_str()));
-            else for (int d = 0; d < std::atoi(spec.c_str()); ++d) devices.push_back(have > 0 ? d % have : d);
-        }
-        if (devices.empty()) devices.push_back(dsa_pick_device());
-        const int rc = mpe_cluster_batch_sharded(devices.data(), (int32_t)devices.size(), &prm, probOff.data(), (int32_t)problems.size(),
-                                                 X.data(), Y.data(), U.data(), toXO.data(), toYO.data(), nClusters.data(), member.data(),
-                                                 status.data(), &t);
-        if (rc != 0) die(std::string("Error: mate pair clustering on the GPU failed: ") + mpe_last_error());
-        if (std::getenv("DEFUSE_TIMING"))
-            std::cerr << "[clustermatepairs] " << t.n_problems << " bin pairs, " << t.n_mate_pairs << " mate pairs, " << t.em_iterations
-                      << " EM iterations, " << t.n_wave_problems << " bin pairs with a wave each, " << devices.size() << " device share(s), kernel " << t.kernel_ms << " ms" << std::endl;
-        for (size_t p = 0; p < problems.size(); ++p)
-            if (status[p]) die("Error: a consistency check of the mate pair clusterer failed (DebugCheck in the reference)");
-    }
-
-    stage("clustering");
-    // output (:549-583): per emitted cluster one alignment pair per distinct fragment, in mate pair order
-    // every host thread formats a contiguous share of the problems (cluster ids from a prefix sum of the emitted
-    // clusters), the texts are written in order
-    std::vector<int> firstCluster(problems.size() + 1, 0);
-    for (size_t p = 0; p < problems.size(); ++p) firstCluster[p + 1] = firstCluster[p] + nClusters[p];
-    const int clusterID = firstCluster[problems.size()];
-    std::vector<size_t> outShare(nThreads + 1, 0);
-    std::vector<std::string> texts(nThreads);
-    auto format_share = [&](unsigned t) {
-        std::string& buf = texts[t];
-        std::vector<int> usedFragments;
-        auto put_int = [&](long long v) { append_int(buf, v); };
-        for (size_t p = outShare[t]; p < outShare[t + 1]; ++p) {
-            const Problem& prob = problems[p];
-            const int64_t base = probOff[p];
-            for (int j = 0; j < nClusters[p]; ++j) {
-                const int id = firstCluster[p] + j;
-                usedFragments.clear();
-                for (size_t k = 0; k < prob.alignPairs.size(); ++k) {
-                    if (!((member[base + k] >> j) & 1)) continue;
-                    const CompactAlignment& a1 = prob.alignments1[prob.alignPairs[k].first];
-                    const CompactAlignment& a2 = prob.alignments2[prob.alignPairs[k].second];
-                    // mate pairs are listed fragment by fragment, so a fragment seen before is the last one used
-                    if (!usedFragments.empty() && usedFragments.back() == a1.fragmentIndex) continue;
-                    usedFragments.push_back(a1.fragmentIndex);
-                    for (int ce = 0; ce <= 1; ++ce) {
-                        const CompactAlignment& a = ce ? a2 : a1;
-                        put_int(id); buf += '\t'; put_int(ce); buf += '\t'; put_int(a.fragmentIndex); buf += '\t'; put_int(a.readEnd);
-                        buf += '\t'; buf += refNames[a.referenceIndex]; buf += '\t'; buf += (a.strand == PlusStrand ? '+' : '-'); buf += '\t';
-                        put_int(a.region.start); buf += '\t'; put_int(a.region.end); buf += '\n';
-                    }
-                }
+    {
+        // stage hand-offs: built[c] / clustered[c] are set under one mutex; the GPU thread and the writer wait for them in order
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<char> built(nChunks, 0), clustered(nChunks, 0);
+        double t_build = 0, t_cluster = 0, t_write = 0;
+        auto wait_for = [&](std::vector<char>& flag, unsigned c) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return flag[c] != 0; });
+        };
+        auto signal = [&](std::vector<char>& flag, unsigned c) {
+            { std::lock_guard<std::mutex> lk(mu); flag[c] = 1; }
+            cv.notify_all();
+        };
+        std::thread gpu([&] {
+            for (unsigned c = 0; c < nChunks; ++c) {
+                wait_for(built, c);
+                const double t0 = now();
+                cluster_chunk(chunks[c]);
+                t_cluster += now() - t0;
+                signal(clustered, c);
             }
+        });
+        std::thread writer([&] {
+            for (unsigned c = 0; c < nChunks; ++c) {
+                wait_for(clustered, c);
+                const double t0 = now();
+                write_chunk(chunks[c]);
+                chunks[c] = Chunk();
+                t_write += now() - t0;
+            }
+        });
+        for (unsigned c = 0; c < nChunks; ++c) {
+            const double t0 = now();
+            build_chunk(chunkCut[c], chunkCut[c + 1], chunks[c]);
+            t_build += now() - t0;
+            signal(built, c);
         }
-    };
-    for (size_t lo = 0; lo < problems.size();) {              // rounds of about a million mate pairs bound the text held in memory
-        size_t hi = lo;
-        while (hi < problems.size() && probOff[hi] - probOff[lo] < (1 << 20)) ++hi;
-        outShare[0] = lo;
-        for (unsigned t = 1; t <= nThreads; ++t) {
-            const int64_t want = probOff[lo] + (probOff[hi] - probOff[lo]) / nThreads * t;
-            size_t at = t == nThreads ? hi : (size_t)(std::lower_bound(probOff.begin() + lo, probOff.begin() + hi, want) - probOff.begin());
-            outShare[t] = std::min(std::max(at, outShare[t - 1]), hi);
+        gpu.join();
+        writer.join();
+        if (timing) {
+            std::cerr << "[clustermatepairs] " << tsum.n_problems << " bin pairs, " << tsum.n_mate_pairs << " mate pairs, " << tsum.em_iterations
+                      << " EM iterations, " << tsum.n_wave_problems << " bin pairs with a wave each, " << devices.size() << " device share(s), kernel "
+                      << tsum.kernel_ms << " ms" << std::endl;
+            std::cerr << "[clustermatepairs] " << nChunks << " chunk(s), stages overlapped: problems " << t_build << " s, clustering " << t_cluster
+                      << " s, output " << t_write << " s" << std::endl;
         }
-        run_threads(format_share);
-        out.write_round(texts, nThreads);
-        for (std::string& tbuf : texts) tbuf.clear();
-        lo = hi;
     }
     if (!out.close_file()) die("Error: failed writing the clusters file");
-    stage("output");
+    stage("problems + clustering + output");
     std::cout << "Created " << clusterID << " clusters" << std::endl;
     return 0;
 }
