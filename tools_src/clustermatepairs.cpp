@@ -207,7 +207,7 @@ int main(int argc, char* argv[])
         size_t errorLine = 0;                                // 1-based line inside the piece, 0 = none
         std::string error;
         std::vector<std::string> errorStdout;
-        std::unordered_map<uint64_t, uint32_t> binPairIndex;
+        FlatMap64 binPairIndex{1 << 16};
         std::vector<uint64_t> binPairKey;
         std::vector<std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>>> binPairStore;
     };
@@ -301,13 +301,14 @@ int main(int argc, char* argv[])
         Piece& pc = pieces[t];
         auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
             const uint64_t key = ((uint64_t)lo << 32) | hi;
-            auto it = pc.binPairIndex.find(key);
-            if (it == pc.binPairIndex.end()) {
-                it = pc.binPairIndex.emplace(key, (uint32_t)pc.binPairStore.size()).first;
+            bool added;
+            uint32_t& slot = pc.binPairIndex.find_or_add(key, added);
+            if (added) {
+                slot = (uint32_t)pc.binPairStore.size();
                 pc.binPairKey.push_back(key);
                 pc.binPairStore.emplace_back();
             }
-            return pc.binPairStore[it->second];
+            return pc.binPairStore[slot];
         };
         std::vector<std::pair<int, int>> conc[2];
         std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
@@ -369,6 +370,7 @@ int main(int argc, char* argv[])
         }
         pc.recs.clear();
         pc.recs.shrink_to_fit();
+        pc.binPairIndex.release();
     };
     run_threads(bin_piece);
     stage("  binned");
@@ -379,41 +381,61 @@ int main(int argc, char* argv[])
         }
 
     // bin pairs by (first.id, second.id), the pieces joined in file order; visited in ascending key order afterwards (canonical)
-    std::vector<uint64_t> binPairKey;
-    std::vector<PackedPair> binPairStore;
-    if (nThreads == 1) {
-        binPairKey.swap(pieces[0].binPairKey);
-        binPairStore.swap(pieces[0].binPairStore);
-    } else {
-        // thread t joins the keys whose hash falls to it, walking the pieces in file order
-        struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
-        std::vector<Joined> joined(nThreads);
+    // Thread t joins the keys whose hash falls to it, walking the pieces in file order; the joined lists stay where they are
+    // (one table of pointers over all threads' shares instead of a copy), and every thread frees its own piece at the end.
+    struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
+    std::vector<Joined> joined(nThreads);
+    {
         auto join_keys = [&](unsigned t) {
             Joined& j = joined[t];
-            std::unordered_map<uint64_t, uint32_t> index;
+            if (nThreads == 1) {
+                j.key.swap(pieces[0].binPairKey);
+                j.store.swap(pieces[0].binPairStore);
+                return;
+            }
+            size_t mine = 0;
+            for (const Piece& pc : pieces)
+                for (uint64_t key : pc.binPairKey) mine += ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads == t) ? 1 : 0;
+            j.key.reserve(mine);                              // upper bound: no regrowth, the lists are never moved twice
+            j.store.reserve(mine);
+            FlatMap64 index(1 << 16);
             for (Piece& pc : pieces)
                 for (size_t k = 0; k < pc.binPairKey.size(); ++k) {
                     const uint64_t key = pc.binPairKey[k];
                     if ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads != t) continue;
-                    auto it = index.find(key);
-                    if (it == index.end()) {
-                        index.emplace(key, (uint32_t)j.store.size());
+                    bool added;
+                    uint32_t& slot = index.find_or_add(key, added);
+                    if (added) {
+                        slot = (uint32_t)j.store.size();
                         j.key.push_back(key);
                         j.store.push_back(std::move(pc.binPairStore[k]));
                     } else {
-                        PackedPair& d = j.store[it->second];
+                        PackedPair& d = j.store[slot];
                         d.first.insert(d.first.end(), pc.binPairStore[k].first.begin(), pc.binPairStore[k].first.end());
                         d.second.insert(d.second.end(), pc.binPairStore[k].second.begin(), pc.binPairStore[k].second.end());
                     }
                 }
         };
         run_threads(join_keys);
+        run_threads([&](unsigned t) { pieces[t] = Piece(); });          // millions of small lists: freed side by side
+    }
+    std::vector<uint64_t> binPairKey;
+    std::vector<PackedPair*> binPairStorePtr;
+    {
+        size_t total = 0;
+        for (const Joined& j : joined) total += j.key.size();
+        binPairKey.reserve(total);
+        binPairStorePtr.reserve(total);
         for (Joined& j : joined) {
             binPairKey.insert(binPairKey.end(), j.key.begin(), j.key.end());
-            for (PackedPair& pp : j.store) binPairStore.push_back(std::move(pp));
+            for (PackedPair& pp : j.store) binPairStorePtr.push_back(&pp);
         }
-        pieces.clear();
     }
+    struct StoreView {                                        // binPairStore[i] as before
+        std::vector<PackedPair*>* p;
+        PackedPair& operator[](size_t i) const { return *(*p)[i]; }
+        size_t size() const { return p->size(); }
+    } binPairStore{&binPairStorePtr};
 
     stage("read + bin pairs");
     std::cout << "Initializing clusterer" << std::endl;
@@ -454,7 +476,7 @@ int main(int argc, char* argv[])
         std::vector<uint16_t> member;
     };
     size_t totalAlignments = 0;
-    for (const PackedPair& pp : binPairStore) totalAlignments += pp.first.size() + pp.second.size();
+    for (const PackedPair* pp : binPairStorePtr) totalAlignments += pp->first.size() + pp->second.size();
     const bool dumping = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS") || std::getenv("DEFUSE_CMP_DUMP_EM");
     unsigned nChunks = totalAlignments >= ((size_t)8 << 20) ? 4u : 1u;
     if (const char* e = std::getenv("DEFUSE_CMP_CHUNKS")) nChunks = (unsigned)std::max(1, std::atoi(e));

@@ -154,6 +154,48 @@ inline void run_threads(unsigned n, const std::function<void(unsigned)>& fn)
     for (std::thread& x : th) x.join();
 }
 
+// 64-bit key -> 32-bit value, open addressing with linear probing (the bin pair tables of clustermatepairs: millions of
+// keys, looked up once per alignment); key ~0 is reserved.  find_or_add returns the slot's value reference and whether
+// the key was new.
+class FlatMap64 {
+public:
+    explicit FlatMap64(size_t cap_pow2 = 1024) : keys_(cap_pow2, EMPTY), vals_(cap_pow2, 0), mask_(cap_pow2 - 1) {}
+    uint32_t& find_or_add(uint64_t key, bool& added)
+    {
+        if ((n_ + 1) * 2 > keys_.size()) grow();
+        size_t i = hash(key) & mask_;
+        for (;; i = (i + 1) & mask_) {
+            if (keys_[i] == key) { added = false; return vals_[i]; }
+            if (keys_[i] == EMPTY) { keys_[i] = key; ++n_; added = true; return vals_[i]; }
+        }
+    }
+    size_t size() const { return n_; }
+    void release() { std::vector<uint64_t>().swap(keys_); std::vector<uint32_t>().swap(vals_); n_ = 0; mask_ = 0; }
+private:
+    static constexpr uint64_t EMPTY = ~(uint64_t)0;
+    static uint64_t hash(uint64_t x)
+    {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    }
+    void grow()
+    {
+        std::vector<uint64_t> ok(keys_.size() * 2, EMPTY);
+        std::vector<uint32_t> ov(keys_.size() * 2, 0);
+        ok.swap(keys_); ov.swap(vals_);
+        mask_ = keys_.size() - 1;
+        for (size_t k = 0; k < ok.size(); ++k) {
+            if (ok[k] == EMPTY) continue;
+            size_t i = hash(ok[k]) & mask_;
+            while (keys_[i] != EMPTY) i = (i + 1) & mask_;
+            keys_[i] = ok[k]; vals_[i] = ov[k];
+        }
+    }
+    std::vector<uint64_t> keys_;
+    std::vector<uint32_t> vals_;
+    size_t mask_, n_ = 0;
+};
+
 // A whole text input in memory: a regular file is mapped (threads that parse pieces of it fault its pages in side by side),
 // anything else ("-" = stdin, pipes) is collected in a plain buffer.
 struct MappedText {
