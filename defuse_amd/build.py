@@ -34,7 +34,7 @@ LIB_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 def lib_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h")]
+           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h", "defuse_cov.h")]
 
 
 def source_hash(extra_flags=()):
@@ -55,11 +55,11 @@ def build_lib(force=False):
     if force or _newer(LIB, srcs):
         _run([HIPCC] + LIB_FLAGS + ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(),
               "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip"),
-              os.path.join(CSRC, "la_api.hip"), os.path.join(CSRC, "hc_api.hip")])
+              os.path.join(CSRC, "la_api.hip"), os.path.join(CSRC, "hc_api.hip"), os.path.join(CSRC, "cov_api.hip")])
     return LIB
 
 
-TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign", "defuse_glue"]
+TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign", "defuse_glue", "calccov"]
 
 
 def build_tools(force=False):
@@ -73,7 +73,7 @@ def build_tools(force=False):
         out = os.path.join(bindir, t)
         deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
                 os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
-                os.path.join(ROOT, "include", "defuse_la.h"), lib]
+                os.path.join(ROOT, "include", "defuse_la.h"), os.path.join(ROOT, "include", "defuse_cov.h"), lib]
         if force or _newer(out, deps):
             _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, lib,
                   "-Wl,-rpath,$ORIGIN/../defuse_amd"])

@@ -403,6 +403,12 @@ public:
     {
         args_.push_back({flag, name, desc, type, default_value, false, false});
     }
+    // a switch without a value (tclap SwitchArg, long form only when flag is empty): is_set(name) tells whether it was given
+    void add_switch(const std::string& flag, const std::string& name, const std::string& desc)
+    {
+        args_.push_back({flag, name, desc, "switch", "", false, false});
+    }
+    bool is_set(const std::string& name) const { return get(name).set; }
     void parse(int argc, char** argv)
     {
         prog_ = argc > 0 ? argv[0] : "prog";
@@ -416,6 +422,7 @@ public:
             Arg* a = find(tok);
             if (!a) fail("Argument: " + tok, "Couldn't find match for argument");
             if (a->set) fail("Argument: " + id(*a), "Argument already set!");
+            if (a->type == "switch") { a->set = true; continue; }
             if (i + 1 >= argc) fail("Argument: " + id(*a), "Missing a value for this argument!");
             a->value = argv[++i];
             a->set = true;
@@ -444,11 +451,11 @@ private:
         is >> v;
         return !is.fail() && is.peek() == EOF;
     }
-    static std::string id(const Arg& a) { return "-" + a.flag + " (--" + a.name + ")"; }
+    static std::string id(const Arg& a) { return a.flag.empty() ? "(--" + a.name + ")" : "-" + a.flag + " (--" + a.name + ")"; }
     Arg* find(const std::string& tok)
     {
         for (Arg& a : args_)
-            if (tok == "-" + a.flag || tok == "--" + a.name) return &a;
+            if ((!a.flag.empty() && tok == "-" + a.flag) || tok == "--" + a.name) return &a;
         return nullptr;
     }
     const Arg& get(const std::string& name) const
@@ -460,7 +467,10 @@ private:
     void short_usage(std::ostream& os) const
     {
         os << "   " << prog_;
-        for (const Arg& a : args_) os << (a.required ? " -" : " [-") << a.flag << " <" << a.type << ">" << (a.required ? "" : "]");
+        for (const Arg& a : args_) {
+            if (a.type == "switch") { os << " [" << (a.flag.empty() ? "--" + a.name : "-" + a.flag) << "]"; continue; }
+            os << (a.required ? " -" : " [-") << a.flag << " <" << a.type << ">" << (a.required ? "" : "]");
+        }
         os << " [--] [--version] [-h]" << std::endl;
     }
     void usage(std::ostream& os) const
@@ -468,9 +478,14 @@ private:
         os << std::endl << "USAGE: " << std::endl << std::endl;
         short_usage(os);
         os << std::endl << std::endl << "Where: " << std::endl << std::endl;
-        for (const Arg& a : args_)
+        for (const Arg& a : args_) {
+            if (a.type == "switch") {
+                os << "   " << (a.flag.empty() ? "" : "-" + a.flag + ",  ") << "--" << a.name << std::endl << "     " << a.desc << std::endl << std::endl;
+                continue;
+            }
             os << "   -" << a.flag << " <" << a.type << ">,  --" << a.name << " <" << a.type << ">" << std::endl
                << "     " << (a.required ? "(required)  " : "") << a.desc << std::endl << std::endl;
+        }
         os << "   --,  --ignore_rest" << std::endl << "     Ignores the rest of the labeled arguments following this flag." << std::endl << std::endl
            << "   --version" << std::endl << "     Displays version information and exits." << std::endl << std::endl
            << "   -h,  --help" << std::endl << "     Displays usage information and exits." << std::endl << std::endl << std::endl
@@ -633,6 +648,7 @@ public:
             exons_[transcript] = exons;
             length_[transcript] = total;
             gene_[transcript] = gene;
+            gene_transcripts_[gene].push_back(transcript);
             exons_str_[PlusStrand][transcript] = exons;
             std::vector<Region> minus;   // TransformExons :114-124
             for (auto it = exons.rbegin(); it != exons.rend(); ++it) minus.push_back(Region{-it->end, -it->start});
@@ -644,6 +660,20 @@ public:
         return true;
     }
     bool IsTranscript(const std::string& t) const { return gene_.count(t) != 0; }
+    // GetGenes (:126-129): the reference lists its unordered_set of gene names; canonical order = ascending
+    std::vector<std::string> GetGenes() const
+    {
+        std::vector<std::string> g;
+        for (const auto& kv : gene_transcripts_) g.push_back(kv.first);
+        return g;
+    }
+    const std::vector<std::string>& GetGeneTranscripts(const std::string& gene) const { return gene_transcripts_.at(gene); }   // file order
+    int GetTranscriptLength(const std::string& t) const
+    {
+        auto it = length_.find(t);
+        if (it == length_.end()) die("Error: Data mismatch, unable to find length for transcript " + t);
+        return it->second;
+    }
     const std::string& GetTranscriptGene(const std::string& t) const
     {
         auto it = gene_.find(t);
@@ -717,6 +747,7 @@ private:
     static constexpr int kBin = 100000;   // :19
     std::unordered_map<std::string, std::string> chromosome_, gene_;
     std::unordered_map<std::string, int> strand_, length_;
+    std::map<std::string, std::vector<std::string>> gene_transcripts_;
     std::unordered_map<std::string, std::vector<Region>> exons_;
     mutable std::unordered_map<std::string, std::vector<Region>> exons_str_[2];
     std::unordered_map<std::string, Region> region_;
