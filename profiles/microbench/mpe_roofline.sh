@@ -1,0 +1,74 @@
+#!/bin/bash
+# Roofline figures of the EM kernel of clustermatepairs (k_mpe_problem_wave) on the config-3 probe (default 5 M fragments):
+# kernel time (rocprofv3 kernel trace), SQ counters (VALU issue, lanes busy, waits), HBM-side traffic (FETCH_SIZE / WRITE_SIZE,
+# separate passes) and L2 hits, each in its own rocprofv3 --pmc pass.  Writes gpurun_out/mpe_roofline/roofline.json
+# (copy to profiles/rNN/clustermatepairs/).    gpurun -- bash profiles/microbench/mpe_roofline.sh [fragments]
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+D=/tmp/cmp_scale
+O=$R/gpurun_out/mpe_roofline
+mkdir -p $O
+python3 $R/profiles/microbench/cmp_scale.py --fragments ${1:-5000000} --out $D --generate-only > $O/gen.json || exit 1
+cd /tmp
+T="$R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.pmc"
+export DEFUSE_CMP_CHUNKS=1 DEFUSE_TIMING=1
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- $T > $O/kt.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq -o p --output-format csv -- $T > $O/sq.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_INSTS_SMEM -d $O/sq2 -o p --output-format csv -- $T > $O/sq2.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $T > $O/fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $T > $O/write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/tcc -o p --output-format csv -- $T > $O/tcc.log 2>&1 || exit 1
+python3 - <<'PY'
+import collections, csv, glob, json, os, re, sys
+R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+O = R + "/gpurun_out/mpe_roofline"
+sys.path.insert(0, R)
+import bench
+K = "k_mpe_problem_wave"
+def counters(d):
+    acc = collections.defaultdict(float)
+    for f in glob.glob(O + "/%s/**/*counter_collection.csv" % d, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if K in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+    return dict(acc)
+ms = calls = 0.0
+for f in glob.glob(O + "/kt/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if K in r["Name"]:
+            ms += float(r["TotalDurationNs"]) / 1e6
+            calls += float(r["Calls"])
+log = open(O + "/kt.log").read()
+m = re.search(r"(\d+) bin pairs, (\d+) mate pairs, (\d+) EM iterations", log)
+bin_pairs, mate_pairs, em_iters = (int(v) for v in m.groups())
+sq, sq2, fe, wr, tcc = counters("sq"), counters("sq2"), counters("fetch"), counters("write"), counters("tcc")
+cycles = ms * 1e-3 * 2.4e9                       # nominal clock
+simds = 256 * 4
+issue = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (cycles * simds)          # SQ counts quad-cycles
+lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+fetch_b, write_b = fe.get("FETCH_SIZE", 0.0) * 1024, wr.get("WRITE_SIZE", 0.0) * 1024
+out = {
+    "kernel": K, "source_hash": bench.library_hash(), "workload": json.load(open(O + "/gen.json")),
+    "kernel_ms": ms, "launches": calls, "bin_pairs": bin_pairs, "mate_pairs": mate_pairs, "em_iterations": em_iters,
+    "bound": "latency of dependent FP64 chains and their loads (neither HBM nor MFMA): see waits",
+    "valu": {"issue_busy_frac_of_simd_cycles": issue, "lanes_busy_per_instruction": lanes,
+             "fp64_lane_throughput_frac": issue * lanes / 64.0,
+             "note": "nominal 2.4 GHz, one quad-cycle of issue per wave instruction; the serial sums the reference prescribes "
+                     "keep one lane per component (M step) or per fit (likelihood chain) busy"},
+    "waits": {"wait_any_over_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+              "wait_inst_any_over_wave_cycles": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"],
+              "salu_per_valu": sq["SQ_INSTS_SALU"] / sq["SQ_INSTS_VALU"]},
+    "memory": {"fetch_bytes_raw": fetch_b, "write_bytes": write_b,
+               "fabric_GBps_raw": (fetch_b + write_b) / (ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
+               "frac_of_hbm_peak_raw": (fetch_b + write_b) / (ms * 1e-3) / 1e9 / 8000.0,
+               "bytes_per_em_iteration_raw": (fetch_b + write_b) / max(1, em_iters),
+               "l2_hit_rate": tcc.get("TCC_HIT_sum", 0.0) / max(1.0, tcc.get("TCC_HIT_sum", 0.0) + tcc.get("TCC_MISS_sum", 0.0)),
+               "vmem_read_instructions": sq2.get("SQ_INSTS_VMEM_RD"), "vmem_write_instructions": sq2.get("SQ_INSTS_VMEM_WR"),
+               "note": "FETCH_SIZE as counted (8-byte scattered reads: the gfx950 x2 correction is calibrated for 16-B streaming reads only)"},
+    "raw": {"sq": sq, "sq2": sq2, "tcc": tcc},
+}
+json.dump(out, open(O + "/roofline.json", "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("kernel_ms", "valu", "waits")}, indent=1))
+print(json.dumps(out["memory"], indent=1))
+PY
+rm -rf $D $O/kt $O/sq $O/sq2 $O/fetch $O/write $O/tcc

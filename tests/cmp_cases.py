@@ -137,3 +137,43 @@ def config3_lines(n_fragments, seed=3):
             return f.readlines()
     finally:
         os.remove(path)
+
+
+def adversarial_em_batch(seed, n_problems=4000, mean=300.0):
+    """Problems for mpe_cluster_batch that leave the beaten path of MatePairEM (found by searching with the C oracle's
+    counters): far-apart tight groups and far outliers make components lose every responsibility (MaxLikelihood returns
+    false, NK == 0, tools/MatePairEM.cpp:277: A/B keep their values) and make LogLikelihood underflow to -DBL_MAX (:127-131:
+    that K is dropped); groups of identical points stop the KKZ seeding (:375-378); points on a line tie distances.
+    Returns (prob_off, x, y, u, to_xo, to_yo) as numpy arrays."""
+    from oracle import mpe_c
+    rng = np.random.default_rng(seed)
+    xs, ys, off = [], [], [0]
+    for p in range(n_problems):
+        n = int(rng.integers(5, 40))
+        kind = p % 4
+        if kind == 0:
+            k = int(rng.integers(2, 6))
+            cx, cy = rng.integers(-100000, 100000, size=k), rng.integers(-100000, 100000, size=k)
+            a = rng.integers(0, k, size=n)
+            x, y = cx[a] + rng.integers(0, 30, size=n), cy[a] + rng.integers(0, 30, size=n)
+        elif kind == 1:
+            x, y = rng.integers(0, 200, size=n), rng.integers(0, 200, size=n)
+            m = int(rng.integers(1, 4))
+            x[:m] += rng.integers(2000, 30000, size=m)
+            y[:m] -= rng.integers(2000, 30000, size=m)
+        elif kind == 2:
+            k = int(rng.integers(2, 5))
+            px, py = rng.integers(0, 5000, size=k), rng.integers(0, 5000, size=k)
+            a = rng.integers(0, k, size=n)
+            x, y = px[a], py[a]
+        else:
+            x = np.sort(rng.integers(0, 20000, size=n))
+            y = -x + rng.integers(0, 400, size=n)
+        xs.append(x.astype(np.float64))
+        ys.append(y.astype(np.float64))
+        off.append(off[-1] + n)
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    u = np.full(len(x), mean - 100.0)
+    to_xo = np.concatenate([mpe_c.ranks_desc(a) for a in xs])
+    to_yo = np.concatenate([mpe_c.ranks_desc(a) for a in ys])
+    return np.array(off, dtype=np.int64), x, y, u, to_xo, to_yo

@@ -287,3 +287,44 @@ def test_tool_chunks_give_the_same_file(built, tmp_path, chunks):
     exp, n = o.clustermatepairs(lines, 300, 30, 0.95, 5)
     assert n >= 5 and txt == exp
     assert "chunk(s), stages overlapped" in r.stderr
+
+
+def test_c_oracle_reaches_the_rare_paths_on_the_adversarial_batch(built):
+    """What tests/cmp_cases.adversarial_em_batch is for: components that lose every responsibility, likelihoods that
+    underflow, seedings that run out of distinct points.  The stale-state reads the reference's members would allow
+    (a component without responsibility in the FIRST M step of a fit, every K failing) never occur: k-means leaves no
+    cluster empty, and K = 1 cannot fail."""
+    from oracle import mpe_c
+    off, x, y, u, to_xo, to_yo = cmp_cases.adversarial_em_batch(1, 2000)
+    mp = mpe_c.lib().ora_min_probability(30.0, 0.95)
+    ncl, member, status, dg, _ = mpe_c.cluster_batch(300.0, 30.0, mp, 5, off, x, y, u, to_xo, to_yo)
+    assert dg.nk_zero > 10 and dg.ll_underflow > 0 and dg.kkz_fail > 1000
+    assert dg.nk_zero_first_iter == 0 and dg.all_k_failed == 0 and not status.any()
+    assert ncl.sum() > 1000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave_min", [None, "1000000000"])
+def test_em_rare_paths_wave_lane_and_oracle_agree(built, wave_min):
+    """The adversarial batch through mpe_cluster_batch — one wave per bin pair (default) and one lane per fit
+    (DEFUSE_MPE_WAVE_MIN) — against the C oracle: every membership bit."""
+    from defuse_amd import mpe
+    from oracle import mpe_c
+    mp = mpe_c.lib().ora_min_probability(30.0, 0.95)
+    old = os.environ.get("DEFUSE_MPE_WAVE_MIN")
+    try:
+        if wave_min:
+            os.environ["DEFUSE_MPE_WAVE_MIN"] = wave_min
+        for seed in (1, 2):
+            args = (300.0, 30.0, mp, 5) + cmp_cases.adversarial_em_batch(seed, 4000)
+            o_ncl, o_member, o_status, dg, _ = mpe_c.cluster_batch(*args)
+            g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
+            assert dg.nk_zero > 20 and dg.ll_underflow > 0 and dg.kkz_fail > 1000
+            assert not g_status.any() and (g_ncl == o_ncl).all()
+            assert g_member.tobytes() == o_member.tobytes()
+            assert (t.n_wave_problems == 0) == bool(wave_min)
+    finally:
+        if old is None:
+            os.environ.pop("DEFUSE_MPE_WAVE_MIN", None)
+        else:
+            os.environ["DEFUSE_MPE_WAVE_MIN"] = old
