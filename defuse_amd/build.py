@@ -75,9 +75,32 @@ def build_tools(force=False):
                 os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
                 os.path.join(ROOT, "include", "defuse_la.h"), os.path.join(ROOT, "include", "defuse_cov.h"), lib]
         if force or _newer(out, deps):
-            _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, lib,
-                  "-Wl,-rpath,$ORIGIN/../defuse_amd"])
+            if t == "dosplitalign":          # opens the C-ABI library at run time (on a helper thread), see tools_src/dosplitalign.cpp
+                _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, "-ldl"])
+            else:
+                _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, lib,
+                      "-Wl,-rpath,$ORIGIN/../defuse_amd"])
         outs.append(out)
+    return outs
+
+
+def build_sanitized(kind, force=False):
+    """The host code of the tools under a sanitizer (the CPU build is where sanitizers run; the GPU pool
+    has none): kind "asan" = -fsanitize=address,undefined, "tsan" = -fsanitize=thread, binaries in bin/<kind>/.  They link
+    the same C-ABI library; tests/test_sanitizers.py runs their host stages (threaded parsers, binners, glue) with them."""
+    flags = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "tsan": ["-fsanitize=thread"]}[kind]
+    bindir = os.path.join(ROOT, "bin", kind)
+    os.makedirs(bindir, exist_ok=True)
+    lib = build_lib()
+    outs = {}
+    for t in TOOLS:
+        src = os.path.join(ROOT, "tools_src", t + ".cpp")
+        out = os.path.join(bindir, t)
+        if force or _newer(out, [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), lib]):
+            cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread"] + flags + ["-o", out, src]
+            cmd += ["-ldl"] if t == "dosplitalign" else [lib, "-Wl,-rpath,$ORIGIN/../../defuse_amd"]
+            _run(cmd)
+        outs[t] = out
     return outs
 
 

@@ -583,34 +583,45 @@ private:
     struct Entry { long long len = 0, offset = 0; int line_blen = 0, line_len = 0; };
     static void build(const std::string& fasta, const std::string& fai)
     {
-        std::ifstream in(fasta.c_str(), std::ios::binary);
-        if (!in.good()) die("[fai_build] fail to open the FASTA file " + fasta);
+        // fai_build (faidx.c:103-170) over the mapped file: per sequence its name, length (graph characters), the offset of
+        // its first base and the byte / base length of its first line
+        MappedText in;
+        {
+            const int fd = open(fasta.c_str(), O_RDONLY);
+            if (fd < 0) die("[fai_build] fail to open the FASTA file " + fasta);
+            close(fd);
+        }
+        in.load(fasta, "[fai_build] fail to open the FASTA file ");
         std::ofstream out(fai.c_str(), std::ios::binary);
         if (!out.good()) die("[fai_build] fail to write FASTA index " + fai);
-        std::string line, name;
-        long long pos = 0, len = 0, offset = 0;
+        std::string name;
+        long long len = 0, offset = 0;
         int line_blen = 0, line_len = 0;
         bool have = false, first_line = true;
         auto flush = [&]() { if (have) out << name << "\t" << len << "\t" << offset << "\t" << line_blen << "\t" << line_len << "\n"; };
-        while (std::getline(in, line)) {
-            const long long raw = (long long)line.size() + 1;
-            if (!line.empty() && line[0] == '>') {
+        for (size_t pos = 0; pos < in.size();) {
+            const size_t e = in.line_end(pos);
+            const bool nl = e > pos && in[e - 1] == '\n';
+            const char* line = in.data() + pos;
+            const size_t n = nl ? e - 1 - pos : e - pos;
+            const long long raw = (long long)n + 1;                      // a last line without a newline counts as if it had one
+            if (n > 0 && line[0] == '>') {
                 flush();
-                size_t e = 1;
-                while (e < line.size() && !std::isspace((unsigned char)line[e])) ++e;
-                name = line.substr(1, e - 1);
+                size_t k = 1;
+                while (k < n && !std::isspace((unsigned char)line[k])) ++k;
+                name.assign(line + 1, k - 1);
                 have = true;
                 len = 0;
-                offset = pos + raw;
+                offset = (long long)pos + raw;
                 first_line = true;
                 line_blen = line_len = 0;
             } else if (have) {
                 int graph = 0;
-                for (char c : line) graph += std::isgraph((unsigned char)c) ? 1 : 0;
+                for (size_t k = 0; k < n; ++k) graph += std::isgraph((unsigned char)line[k]) ? 1 : 0;
                 if (first_line) { line_blen = graph; line_len = (int)raw; first_line = false; }
                 len += graph;
             }
-            pos += raw;
+            pos = e;
         }
         flush();
     }

@@ -14,10 +14,51 @@
 #include <mutex>
 #include <numeric>
 
+#include <dlfcn.h>
+
 #include "../include/defuse_dsa.h"
 #include "defuse_host.hpp"
 
 using namespace defuse;
+
+namespace {
+
+// The C-ABI library is opened at run time (as a JNI / ctypes / cgo binding of the same ABI would) instead of being a link
+// dependency: loading the HIP runtime and registering the code objects takes a tenth of a second, which now passes on a
+// helper thread while the main thread reads the text inputs.  $DEFUSE_DSA_LIB names the library, default
+// <directory of this binary>/../defuse_amd/libdefuse_dsa.so.
+struct DsaLib {
+    decltype(&dsa_create) create = nullptr;
+    decltype(&dsa_destroy) destroy = nullptr;
+    decltype(&dsa_pick_device) pick_device = nullptr;
+    decltype(&dsa_align_batch) align_batch = nullptr;
+    decltype(&dsa_last_error) last_error = nullptr;
+    std::string error;
+    bool load()
+    {
+        std::string path;
+        if (const char* e = std::getenv("DEFUSE_DSA_LIB")) path = e;
+        else {
+            char exe[4096];
+            const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+            if (n <= 0) { error = "cannot resolve /proc/self/exe"; return false; }
+            exe[n] = 0;
+            path = exe;
+            path = path.substr(0, path.find_last_of('/')) + "/../defuse_amd/libdefuse_dsa.so";
+        }
+        void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { error = dlerror(); return false; }
+        create = (decltype(create))dlsym(h, "dsa_create");
+        destroy = (decltype(destroy))dlsym(h, "dsa_destroy");
+        pick_device = (decltype(pick_device))dlsym(h, "dsa_pick_device");
+        align_batch = (decltype(align_batch))dlsym(h, "dsa_align_batch");
+        last_error = (decltype(last_error))dlsym(h, "dsa_last_error");
+        if (!create || !destroy || !pick_device || !align_batch || !last_error) { error = "missing symbols in " + path; return false; }
+        return true;
+    }
+};
+
+}  // namespace
 
 int main(int argc, char* argv[])
 {
@@ -48,7 +89,8 @@ int main(int argc, char* argv[])
     // would otherwise sit in front of the first batch).  A run without candidates never needs the result.
     dsa_ctx* ctx = nullptr;
     int ctx_rc = DSA_OK;
-    std::thread ctx_thread([&] { ctx_rc = dsa_create(&ctx, dsa_pick_device()); });
+    DsaLib dsa;
+    std::thread ctx_thread([&] { ctx_rc = dsa.load() ? dsa.create(&ctx, dsa.pick_device()) : DSA_E_DEVICE; });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } ctx_joiner{ctx_thread};
 
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
@@ -131,19 +173,20 @@ int main(int argc, char* argv[])
             }
         }
         if (ctx_thread.joinable()) ctx_thread.join();
+        if (!dsa.error.empty()) die("Error: cannot load the split alignment library: " + dsa.error);
         if (ctx_rc != DSA_OK || !ctx) die("Error: no usable MI355X/HIP device (dsa_create failed)");
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
         int64_t n = 0;
-        int rc = dsa_align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
+        int rc = dsa.align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
                                  B.read_bytes.data(), (int64_t)B.read_bytes.size(), pairs.data(), (int64_t)pairs.size(), recs.data(),
                                  (int64_t)recs.size(), &n);
         if (rc == DSA_E_CAPACITY) {
             recs.resize((size_t)n);
-            rc = dsa_align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
+            rc = dsa.align_batch(ctx, B.ref_bytes.data(), (int64_t)B.ref_bytes.size(), B.fusions.data(), (int32_t)nf,
                                  B.read_bytes.data(), (int64_t)B.read_bytes.size(), pairs.data(), (int64_t)pairs.size(),
                                  recs.data(), (int64_t)recs.size(), &n);
         }
-        if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa_last_error(ctx));
+        if (rc != DSA_OK) die(std::string("Error: split alignment on the GPU failed: ") + dsa.last_error(ctx));
         const double t_g1 = now();
 
         // back to the visiting order: records arrive grouped by batch pair index; contiguous shares of the candidates are
@@ -277,7 +320,16 @@ int main(int argc, char* argv[])
         // (3) + (4): the kept candidates of the round, batch by batch
         struct Pending { const char* src; size_t len; size_t dst; bool revcomp; };
         std::vector<Pending> copies;
+        size_t read_at = batch[cur].read_bytes.size();                   // bytes of the current batch handed out so far
+        {
+            size_t kept = 0;
+            for (const SamPiece& pc : pieces)
+                for (uint8_t k : pc.keep) kept += k;
+            copies.reserve(kept);
+            batch[cur].cand.reserve(batch[cur].cand.size() + std::min(kept, batch_pairs + 4096));
+        }
         auto fill_reads = [&](Batch& B) {
+            B.read_bytes.resize(read_at);                                  // grown once per call, not per candidate
             if (copies.empty()) return;
             const unsigned nt = copies.size() < 4096 ? 1u : nThreads;
             run_threads(nt, [&](unsigned t) {
@@ -323,20 +375,21 @@ int main(int argc, char* argv[])
                     }
                     dsa_pair p{};
                     p.fusion_idx = fusion_slot[(size_t)ordinal];
-                    p.read_off = (int32_t)B.read_bytes.size();
+                    p.read_off = (int32_t)read_at;
                     p.read_len = (int32_t)rn;
                     p.frag = frag;
                     p.read_end = (uint8_t)read_end;
                     p.revcomp = (uint8_t)revcomp;
-                    copies.push_back(Pending{rs, rn, B.read_bytes.size(), revcomp != 0});
-                    B.read_bytes.resize(B.read_bytes.size() + rn);
+                    copies.push_back(Pending{rs, rn, read_at, revcomp != 0});
+                    read_at += rn;
                     B.cand.push_back(p);
                 }
                 // between two SAM records: a batch never splits the candidates of one record
-                if (B.cand.size() >= batch_pairs || B.read_bytes.size() > ((size_t)1 << 30) || B.ref_bytes.size() > ((size_t)1 << 30)) {
+                if (B.cand.size() >= batch_pairs || read_at > ((size_t)1 << 30) || B.ref_bytes.size() > ((size_t)1 << 30)) {
                     fill_reads(B);
                     new_batch();
                     flush();
+                    read_at = batch[cur].read_bytes.size();
                 }
             }
             if (pc.errorLine) {                                         // the records before the bad line were taken up, as a serial reader does
