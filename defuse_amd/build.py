@@ -71,7 +71,7 @@ def build_tools(force=False):
     for t in TOOLS:
         src = os.path.join(ROOT, "tools_src", t + ".cpp")
         out = os.path.join(bindir, t)
-        deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
+        deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "tools_src", "evaluate.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
                 os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
                 os.path.join(ROOT, "include", "defuse_la.h"), os.path.join(ROOT, "include", "defuse_cov.h"), lib]
         if force or _newer(out, deps):
@@ -96,7 +96,7 @@ def build_sanitized(kind, force=False):
     for t in TOOLS:
         src = os.path.join(ROOT, "tools_src", t + ".cpp")
         out = os.path.join(bindir, t)
-        if force or _newer(out, [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), lib]):
+        if force or _newer(out, [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "tools_src", "evaluate.hpp"), lib]):
             cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread"] + flags + ["-o", out, src]
             cmd += ["-ldl"] if t == "dosplitalign" else [lib, "-Wl,-rpath,$ORIGIN/../../defuse_amd"]
             _run(cmd)

@@ -151,6 +151,15 @@ def test_config5_shaped_chain_every_intermediate_file(built, tmp_path):
     run("evalsplitalign", *common, "-a", d + "splitreads.alignments.sorted", "-q", d + "out.seq", "-b", d + "out.break", "-p", d + "out.predalign")
     seq, brk, pred = do.evalsplitalign(*ocommon, d + "splitreads.alignments.sorted")
     assert open(d + "out.seq").read() == seq and open(d + "out.break").read() == brk and open(d + "out.predalign").read() == pred
+    # the fused mode: one dosplitalign process from the set-cover clusters to the predictions, writing the same
+    # intermediate files as the separate steps above
+    open(d + "clusters.sc", "w").write(sc)
+    run("dosplitalign", "-f", case["fasta"], "-e", case["exons"], "-u", "450", "-s", "45", "-n", "150", "-x", "150",
+        "--clusters", d + "clusters.sc", "-r", d + "fused.regions", "-i", case["improper"], "-1", case["seq1"], "-2", case["seq2"],
+        "-a", d + "fused.alignments", "--sorted", "-q", d + "fused.seq", "-b", d + "fused.break", "-p", d + "fused.predalign")
+    assert open(d + "fused.regions").read() == regions
+    assert open(d + "fused.alignments").read() == open(d + "splitreads.alignments.sorted").read()
+    assert (open(d + "fused.seq").read(), open(d + "fused.break").read(), open(d + "fused.predalign").read()) == (seq, brk, pred)
     found = {tuple(l.split("\t")[2:5]) for l in brk.splitlines()}
     for (ca, sa, ba, cb, sb, bb) in case["planted"][2:5]:            # the planted junctions come back (those without microhomology exactly)
         assert (ca, sa, str(ba)) in found and (cb, sb, str(bb)) in found

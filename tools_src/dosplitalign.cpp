@@ -17,7 +17,7 @@
 #include <dlfcn.h>
 
 #include "../include/defuse_dsa.h"
-#include "defuse_host.hpp"
+#include "evaluate.hpp"
 
 using namespace defuse;
 
@@ -74,7 +74,20 @@ int main(int argc, char* argv[])
     cmd.add("1", "seq1", "End 1 Sequences", "string");
     cmd.add("2", "seq2", "End 2 Sequences", "string");
     cmd.add("a", "align", "Split Alignments Filename", "string");
+    // Fused mode (optional, the drop-in call never gives these): one process goes from the set-cover
+    // clusters to the breakpoint predictions and still writes every intermediate file the pipeline's separate steps would
+    // (scripts/defuse_run.pl:506-533: get_align_regions.pl -> dosplitalign -> sort -n -k 1 -> evalsplitalign).
+    cmd.add_optional("c", "clusters", "Fused mode: clusters file (setcover / remove_duplicates output); the regions file named by -r is WRITTEN "
+                     "from it by the rule of get_align_regions.pl", "string", "");
+    cmd.add_switch("", "sorted", "Fused mode: write the alignments in the order of `LC_ALL=C sort -n -k 1`");
+    cmd.add_optional("q", "seq", "Fused mode: Sequence Predictions Filename (evalsplitalign -q)", "string", "");
+    cmd.add_optional("b", "break", "Fused mode: Breakpoint Predictions Filename (evalsplitalign -b)", "string", "");
+    cmd.add_optional("p", "predalign", "Fused mode: Predicted Alignments Filename (evalsplitalign -p)", "string", "");
     cmd.parse(argc, argv);
+    const bool fused_eval = !cmd.str("seq").empty() || !cmd.str("break").empty() || !cmd.str("predalign").empty();
+    if (fused_eval && (cmd.str("seq").empty() || cmd.str("break").empty() || cmd.str("predalign").empty()))
+        die("Error: the fused mode needs all of --seq, --break and --predalign");
+    const bool collect = fused_eval || cmd.is_set("sorted");
     const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_main = now();
@@ -93,6 +106,46 @@ int main(int argc, char* argv[])
     std::thread ctx_thread([&] { ctx_rc = dsa.load() ? dsa.create(&ctx, dsa.pick_device()) : DSA_E_DEVICE; });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } ctx_joiner{ctx_thread};
 
+    if (!cmd.str("clusters").empty()) {
+        // scripts/get_align_regions.pl:14-53 (as bin/defuse_glue get_align_regions): per cluster end the reference, the strand
+        // and the span of its alignments; clusters ascending, end 0 then 1
+        struct EndInfo { std::string ref, strand; int start = 0, end = 0; bool have = false; };
+        std::map<int, std::map<int, EndInfo>> clusters;
+        MappedText ctext;
+        ctext.load(cmd.str("clusters"), "Error: Unable to open clusters file ");
+        for (size_t pos = 0; pos < ctext.size();) {
+            const size_t e = ctext.line_end(pos);
+            const size_t len = (e > pos && ctext[e - 1] == '\n') ? e - 1 - pos : e - pos;
+            const std::vector<std::string> f = split_tabs(std::string(ctext.data() + pos, len));
+            pos = e;
+            if (f.size() < 8) die("Error: cluster line with fewer than 8 fields");
+            const int id = lexical_int_or_die(f[0], "as cluster id"), ce = lexical_int_or_die(f[1], "as cluster end");
+            const int start = lexical_int_or_die(f[6], "as start"), end = lexical_int_or_die(f[7], "as end");
+            EndInfo& ei = clusters[id][ce];
+            ei.ref = f[4];
+            ei.strand = f[5];
+            if (!ei.have) { ei.start = start; ei.end = end; ei.have = true; }
+            ei.start = std::min(ei.start, start);
+            ei.end = std::max(ei.end, end);
+        }
+        std::string text;
+        for (const auto& c : clusters) {
+            if (c.second.size() != 2) die("Error: Did not find 2 ends for cluster " + std::to_string(c.first));
+            for (const auto& en : c.second) {
+                append_int(text, c.first); text += '\t';
+                append_int(text, en.first); text += '\t';
+                text += en.second.ref; text += '\t';
+                text += en.second.strand; text += '\t';
+                append_int(text, en.second.start); text += '\t';
+                append_int(text, en.second.end); text += '\n';
+            }
+        }
+        OrderedFileWriter rf;
+        if (!rf.open_file(cmd.str("regions"))) die("Error: unable to write " + cmd.str("regions"));
+        rf.write_round({text}, 1);
+        if (!rf.close_file()) die("Error: failed writing " + cmd.str("regions"));
+        stage("clusters -> regions file");
+    }
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
     stage("regions");
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
@@ -143,6 +196,7 @@ int main(int argc, char* argv[])
     if (const char* e = std::getenv("DEFUSE_DSA_BATCH_PAIRS")) batch_pairs = std::max<size_t>(1, (size_t)std::atoll(e));
     const unsigned nThreads = host_threads();
     std::mutex time_mutex;
+    std::vector<std::string> collected;
     auto run_batch = [&](Batch& B) {
         std::vector<dsa_pair>& cand = B.cand;
         if (cand.empty()) return;
@@ -212,7 +266,10 @@ int main(int argc, char* argv[])
                 }
             }
         });
-        out.write_round(texts, nt);
+        if (collect)
+            for (std::string& tx : texts) collected.push_back(std::move(tx));     // fused mode: sorted and evaluated at the end
+        else
+            out.write_round(texts, nt);
         std::lock_guard<std::mutex> lk(time_mutex);
         t_gpu += t_g1 - t_g0;
         t_write += now() - t_g1;
@@ -410,6 +467,72 @@ int main(int argc, char* argv[])
     new_batch();
     flush();
     if (worker.joinable()) worker.join();
+    if (collect) {
+        // `sort -n -k 1` of the pipeline (scripts/defuse_run.pl:528) in the C locale: by fusion id, lines of one fusion in byte
+        // order (sort's last-resort comparison).  Lines are indexed, grouped by id with a stable sort, and the groups — which
+        // are independent — are ordered, written and (fused evaluation) evaluated by contiguous shares of the groups.
+        struct Line { int id; uint32_t len; const char* p; };
+        std::vector<Line> lines;
+        for (const std::string& tx : collected)
+            for (size_t pos = 0; pos < tx.size();) {
+                const char* nl = (const char*)memchr(tx.data() + pos, '\n', tx.size() - pos);
+                const size_t e = nl ? (size_t)(nl - tx.data()) + 1 : tx.size();
+                int id = 0;
+                const char* tab = (const char*)memchr(tx.data() + pos, '\t', e - pos);
+                field_int(tx.data() + pos, tab ? (size_t)(tab - (tx.data() + pos)) : 0, id);
+                lines.push_back(Line{id, (uint32_t)(e - pos), tx.data() + pos});
+                pos = e;
+            }
+        std::stable_sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) { return a.id < b.id; });
+        std::vector<size_t> group(1, 0);
+        for (size_t k = 1; k < lines.size(); ++k)
+            if (lines[k].id != lines[k - 1].id) group.push_back(k);
+        if (!lines.empty()) group.push_back(lines.size());
+        const size_t ng = group.empty() ? 0 : group.size() - 1;
+        const unsigned nt = ng < 64 ? 1u : nThreads;
+        std::vector<std::string> sorted_text(nt);
+        std::vector<EvalTexts> ev(nt);
+        const SplitAlignmentTask emptyTask;
+        run_threads(nt, [&](unsigned t) {
+            std::vector<SplitAlignment> alignments;
+            std::vector<const SplitAlignment*> kept;
+            std::map<std::pair<int, int>, int> splitScore;
+            for (size_t g = ng * t / nt; g < ng * (t + 1) / nt; ++g) {
+                std::sort(lines.begin() + (std::ptrdiff_t)group[g], lines.begin() + (std::ptrdiff_t)group[g + 1], [](const Line& a, const Line& b) {
+                    const int c = memcmp(a.p, b.p, std::min(a.len, b.len));
+                    return c != 0 ? c < 0 : a.len < b.len;
+                });
+                alignments.clear();
+                for (size_t k = group[g]; k < group[g + 1]; ++k) {
+                    sorted_text[t].append(lines[k].p, lines[k].len);
+                    if (fused_eval) {
+                        SplitAlignment a;
+                        bool id_read;
+                        const std::string err = parse_line(lines[k].p, lines[k].len - 1, a, id_read);
+                        if (!err.empty()) die(err);
+                        alignments.push_back(a);
+                    }
+                }
+                if (fused_eval) {
+                    auto ti = tasks.find(lines[group[g]].id);
+                    EvaluateGroup(ti == tasks.end() ? emptyTask : ti->second, alignments, ev[t], kept, splitScore);
+                }
+            }
+        });
+        out.write_round(sorted_text, nt);
+        if (fused_eval) {
+            const char* names[3] = {"seq", "break", "predalign"};
+            for (int f = 0; f < 3; ++f) {
+                OrderedFileWriter w;
+                if (!w.open_file(cmd.str(names[f]))) die("Error: Unable to open " + cmd.str(names[f]));
+                std::vector<std::string> parts(nt);
+                for (unsigned t = 0; t < nt; ++t) parts[t].swap(f == 0 ? ev[t].seq : f == 1 ? ev[t].brk : ev[t].pred);
+                w.write_round(parts, nt);
+                if (!w.close_file()) die("Error: failed writing " + cmd.str(names[f]));
+            }
+        }
+        stage("fused: sort + evaluation + files");
+    }
     stage("candidates + alignment + output");
     if (timing) std::cerr << "[dosplitalign] of which GPU calls " << t_gpu << " s, formatting and writing " << t_write << " s" << std::endl;
     if (ctx_thread.joinable()) ctx_thread.join();
