@@ -10,6 +10,8 @@
 // computes it.  Latency/HBM bound integer-and-compare work; nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
+#include "hip_raii.hpp"
+
 #include <chrono>
 #include <cstdio>
 #include <string>
@@ -239,8 +241,8 @@ extern "C" int hc_cluster_batch(int device, int32_t n_tables, const int32_t* n_i
     if (in_end) HC_HIP(hipMemcpy(d_in.p, distances, sizeof(double) * in_end, hipMemcpyHostToDevice));
     const double t_up = now_ms();
 
-    hipEvent_t e0, e1;
-    HC_HIP(hipEventCreate(&e0)); HC_HIP(hipEventCreate(&e1));
+    hipraii::Event e0, e1;                 // destroyed on every return
+    HC_HIP(e0.create()); HC_HIP(e1.create());
     HC_HIP(hipEventRecord(e0, nullptr));
     hipLaunchKernelGGL(k_hc, dim3(n_tables), dim3(HC_THREADS), 0, nullptr, d_tabs.p, d_in.p, d_D.p, d_S.p, d_slots.p,
                        d_members.p, d_cluster_of.p, d_ncl.p, d_nmerge.p);
@@ -249,7 +251,6 @@ extern "C" int hc_cluster_batch(int device, int32_t n_tables, const int32_t* n_i
     HC_HIP(hipEventSynchronize(e1));
     float kms = 0;
     HC_HIP(hipEventElapsedTime(&kms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 
     std::vector<int32_t> nmerge(n_tables);
     HC_HIP(hipMemcpy(n_clusters, d_ncl.p, sizeof(int32_t) * n_tables, hipMemcpyDeviceToHost));

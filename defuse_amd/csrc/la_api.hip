@@ -20,6 +20,8 @@
 // same number of rows and tiles.
 #include <hip/hip_runtime.h>
 
+#include "hip_raii.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -421,8 +423,8 @@ int la_align_batch_min(int device, int32_t match, int32_t mismatch, int32_t gap,
     HIPL(d_scores.alloc((size_t)n_items));
     HIPL(hipMemcpy(d_pool.p, pool, (size_t)pool_len, hipMemcpyHostToDevice));
     HIPL(hipMemcpy(d_items.p, items, (size_t)n_items * sizeof(la_item), hipMemcpyHostToDevice));
-    hipEvent_t ev[3];
-    for (auto& e : ev) HIPL(hipEventCreate(&e));
+    hipraii::Event ev[3];                 // destroyed on every return
+    for (auto& e : ev) HIPL(e.create());
 
     size_t budget_dwords = (size_t)2 << 28;       // 2 GiB of planes per launch group
     if (const char* e = getenv("DEFUSE_LA_SCRATCH_MB")) budget_dwords = std::max<size_t>(1, (size_t)atoll(e)) << 18;
@@ -475,7 +477,6 @@ int la_align_batch_min(int device, int32_t match, int32_t mismatch, int32_t gap,
     };
     int rc = run_range(0, first16, 1);
     if (rc == DSA_OK) rc = run_range(first16, n_items, 2);
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (rc != DSA_OK) return rc;
     HIPL(hipMemcpy(scores, d_scores.p, (size_t)n_items * sizeof(int32_t), hipMemcpyDeviceToHost));
     tm.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

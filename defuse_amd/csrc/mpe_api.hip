@@ -14,6 +14,8 @@
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 
+#include "hip_raii.hpp"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1028,12 +1030,12 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         MPE_HIP(hipMemcpy(d_tyo.p, to_yo, n_mp * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     MPE_HIP(hipMemset(d_iters.p, 0, sizeof(unsigned long long)));
-    hipEvent_t e0, e1, e2;
-    MPE_HIP(hipEventCreate(&e0));
-    MPE_HIP(hipEventCreate(&e1));
-    MPE_HIP(hipEventCreate(&e2));
-    hipStream_t s_wave;
-    MPE_HIP(hipStreamCreateWithFlags(&s_wave, hipStreamNonBlocking));
+    hipraii::Event e0, e1, e2;               // destroyed on every return, the early ones of MPE_HIP included
+    MPE_HIP(e0.create());
+    MPE_HIP(e1.create());
+    MPE_HIP(e2.create());
+    hipraii::Stream s_wave;
+    MPE_HIP(s_wave.create(hipStreamNonBlocking));
     // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none).  The wave
     // version is the faster one at every size (profiles/microbench/mpe_sweep.sh); the lane version stays as the literal
     // transcription it is checked against
@@ -1120,10 +1122,6 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     if (n_mp) MPE_HIP(hipMemcpy(member, d_member.p, n_mp * sizeof(uint16_t), hipMemcpyDeviceToHost));
     unsigned long long it = 0;
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipEventDestroy(e2);
-    (void)hipStreamDestroy(s_wave);
 
     t.em_iterations = (int64_t)it;
     for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;

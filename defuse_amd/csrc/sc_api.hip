@@ -2,6 +2,8 @@
 // tools/setcover.cpp:30-110.  Integer/byte work: radix sort + label propagation are HBM-bound, the
 // per-component greedy is latency-bound; nothing here is shaped into a GEMM.
 #include <hip/hip_runtime.h>
+
+#include "hip_raii.hpp"
 #include <hipcub/hipcub.hpp>
 
 #include <cstdio>
@@ -224,8 +226,8 @@ extern "C" int sc_cover(int device, const int64_t* cluster_off, const int32_t* e
     for (int64_t e = 0; e <= max_element; ++e) owner[e] = -1;
     if (n_clusters == 0 || n_occ == 0) { if (timing) *timing = t; return 0; }
 
-    hipEvent_t ev[4];
-    for (auto& e : ev) SC_HIP(hipEventCreate(&e));
+    hipraii::Event ev[4];                 // destroyed on every return
+    for (auto& e : ev) SC_HIP(e.create());
     Buf<int64_t> d_coff, d_e2c_off;
     Buf<int32_t> d_el, d_occ_cluster, d_keys_sorted, d_e2c, d_label, d_label_sorted, d_idx, d_comp_clusters, d_flag, d_rank,
         d_comp_begin, d_size, d_seq, d_owner, d_large, d_nlarge;
@@ -312,7 +314,6 @@ extern "C" int sc_cover(int device, const int64_t* cluster_off, const int32_t* e
     t.n_components = n_components;
     t.n_large = n_large;
     t.cc_iterations = iterations;
-    for (auto& e : ev) (void)hipEventDestroy(e);
     if (timing) *timing = t;
     return 0;
 }
