@@ -56,7 +56,7 @@ def profile_block(name, workload, lib_hash):
     except (OSError, ValueError):
         return None, "no %s" % os.path.relpath(path, ROOT)
     w = d.get("workload", {})
-    if tuple(w.get(k) for k in ("fusions", "reads", "lq", "lr")) != tuple(workload[k] for k in ("fusions", "reads", "lq", "lr")):
+    if workload is not None and tuple(w.get(k) for k in ("fusions", "reads", "lq", "lr")) != tuple(workload[k] for k in ("fusions", "reads", "lq", "lr")):
         return None, "%s was taken on another workload" % os.path.relpath(path, ROOT)
     if d.get("source_hash") != lib_hash:
         return None, "%s was taken on other kernels (source hash %s, library %s): re-profile" % (
@@ -82,7 +82,8 @@ def valu_issue(workload, lib_hash, launch_ms):
            "frac_flat4": 4.0 * instr / simds / kernel_cycles,
            "measured_busy_frac": (4.0 * busy_quads / simds / kernel_cycles) if busy_quads else None,
            "unit": "cycles per SIMD at 2.4 GHz nominal", "source": src}
-    mix = d.get("mix")             # {"two_cycle": share, "four_cycle": share} of the kernel's VALU instructions (ISA dump)
+    md, _ = profile_block("fill_mix.json", None, lib_hash)      # static mix of the row sweep (profiles/microbench/fill_mix.py)
+    mix = md.get("mix") if md else None
     if mix:
         per = 2.0 * mix["two_cycle"] + 4.0 * mix["four_cycle"]
         out["issue_cycles_priced"] = per * instr / simds
