@@ -66,6 +66,7 @@ struct PipeLane {
     int64_t resident_upload = -1;   // the descriptors of (resident_upload, resident_slice) are on the device
     int resident_slice = -1;
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
+    bool fill_recorded = false; // ev[2] (end of a fill) has been recorded at least once in this run
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
@@ -536,7 +537,17 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
         L.resident_slice = slice_idx;
     }
     HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
+    // The fill launches of consecutive slices run one after the other (this lane's fill waits for the other lane's fill to
+    // end), so a launch has the chip to itself and its duration means what it says; what overlaps with a fill is the other
+    // lane's latency-bound finish stage.  DEFUSE_DSA_OVERLAP_FILLS=1 lets the fills themselves overlap (measured within 1 %
+    // of this on BASELINE configs[1] and configs[3]; it blurs the per-launch times).
+    {
+        PipeLane& other = ctx->lanes->lane[&L == &ctx->lanes->lane[0] ? 1 : 0];
+        static const bool overlap_fills = [] { const char* e = getenv("DEFUSE_DSA_OVERLAP_FILLS"); return e && atoi(e) != 0; }();
+        if (!overlap_fills && other.fill_recorded) HIPC(hipStreamWaitEvent(st, other.ev[2], 0));
+    }
     if (int rc = launch_compute(ctx, L, s)) return rc;
+    L.fill_recorded = true;
     L.slice = slice_idx;
     return DSA_OK;
 }
@@ -802,6 +813,7 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
     ctx->n_records = 0;
     ctx->timing = dsa_timing{};
     ctx->timing.cells = ctx->total_cells;
+    for (PipeLane& L : ctx->lanes->lane) L.fill_recorded = false;
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
     const auto t0 = std::chrono::steady_clock::now();
