@@ -66,7 +66,6 @@ struct PipeLane {
     int64_t resident_upload = -1;   // the descriptors of (resident_upload, resident_slice) are on the device
     int resident_slice = -1;
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
-    bool fill_recorded = false; // ev[2] (end of a fill) has been recorded at least once in this run
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
@@ -308,10 +307,13 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     const int lq1 = (lqmax + 1 + 3) & ~3;
     const size_t per_wg = slice_scratch_bytes(WG_WAVES, lq1, nch_all);
     int64_t chunk = (int64_t)std::min<size_t>((size_t)1 << 40, ctx->scratch_budget / std::max<size_t>(per_wg, 1)) * WG_LANES;
-    // A batch that fits one slice but is large is cut in two, so that the latency-bound finish kernels of the first half run
-    // beside the fill of the second on the other lane (+2 % aligns/s on BASELINE configs[1], 4.01 against 4.09 ms per
-    // step; four or eight slices lose: 4.66 and 5.61 ms, the concurrent fill launches slow each other down).
-    if (chunk >= n_pairs && n_pairs >= ((int64_t)1 << 19)) chunk = ((n_pairs + 1) / 2 + WG_LANES - 1) / WG_LANES * WG_LANES;
+    // A batch that fits one slice runs as ONE fill launch.  Cutting it in two so that the latency-bound finish kernels of the
+    // first half run beside the fill of the second (DEFUSE_DSA_SPLIT_LARGE=1) measured +1 % aligns/s on BASELINE configs[1]
+    // (4.04 against 4.08 ms per step) with the two fills overlapping on the two lanes — which blurs the per-launch times the
+    // roofline is computed from — and -10 % with the fills serialised (4.52 ms: two launch tails instead of one); four or
+    // eight slices lose as well (4.66, 5.61 ms).  So it stays off.
+    if (const char* e = getenv("DEFUSE_DSA_SPLIT_LARGE"))
+        if (atoi(e) != 0 && chunk >= n_pairs && n_pairs >= ((int64_t)1 << 19)) chunk = ((n_pairs + 1) / 2 + WG_LANES - 1) / WG_LANES * WG_LANES;
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
     if (chunk < 2 * WG_LANES) return 0;
     DevBuf<FusionStat> d_stat;
@@ -537,17 +539,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
         L.resident_slice = slice_idx;
     }
     HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
-    // The fill launches of consecutive slices run one after the other (this lane's fill waits for the other lane's fill to
-    // end), so a launch has the chip to itself and its duration means what it says; what overlaps with a fill is the other
-    // lane's latency-bound finish stage.  DEFUSE_DSA_OVERLAP_FILLS=1 lets the fills themselves overlap (measured within 1 %
-    // of this on BASELINE configs[1] and configs[3]; it blurs the per-launch times).
-    {
-        PipeLane& other = ctx->lanes->lane[&L == &ctx->lanes->lane[0] ? 1 : 0];
-        static const bool overlap_fills = [] { const char* e = getenv("DEFUSE_DSA_OVERLAP_FILLS"); return e && atoi(e) != 0; }();
-        if (!overlap_fills && other.fill_recorded) HIPC(hipStreamWaitEvent(st, other.ev[2], 0));
-    }
     if (int rc = launch_compute(ctx, L, s)) return rc;
-    L.fill_recorded = true;
     L.slice = slice_idx;
     return DSA_OK;
 }
@@ -813,7 +805,6 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
     ctx->n_records = 0;
     ctx->timing = dsa_timing{};
     ctx->timing.cells = ctx->total_cells;
-    for (PipeLane& L : ctx->lanes->lane) L.fill_recorded = false;
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
     const auto t0 = std::chrono::steady_clock::now();
