@@ -211,7 +211,7 @@ int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs,
 // Returns 1 if the plan was made, 0 if not.
 // plans pairs [begin, end) of the caller's order as one slice; 0 = some fusion is not one run in it
 int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t end, int lq1, DevBuf<FusionStat>& d_stat,
-               DevBuf<int32_t>& d_votes, DevBuf<uint8_t>& d_tiles, DevBuf<int32_t>& d_start, Slice& cur)
+               DevBuf<int32_t>& d_votes, DevBuf<uint8_t>& d_tiles, DevBuf<int32_t>& d_start, DevBuf<int32_t>& d_rank, Slice& cur)
 {
     const int nf = ctx->n_fusions;
     const int64_t n = end - begin;
@@ -287,9 +287,23 @@ int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t e
     cur.g.n_pairs = n;
     cur.g.orig = ctx->d_orig.p + begin;        // slice-relative indices of the caller's order
 
-    // pairs into sweep order on the device
+    // pairs into sweep order on the device: the fusions in the order just made, the pairs of a fusion by the estimated
+    // read split (k_rank_in_fusion), alternate fusions in opposite directions (DEFUSE_DSA_NO_RANK=1: caller's order inside)
+    std::vector<uint8_t> flip((size_t)nf, 0);
+    {
+        int pos_in_order = 0;
+        for (int f : forder) flip[f] = (uint8_t)(pos_in_order++ & 1);
+    }
+    static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
     HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p,
+    HIPC(hipMemcpyAsync(d_tiles.p, flip.data(), (size_t)nf, hipMemcpyHostToDevice, st));        // the tile votes were read above: the buffer is free
+    HIPC(d_rank.reserve((size_t)n));
+    if (no_rank)
+        hipLaunchKernelGGL(k_rank_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_rank.p);
+    else
+        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p, pairs,
+                           d_stat.p, d_tiles.p, d_rank.p);
+    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p, d_rank.p,
                        ctx->d_pairs_sweep.p + begin, ctx->d_orig.p + begin);
     HIPC(hipStreamSynchronize(st));             // new_start is reused by the next chunk
     HIPC(hipGetLastError());
@@ -317,7 +331,7 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
     if (chunk < 2 * WG_LANES) return 0;
     DevBuf<FusionStat> d_stat;
-    DevBuf<int32_t> d_votes, d_start;
+    DevBuf<int32_t> d_votes, d_start, d_rank;
     DevBuf<uint8_t> d_tiles;
     HIPC(d_stat.reserve((size_t)nf));
     HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
@@ -329,7 +343,7 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
     ctx->total_cells = 0;
     for (int64_t b = 0; b < n_pairs; b += chunk) {
         Slice cur;
-        const int rc = plan_chunk(ctx, fusions, b, std::min(n_pairs, b + chunk), lq1, d_stat, d_votes, d_tiles, d_start, cur);
+        const int rc = plan_chunk(ctx, fusions, b, std::min(n_pairs, b + chunk), lq1, d_stat, d_votes, d_tiles, d_start, d_rank, cur);
         if (rc != 1) return rc;                 // the caller's pairs are untouched: the unplanned path takes over
         slices.push_back(std::move(cur));
     }

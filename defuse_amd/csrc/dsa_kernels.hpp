@@ -343,14 +343,120 @@ __global__ __launch_bounds__(64) void k_probe_wave(const uint8_t* __restrict__ r
     }
 }
 
-// pair p of fusion f (one run starting at first[f]) goes to sweep position new_start[f] + (p - first[f])
+// Order of the pairs INSIDE a fusion (speed only, like the order of the fusions).  All reads of a fusion end their window-0
+// alignment in the same column (the junction) and begin it a read-split a* earlier, so the rows of M1 a wave must sweep in
+// the junction's tile are max(a*) of its lanes, and those of M2 in its tile Lq - min(a*).  Reads in caller order give every
+// wave the full range; sorted by a* a wave holds a contiguous part of it and both matrices stop earlier (exact pruning,
+// DESIGN.md 4).  a* is estimated by the diagonal of the read's first 11-mer found in window 0 (hash of the window's
+// 11-mers in LDS; a read without one — its junction is in its first bases, or it does not belong — sorts to the
+// small-a* end).  Fusions alternate the direction (flip) so that a wave straddling two fusions continues in the same range.
+// One workgroup per fusion; rank[p - first] = position of pair p inside the fusion's run.  Fusions with more than
+// RANK_MAX pairs or windows of 1000 bases and more keep the caller's order.
+constexpr int RANK_MAX = 2048, RANK_K = 11, RANK_HASH = 2048;
+__global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
+                                                        const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
+                                                        const FusionStat* __restrict__ st, const uint8_t* __restrict__ flip,
+                                                        int32_t* __restrict__ rank)
+{
+    __shared__ uint32_t table[RANK_HASH];          // (11-mer << 10) | first position, ~0 = empty
+    __shared__ uint32_t keys[RANK_MAX];            // (sort key << 16) | index inside the fusion
+    const int f = blockIdx.x;
+    const FusionStat s = st[f];
+    const int n = s.count;
+    if (n <= 0) return;
+    const int64_t p0 = s.first;
+    const dsa_fusion fu = fusions[f];
+    if (n > RANK_MAX || n < 2 || fu.ref0_len >= 1000 || fu.ref0_len < RANK_K) {
+        for (int k = threadIdx.x; k < n; k += blockDim.x) rank[p0 + k] = k;
+        return;
+    }
+    auto code = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; };
+    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) table[k] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint8_t* r0 = ref_bytes + fu.ref0_off;
+    for (int x = threadIdx.x; x + RANK_K <= fu.ref0_len; x += blockDim.x) {
+        uint32_t km = 0;
+        bool ok = true;
+        for (int k = 0; k < RANK_K; ++k) {
+            const int c = code(r0[x + k]);
+            ok = ok && c >= 0;
+            km = (km << 2) | (uint32_t)(c & 3);
+        }
+        if (!ok) continue;
+        const uint32_t val = (km << 10) | (uint32_t)x;
+        uint32_t h = (km * 2654435761u) >> 21;                     // 11 bits
+        for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
+            const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, val);
+            if (old == 0xFFFFFFFFu) break;
+            if ((old >> 10) == km) { atomicMin(&table[h], val); break; }     // same 11-mer: the smallest position stays
+        }
+    }
+    __syncthreads();
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int k = threadIdx.x; k < npad; k += blockDim.x) {
+        uint32_t key = 0xFFFFu;                                   // padding sorts behind everything
+        if (k < n) {
+            const dsa_pair pr = pairs[p0 + k];
+            const uint8_t* rd = read_bytes + pr.read_off;
+            int diag = 1023;                                      // no 11-mer of window 0: junction in the first bases
+            for (int off = 0; off <= 12 && off + RANK_K <= pr.read_len && diag == 1023; off += 4) {
+                uint32_t km = 0;
+                bool ok = true;
+                for (int q = 0; q < RANK_K; ++q) {
+                    const int c = code(rd[off + q]);
+                    ok = ok && c >= 0;
+                    km = (km << 2) | (uint32_t)(c & 3);
+                }
+                if (!ok) continue;
+                uint32_t h = (km * 2654435761u) >> 21;
+                for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
+                    const uint32_t e = table[h];
+                    if (e == 0xFFFFFFFFu) break;
+                    if ((e >> 10) == km) { diag = min(1022, max(0, (int)(e & 1023u) - off + 16)); break; }
+                }
+            }
+            const int kk = flip[f] ? 1023 - diag : diag;
+            key = ((uint32_t)kk << 16) | (uint32_t)k;
+            if (n > 65535) key = 0;                               // (cannot happen: n <= RANK_MAX)
+        } else {
+            key = 0xFFFF0000u | (uint32_t)k;
+        }
+        keys[k] = key;
+    }
+    __syncthreads();
+    // bitonic sort of keys[0 .. npad) ascending: (key, index) pairs are distinct, so the order is fully determined
+    for (int size = 2; size <= npad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
+                const int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
+                const bool up = ((lo / size) & 1) == 0;
+                const uint32_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int r = threadIdx.x; r < n; r += blockDim.x) rank[p0 + (keys[r] & 0xFFFFu)] = r;
+}
+
+// the caller's order inside every fusion
+__global__ void k_rank_identity(const dsa_pair* __restrict__ pairs, int64_t n_pairs, const FusionStat* __restrict__ st, int32_t* __restrict__ rank)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    rank[p] = (int32_t)(p - st[pairs[p].fusion_idx].first);
+}
+
+// pair p of fusion f (one run starting at first[f]) goes to sweep position new_start[f] + rank[p] (its place inside the fusion)
 __global__ void k_permute_pairs(const dsa_pair* __restrict__ pairs, int64_t n_pairs, const FusionStat* __restrict__ st,
-                                const int32_t* __restrict__ new_start, dsa_pair* __restrict__ sweep, int32_t* __restrict__ orig)
+                                const int32_t* __restrict__ new_start, const int32_t* __restrict__ rank, dsa_pair* __restrict__ sweep,
+                                int32_t* __restrict__ orig)
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const dsa_pair pr = pairs[p];
-    const int64_t q = (int64_t)new_start[pr.fusion_idx] + (p - st[pr.fusion_idx].first);
+    (void)st;
+    const int64_t q = (int64_t)new_start[pr.fusion_idx] + rank[p];
     sweep[q] = pr;
     orig[q] = (int32_t)p;
 }
