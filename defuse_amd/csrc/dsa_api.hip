@@ -145,6 +145,9 @@ struct dsa_ctx {
     DevBuf<dsa_pair> d_pairs_sweep;  // second pair buffer: the permutation is written here, then the two are swapped
     DevBuf<dsa_pair> d_pairs;
     DevBuf<int32_t> d_min_score;
+    DevBuf<FusionStat> plan_stat;    // sweep planning (plan_sweep): per-fusion statistics, probe votes, tiles / flips, starts, ranks
+    DevBuf<int32_t> plan_votes, plan_start, plan_rank;
+    DevBuf<uint8_t> plan_tiles;
     std::vector<Slice> slices;
     int64_t total_cells = 0;
 
@@ -330,15 +333,17 @@ int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqm
         if (atoi(e) != 0 && chunk >= n_pairs && n_pairs >= ((int64_t)1 << 19)) chunk = ((n_pairs + 1) / 2 + WG_LANES - 1) / WG_LANES * WG_LANES;
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
     if (chunk < 2 * WG_LANES) return 0;
-    DevBuf<FusionStat> d_stat;
-    DevBuf<int32_t> d_votes, d_start, d_rank;
-    DevBuf<uint8_t> d_tiles;
+    // planning buffers live in the context: an upload after the first finds them allocated
+    DevBuf<FusionStat>& d_stat = ctx->plan_stat;
+    DevBuf<int32_t>&d_votes = ctx->plan_votes, &d_start = ctx->plan_start, &d_rank = ctx->plan_rank;
+    DevBuf<uint8_t>& d_tiles = ctx->plan_tiles;
     HIPC(d_stat.reserve((size_t)nf));
     HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
     HIPC(d_tiles.reserve((size_t)nf * 2));
     HIPC(d_start.reserve((size_t)nf));
     HIPC(ctx->d_orig.reserve((size_t)n_pairs));
     HIPC(ctx->d_pairs_sweep.reserve((size_t)n_pairs + 1));
+    HIPC(d_rank.reserve((size_t)std::min<int64_t>(n_pairs, chunk)));
     std::vector<Slice> slices;
     ctx->total_cells = 0;
     for (int64_t b = 0; b < n_pairs; b += chunk) {
@@ -706,6 +711,7 @@ void dsa_destroy(dsa_ctx* ctx)
     (void)hipDeviceSynchronize();
     ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_sweep.release();
     ctx->d_min_score.release(); ctx->d_records.release(); ctx->d_refcodes.release();
+    ctx->plan_stat.release(); ctx->plan_votes.release(); ctx->plan_start.release(); ctx->plan_rank.release(); ctx->plan_tiles.release();
     for (auto& e : ctx->ev_pack)
         if (e) (void)hipEventDestroy(e);
     ctx->lanes.reset();          // the last context of a shared set frees the lanes (streams, events, scratch planes)
