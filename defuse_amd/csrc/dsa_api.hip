@@ -243,9 +243,23 @@ int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t e
     std::vector<int32_t> forder;
     for (int f = 0; f < nf; ++f)
         if (stat[f].count > 0) forder.push_back(f);
+    // inside a size class the expensive fusions first (longest-processing-time order: the workgroups that are still
+    // running when the launch drains are then the cheap ones).  Cost proxy: the number of distinct tiles in which either
+    // matrix is alive, {t1-1, t1} and {t2-1, t2} with t1, t2 the probed end tiles — 2 when they coincide, up to 4.
+    auto alive_tiles = [&](int f) {
+        const int t1 = tiles[2 * f], t2 = tiles[2 * f + 1];
+        if (t1 == 255 || t2 == 255) return 4;                  // no vote: assume the worst
+        const int d = t1 > t2 ? t1 - t2 : t2 - t1;
+        return d == 0 ? 2 : d == 1 ? 3 : 4;
+    };
+    static const bool lpt = [] { const char* e = getenv("DEFUSE_DSA_NO_LPT"); return !(e && atoi(e) != 0); }();
     std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
         const int ca = size_class(a), cb = size_class(b);
         if (ca != cb) return ca < cb;
+        if (lpt) {
+            const int ka = alive_tiles(a), kb = alive_tiles(b);
+            if (ka != kb) return ka > kb;
+        }
         return tiles[2 * a] * 256 + tiles[2 * a + 1] < tiles[2 * b] * 256 + tiles[2 * b + 1];
     });
 
