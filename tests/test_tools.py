@@ -196,3 +196,47 @@ def test_evalsplitalign_malformed_lines_end_the_run_like_the_reference(tools, tm
     assert r.returncode == 1 and done == groups[:1]
     r, done = run(lines[:third] + ["short\tline\n"] + lines[third:])     # fewer than seven fields at a group change
     assert r.returncode == 1 and "Format error for candidate reads line" in r.stderr and done == groups[:1]
+
+
+def test_outputs_may_be_pipes(tools, tmp_path):
+    """The reference writes its outputs through ofstream, which accepts /dev/stdout, FIFOs and process substitution; the
+    ordered writer of the tools falls back to plain ordered writes when the target is not a regular file."""
+    from oracle import dosplitalign_oracle as ora
+    case = pipeline_case.build(str(tmp_path / "case"), seed=13, n_fusions=5, reads_per_fusion=15)
+    txt = ora.dosplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                           case["regions"], case["improper"], case["seq1"], case["seq2"])
+    lines = sorted(txt.splitlines(True), key=lambda l: int(l.split("\t")[0]))
+    align = tmp_path / "sorted.align"
+    align.write_text("".join(lines))
+    exp = ora.evalsplitalign(case["fasta"], case["exons"], case["ufrag"], case["sfrag"], case["minread"], case["maxread"],
+                             case["regions"], str(align))
+    out = str(tmp_path / "pred")
+    args = eval_args(case, str(align), out)
+    args[args.index("-b") + 1] = "/dev/stdout"                       # the break file goes down a pipe
+    r = subprocess.run([EVAL] + args, capture_output=True, text=True, env=dict(os.environ, DEFUSE_THREADS="3"))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == exp[1] and open(out + ".seq").read() == exp[0] and open(out + ".predalign").read() == exp[2]
+
+
+def test_device_pick_spreads_concurrent_processes(tools, tmp_path):
+    """dsa_pick_device_among: processes that live side by side get different devices (lock files), a lone process gets
+    pid mod n; a taken lock is skipped."""
+    import ctypes
+    import sys
+    code = ("import ctypes, os, sys, time\n"
+            "lib = ctypes.CDLL(sys.argv[1])\n"
+            "print(lib.dsa_pick_device_among(4), flush=True)\n"
+            "time.sleep(float(sys.argv[2]))\n")
+    from defuse_amd import dsa
+    env = dict(os.environ, DEFUSE_GPU_LOCK_DIR=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code, dsa.LIB_PATH, "3"], stdout=subprocess.PIPE, text=True, env=env) for _ in range(4)]
+    picked = [int(p.stdout.readline()) for p in procs]
+    assert sorted(picked) == [0, 1, 2, 3]                              # four live processes, four devices
+    fifth = subprocess.run([sys.executable, "-c", code, dsa.LIB_PATH, "0"], capture_output=True, text=True, env=env)
+    assert int(fifth.stdout) in (0, 1, 2, 3)                           # all taken: pid mod n
+    for p in procs:
+        p.wait()
+    again = subprocess.run([sys.executable, "-c", code, dsa.LIB_PATH, "0"], capture_output=True, text=True, env=env)
+    assert int(again.stdout) in (0, 1, 2, 3)
+    lib = ctypes.CDLL(dsa.LIB_PATH)
+    assert lib.dsa_pick_device_among(1) == 0 and lib.dsa_pick_device_among(0) == 0
