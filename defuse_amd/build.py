@@ -111,7 +111,8 @@ def build_oracle(force=False):
     out2 = os.path.join(ROOT, "oracle", "libmpe_oracle.so")
     srcs = [os.path.join(ROOT, "oracle", "dsa_oracle.c"), os.path.join(ROOT, "include", "defuse_dsa.h")]
     srcs2 = [os.path.join(ROOT, "oracle", "mpe_oracle.c")]
-    ref_missing = os.path.exists("/root/reference/tools/asa136.C") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libasa_ref.so"))
+    ref_missing = os.path.exists("/root/reference/tools/asa136.C") and not (
+        os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libasa_ref.so")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libfaidx_ref.so")))
     if force or _newer(out, srcs) or _newer(out2, srcs2) or ref_missing:
         _run(["make", "-C", os.path.join(ROOT, "oracle")] + (["-B"] if force else []))
     return out

@@ -147,7 +147,10 @@ class FastaIndex:
         e = end
         if beg >= len(seq):
             beg = len(seq)
-        if e >= len(seq):
+        # faidx.c:337 compares the int `end` with the unsigned 32-bit field val.len: a NEGATIVE end (a window that lies wholly
+        # before the sequence start: "name:1--12") converts to a huge unsigned number and is clipped to the sequence END,
+        # so the reference fetches the whole sequence from `beg` on (pinned by tests/test_faidx_ref.py)
+        if e < 0 or e >= len(seq):
             e = len(seq)
         if beg > e:
             beg = e

@@ -73,7 +73,7 @@ def test_cli(built):
     from defuse_amd import build
     build.build_tools()
     r = subprocess.run([TOOL, "-c", "x"], capture_output=True, text=True)
-    assert r.returncode == 1 and "Required arguments missing: minclustersize, outclust" in r.stderr
+    assert r.returncode == 1 and "One or more required arguments missing!" in r.stderr
     r = subprocess.run([TOOL, "--help"], capture_output=True, text=True)
     assert "Set cover for maximum parsimony" in r.stdout
 

@@ -29,7 +29,7 @@ def smoke_args(tmp, out, regions="regions.txt"):
 
 def test_cli_errors(tools, tmp_path):
     r = subprocess.run([TOOL, "-f", "x"], capture_output=True, text=True)
-    assert r.returncode == 1 and r.stderr.startswith("PARSE ERROR:") and "Required arguments missing" in r.stderr
+    assert r.returncode == 1 and r.stderr.startswith("PARSE ERROR:") and "One or more required arguments missing!" in r.stderr
     r = subprocess.run([TOOL, "--bogus", "1"], capture_output=True, text=True)
     assert r.returncode == 1 and "Couldn't find match for argument" in r.stderr
     args = smoke_args(tmp_path, str(tmp_path / "o"))

@@ -142,9 +142,9 @@ int main(int argc, char* argv[])
     CmdLine cmd("Mate Pair Clustering Tool");
     cmd.add("a", "align", "Alignments Filename", "string");
     cmd.add("c", "clusters", "Output Clusters Filename", "string");
-    cmd.add("u", "fragmentmean", "Fragment Length Mean", "float");
-    cmd.add("s", "fragmentstddev", "Fragment Length Standard Deviation", "float");
-    cmd.add("p", "precision", "Precision", "float");
+    cmd.add("u", "fragmentmean", "Fragment Length Mean", "integer", "float");       // a double the reference labels "integer" (:403-404)
+    cmd.add("s", "fragmentstddev", "Fragment Length Standard Deviation", "integer", "float");
+    cmd.add("p", "precision", "Precision", "double", "float");
     cmd.add("m", "minclustersize", "Minimum Cluster Size", "integer");
     cmd.parse(argc, argv);
     const double fragmentMean = cmd.real("fragmentmean"), fragmentStdDev = cmd.real("fragmentstddev"), precision = cmd.real("precision");

@@ -391,22 +391,24 @@ inline int pack_id(int index, int end) { return (int)(((uint32_t)index & 0x7FFFF
 // ---------------------------------------------------------------------------------------------
 class CmdLine {
 public:
-    struct Arg { std::string flag, name, desc, type; std::string value; bool set = false; bool required = true; };
+    struct Arg { std::string flag, name, desc, type; std::string value; bool set = false; bool required = true; std::string kind; };
     CmdLine(std::string message, std::string version = "none") : message_(std::move(message)), version_(std::move(version)) {}
-    void add(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type)
+    // type: what the usage text shows ("string", "integer", "float", ...: TCLAP's type description, free text in the
+    // reference); kind: how the value is checked — "int", "float" or "string" (default: by the type text)
+    void add(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type, const std::string& kind = "")
     {
-        args_.push_back({flag, name, desc, type, "", false, true});
+        args_.push_back({flag, name, desc, type, "", false, true, kind.empty() ? kind_of(type) : kind});
     }
     // an argument that may be left out (tclap ValueArg with req = false): keeps its default then
     void add_optional(const std::string& flag, const std::string& name, const std::string& desc, const std::string& type,
                       const std::string& default_value)
     {
-        args_.push_back({flag, name, desc, type, default_value, false, false});
+        args_.push_back({flag, name, desc, type, default_value, false, false, kind_of(type)});
     }
     // a switch without a value (tclap SwitchArg, long form only when flag is empty): is_set(name) tells whether it was given
     void add_switch(const std::string& flag, const std::string& name, const std::string& desc)
     {
-        args_.push_back({flag, name, desc, "switch", "", false, false});
+        args_.push_back({flag, name, desc, "switch", "", false, false, "switch"});
     }
     bool is_set(const std::string& name) const { return get(name).set; }
     void parse(int argc, char** argv)
@@ -426,19 +428,18 @@ public:
             if (i + 1 >= argc) fail("Argument: " + id(*a), "Missing a value for this argument!");
             a->value = argv[++i];
             a->set = true;
-            if (a->type == "integer" || a->type == "int") { int v; if (!strict_int(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
-            if (a->type == "float") { double v; if (!strict_double(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
+            if (a->kind == "int") { int v; if (!strict_int(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
+            if (a->kind == "float") { double v; if (!strict_double(a->value, v)) fail("Argument: " + id(*a), "Couldn't read argument value from string '" + a->value + "'"); }
         }
-        std::string missing;
         for (const Arg& a : args_)
-            if (!a.set && a.required) missing += (missing.empty() ? "" : ", ") + a.name;
-        if (!missing.empty()) fail("", "Required arguments missing: " + missing);
+            if (!a.set && a.required) fail(" ", "One or more required arguments missing!");      // the vendored TCLAP's text and its one-space argument id
     }
     std::string str(const std::string& name) const { return get(name).value; }
     int integer(const std::string& name) const { int v = 0; strict_int(get(name).value, v); return v; }
     double real(const std::string& name) const { double v = 0; strict_double(get(name).value, v); return v; }
 
 private:
+    static std::string kind_of(const std::string& type) { return (type == "integer" || type == "int") ? "int" : (type == "float" || type == "double") ? "float" : "string"; }
     static bool strict_int(const std::string& s, int& v)
     {
         std::istringstream is(s);
@@ -464,38 +465,77 @@ private:
             if (a.name == name) return a;
         die("internal error: unknown argument " + name);
     }
+    // The vendored TCLAP (include/tclap of the reference) keeps its arguments in a list it pushes to the FRONT of, so the
+    // usage texts name them in reverse order of definition, the built-in --, --version, -h (defined first) last; the program
+    // name is followed by two spaces (oracle/tclap_ref.cpp runs that library; tests/test_cli_ref.py compares).
     void short_usage(std::ostream& os) const
     {
-        os << "   " << prog_;
-        for (const Arg& a : args_) {
-            if (a.type == "switch") { os << " [" << (a.flag.empty() ? "--" + a.name : "-" + a.flag) << "]"; continue; }
-            os << (a.required ? " -" : " [-") << a.flag << " <" << a.type << ">" << (a.required ? "" : "]");
+        std::string line = prog_ + " ";
+        for (auto it = args_.rbegin(); it != args_.rend(); ++it) {
+            const Arg& a = *it;
+            if (a.type == "switch") { line += " [" + (a.flag.empty() ? "--" + a.name : "-" + a.flag) + "]"; continue; }
+            line += (a.required ? " -" : " [-") + a.flag + " <" + a.type + ">" + (a.required ? "" : "]");
         }
-        os << " [--] [--version] [-h]" << std::endl;
+        line += " [--] [--version] [-h]";
+        space_print(os, line, 3, std::min<int>((int)prog_.size() + 2, 75 / 2));
+    }
+    // TCLAP's line folding (StdOutput::spacePrint with its width of 75): a text that does not fit is cut into lines of at most
+    // 75 - indent characters, each cut moved back to the nearest position in front of a blank, comma or bar (a word longer than
+    // a line is cut where the line ends; a newline in the text ends a line early); the first line is indented by `indent`, the
+    // following ones by `indent + second` and that much shorter; blanks at the start of a continuation line are dropped.
+    static void space_print(std::ostream& os, const std::string& s, int indent, int second)
+    {
+        const int len = (int)s.size(), width = 75;
+        if (len + indent <= width) { os << std::string((size_t)indent, ' ') << s << std::endl; return; }
+        int allowed = width - indent, start = 0;
+        auto at = [&](int k) { return k >= 0 && k < len ? s[(size_t)k] : '\0'; };
+        while (start < len) {
+            int n = std::min(len - start, allowed);
+            if (n == allowed)
+                while (n >= 0 && at(start + n) != ' ' && at(start + n) != ',' && at(start + n) != '|') --n;
+            if (n <= 0) n = allowed;
+            for (int i = 0; i < n; ++i)
+                if (at(start + i) == '\n') n = i + 1;
+            os << std::string((size_t)indent, ' ');
+            if (start == 0) { indent += second; allowed -= second; }
+            os << s.substr((size_t)start, (size_t)n) << std::endl;
+            while (start < len && at(start + n) == ' ') ++start;
+            start += n;
+        }
     }
     void usage(std::ostream& os) const
     {
         os << std::endl << "USAGE: " << std::endl << std::endl;
         short_usage(os);
         os << std::endl << std::endl << "Where: " << std::endl << std::endl;
-        for (const Arg& a : args_) {
-            if (a.type == "switch") {
-                os << "   " << (a.flag.empty() ? "" : "-" + a.flag + ",  ") << "--" << a.name << std::endl << "     " << a.desc << std::endl << std::endl;
-                continue;
-            }
-            os << "   -" << a.flag << " <" << a.type << ">,  --" << a.name << " <" << a.type << ">" << std::endl
-               << "     " << (a.required ? "(required)  " : "") << a.desc << std::endl << std::endl;
+        for (auto it = args_.rbegin(); it != args_.rend(); ++it) {
+            const Arg& a = *it;
+            if (a.type == "switch") space_print(os, (a.flag.empty() ? std::string() : "-" + a.flag + ",  ") + "--" + a.name, 3, 3);
+            else space_print(os, "-" + a.flag + " <" + a.type + ">,  --" + a.name + " <" + a.type + ">", 3, 3);
+            space_print(os, (a.required ? "(required)  " : "") + a.desc, 5, 0);
+            os << std::endl;
         }
-        os << "   --,  --ignore_rest" << std::endl << "     Ignores the rest of the labeled arguments following this flag." << std::endl << std::endl
-           << "   --version" << std::endl << "     Displays version information and exits." << std::endl << std::endl
-           << "   -h,  --help" << std::endl << "     Displays usage information and exits." << std::endl << std::endl << std::endl
-           << "   " << message_ << std::endl << std::endl;
+        space_print(os, "--,  --ignore_rest", 3, 3);
+        space_print(os, "Ignores the rest of the labeled arguments following this flag.", 5, 0);
+        os << std::endl;
+        space_print(os, "--version", 3, 3);
+        space_print(os, "Displays version information and exits.", 5, 0);
+        os << std::endl;
+        space_print(os, "-h,  --help", 3, 3);
+        space_print(os, "Displays usage information and exits.", 5, 0);
+        os << std::endl << std::endl;
+        space_print(os, message_, 3, 0);
+        os << std::endl;
     }
+    // StdOutput::failure of the vendored TCLAP: the message on stderr — with the brief usage line itself on STDOUT, as that
+    // version prints it — then exit(1)
     [[noreturn]] void fail(const std::string& arg_id, const std::string& error) const
     {
         std::cerr << "PARSE ERROR: " << arg_id << std::endl << "             " << error << std::endl << std::endl;
         std::cerr << "Brief USAGE: " << std::endl;
-        short_usage(std::cerr);
+        std::cerr.flush();
+        short_usage(std::cout);
+        std::cout.flush();
         std::cerr << std::endl << "For complete USAGE and HELP type: " << std::endl << "   " << prog_ << " --help" << std::endl << std::endl;
         std::exit(1);
     }
@@ -553,7 +593,9 @@ public:
         long long beg = start, e = end;       // the reference formats "name:start-end" and parses it back with atoi
         if (beg > 0) --beg;
         if (beg >= en.len) beg = en.len;
-        if (e >= en.len) e = en.len;
+        // faidx.c:337 compares the int `end` with the unsigned field val.len: a negative end (a window wholly in front of the
+        // sequence, "name:1--12") turns into a huge unsigned number and is clipped to the sequence END (tests/test_faidx_ref.py)
+        if (e < 0 || e >= en.len) e = en.len;
         if (beg > e) beg = e;
         sequence.clear();
         if (e > beg && en.line_blen > 0) {
@@ -583,8 +625,8 @@ private:
     struct Entry { long long len = 0, offset = 0; int line_blen = 0, line_len = 0; };
     static void build(const std::string& fasta, const std::string& fai)
     {
-        // fai_build (faidx.c:103-170) over the mapped file: per sequence its name, length (graph characters), the offset of
-        // its first base and the byte / base length of its first line
+        // fai_build_core (faidx.c:62-139), character by character over the mapped file, with its state machine (1 = just after
+        // a header, 0 = inside a sequence, 2 = a shorter line was seen, 3 = a line after that) and its refusals
         MappedText in;
         {
             const int fd = open(fasta.c_str(), O_RDONLY);
@@ -592,38 +634,55 @@ private:
             close(fd);
         }
         in.load(fasta, "[fai_build] fail to open the FASTA file ");
+        std::string text, name;
+        long long len = -1, offset = 0;
+        int line_len = -1, line_blen = -1, state = 0;
+        auto insert = [&]() { text += name + "\t" + std::to_string(len) + "\t" + std::to_string(offset) + "\t" + std::to_string(line_blen) + "\t" + std::to_string(line_len) + "\n"; };
+        const size_t n = in.size();
+        size_t pos = 0;
+        while (pos < n) {
+            char c = in[pos++];
+            if (c == '\n') {                                   // an empty line
+                if (state == 1) { offset = (long long)pos; continue; }
+                if ((state == 0 && len < 0) || state == 2) continue;
+            }
+            if (c == '>') {                                    // header
+                if (len >= 0) insert();
+                name.clear();
+                bool more = false;
+                while (pos < n) {
+                    c = in[pos++];
+                    if (std::isspace((unsigned char)c)) { more = true; break; }
+                    name += c;
+                }
+                if (!more) die("[fai_build_core] the last entry has no sequence");
+                if (c != '\n') while (pos < n && in[pos++] != '\n') {}
+                state = 1;
+                len = 0;
+                offset = (long long)pos;
+            } else {
+                if (state == 3) die("[fai_build_core] inlined empty line is not allowed in sequence '" + name + "'.");
+                if (state == 2) state = 3;
+                int l1 = 0, l2 = 0;
+                for (;;) {
+                    ++l1;
+                    if (std::isgraph((unsigned char)c)) ++l2;
+                    if (pos >= n) break;
+                    c = in[pos++];
+                    if (c == '\n') break;
+                }
+                if (state == 3 && l2) die("[fai_build_core] different line length in sequence '" + name + "'.");
+                ++l1;
+                len += l2;
+                if (l2 >= 0x10000) die("[fai_build_core] line length exceeds 65535 in sequence '" + name + "'.");
+                if (state == 1) { line_len = l1; line_blen = l2; state = 0; }
+                else if (state == 0 && (l1 != line_len || l2 != line_blen)) state = 2;
+            }
+        }
+        insert();                                              // (as the reference: also for a file without any header)
         std::ofstream out(fai.c_str(), std::ios::binary);
         if (!out.good()) die("[fai_build] fail to write FASTA index " + fai);
-        std::string name;
-        long long len = 0, offset = 0;
-        int line_blen = 0, line_len = 0;
-        bool have = false, first_line = true;
-        auto flush = [&]() { if (have) out << name << "\t" << len << "\t" << offset << "\t" << line_blen << "\t" << line_len << "\n"; };
-        for (size_t pos = 0; pos < in.size();) {
-            const size_t e = in.line_end(pos);
-            const bool nl = e > pos && in[e - 1] == '\n';
-            const char* line = in.data() + pos;
-            const size_t n = nl ? e - 1 - pos : e - pos;
-            const long long raw = (long long)n + 1;                      // a last line without a newline counts as if it had one
-            if (n > 0 && line[0] == '>') {
-                flush();
-                size_t k = 1;
-                while (k < n && !std::isspace((unsigned char)line[k])) ++k;
-                name.assign(line + 1, k - 1);
-                have = true;
-                len = 0;
-                offset = (long long)pos + raw;
-                first_line = true;
-                line_blen = line_len = 0;
-            } else if (have) {
-                int graph = 0;
-                for (size_t k = 0; k < n; ++k) graph += std::isgraph((unsigned char)line[k]) ? 1 : 0;
-                if (first_line) { line_blen = graph; line_len = (int)raw; first_line = false; }
-                len += graph;
-            }
-            pos = e;
-        }
-        flush();
+        out << text;
     }
     std::unordered_map<std::string, Entry> index_;
     int fd_ = -1;

@@ -19,9 +19,9 @@ int main(int argc, char* argv[])
     cmd.add("x", "maxread", "Maximum Read Length", "integer");
     cmd.add("r", "regions", "Fusion Regions Filename", "string");
     cmd.add("a", "align", "Split Alignments Filename", "string");
-    cmd.add("q", "seq", "Sequence Predictions Filename", "string");
-    cmd.add("b", "break", "Breakpoint Predictions Filename", "string");
-    cmd.add("p", "predalign", "Predicted Alignments Filename", "string");
+    cmd.add("q", "seq", "Sequences Filename", "string");
+    cmd.add("b", "break", "Break Positions Filename", "string");
+    cmd.add("p", "predalign", "Prediction Split Alignments Filename", "string");
     cmd.parse(argc, argv);
 
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
