@@ -312,14 +312,16 @@ int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t e
         for (int f : forder) flip[f] = (uint8_t)(pos_in_order++ & 1);
     }
     static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
+    // DEFUSE_DSA_NO_TIGHTEN=1: no per-pair score bound, pruning against minScore alone (round 1's behaviour)
+    static const bool no_tighten = [] { const char* e = getenv("DEFUSE_DSA_NO_TIGHTEN"); return e && atoi(e) != 0; }();
     HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPC(hipMemcpyAsync(d_tiles.p, flip.data(), (size_t)nf, hipMemcpyHostToDevice, st));        // the tile votes were read above: the buffer is free
     HIPC(d_rank.reserve((size_t)n));
     if (no_rank)
         hipLaunchKernelGGL(k_rank_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_rank.p);
     else
-        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p, pairs,
-                           d_stat.p, d_tiles.p, d_rank.p);
+        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
+                           ctx->d_pairs.p + begin, d_stat.p, d_tiles.p, d_rank.p, no_tighten ? 0 : 1);
     hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p, d_rank.p,
                        ctx->d_pairs_sweep.p + begin, ctx->d_orig.p + begin);
     HIPC(hipStreamSynchronize(st));             // new_start is reused by the next chunk
@@ -820,7 +822,10 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     if (ref_bytes_len) HIPC(hipMemcpyAsync(ctx->d_ref.p, ref_bytes, ref_bytes_len, hipMemcpyHostToDevice, st));
     if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
     if (n_fusions) HIPC(hipMemcpyAsync(ctx->d_fusions.p, fusions, n_fusions * sizeof(dsa_fusion), hipMemcpyHostToDevice, st));
-    if (n_pairs) HIPC(hipMemcpyAsync(ctx->d_pairs.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+    if (n_pairs) {
+        HIPC(hipMemcpyAsync(ctx->d_pairs.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_clear_pad, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs);
+    }
     std::vector<int32_t> tab(lqmax + 1);
     for (int l = 0; l <= lqmax; ++l) tab[l] = min_score_for(l);
     HIPC(ctx->d_min_score.reserve(tab.size()));

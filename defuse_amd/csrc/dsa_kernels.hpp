@@ -114,6 +114,9 @@ __device__ __forceinline__ uint32_t min3u(uint32_t x)   // per field min(x, 3)
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2u, x), three));
 }
 
+// lower bound of the pair's final score found at upload (k_rank_in_fusion), 0 = none
+__device__ __forceinline__ int pair_bound(const dsa_pair& pr) { return (int)pr.pad_[0] | ((int)pr.pad_[1] << 8); }
+
 struct WaveInfo {
     int32_t lq_max;        // longest read among the wave's pairs
     int32_t nch_max;       // most tiles among the wave's pairs (either matrix)
@@ -352,13 +355,43 @@ __global__ __launch_bounds__(64) void k_probe_wave(const uint8_t* __restrict__ r
 // small-a* end).  Fusions alternate the direction (flip) so that a wave straddling two fusions continues in the same range.
 // One workgroup per fusion; rank[p - first] = position of pair p inside the fusion's run.  Fusions with more than
 // RANK_MAX pairs or windows of 1000 bases and more keep the caller's order.
+//
+// The same lookups give every pair a LOWER BOUND of its final score, which tightens the exact pruning: with
+// the read's first 11-mers on a diagonal d1 of window 0 and its last ones on a diagonal d2 of window 1, the ungapped paths
+// along them are valid DP paths (free start in the reference), so m1(a) >= P1(a) = sum_{j<a} c1(j) and m2(Lq-a) >= P2(a) =
+// sum_{j>=a} c2(j) (c = +2 match / -1 mismatch along the diagonal), and the best split scores at least
+// T' = max_a P1(a) + P2(a) over the a where both sides reach the anchor minimum 8.  Only splits of the final maximum
+// s* >= T' are ever emitted, so "cannot reach minScore" becomes "cannot reach max(minScore, T')" with the same proof;
+// for a clean read T' is within a few points of 2 Lq and a tile without a real alignment dies after a handful of rows
+// instead of twenty.  T' travels to the fill kernels in the two padding bytes of the DEVICE copy of dsa_pair (0 = no bound).
 constexpr int RANK_MAX = 2048, RANK_K = 11, RANK_HASH = 2048;
-__global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
-                                                        const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
-                                                        const FusionStat* __restrict__ st, const uint8_t* __restrict__ flip,
-                                                        int32_t* __restrict__ rank)
+__device__ __forceinline__ void rank_table_insert(uint32_t* table, uint32_t km, int x)
 {
-    __shared__ uint32_t table[RANK_HASH];          // (11-mer << 10) | first position, ~0 = empty
+    const uint32_t val = (km << 10) | (uint32_t)x;
+    uint32_t h = (km * 2654435761u) >> 21;                     // 11 bits
+    for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
+        const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, val);
+        if (old == 0xFFFFFFFFu) break;
+        if ((old >> 10) == km) { atomicMin(&table[h], val); break; }     // same 11-mer: the smallest position stays
+    }
+}
+__device__ __forceinline__ int rank_table_find(const uint32_t* table, uint32_t km)
+{
+    uint32_t h = (km * 2654435761u) >> 21;
+    for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
+        const uint32_t e = table[h];
+        if (e == 0xFFFFFFFFu) return -1;
+        if ((e >> 10) == km) return (int)(e & 1023u);
+    }
+    return -1;
+}
+__global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
+                                                        const uint8_t* __restrict__ read_bytes, dsa_pair* __restrict__ pairs,
+                                                        const FusionStat* __restrict__ st, const uint8_t* __restrict__ flip,
+                                                        int32_t* __restrict__ rank, int tighten)
+{
+    __shared__ uint32_t table[RANK_HASH];          // window 0: (11-mer << 10) | first position, ~0 = empty
+    __shared__ uint32_t table1[RANK_HASH];         // window 1 likewise
     __shared__ uint32_t keys[RANK_MAX];            // (sort key << 16) | index inside the fusion
     const int f = blockIdx.x;
     const FusionStat s = st[f];
@@ -367,30 +400,34 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
     const int64_t p0 = s.first;
     const dsa_fusion fu = fusions[f];
     if (n > RANK_MAX || n < 2 || fu.ref0_len >= 1000 || fu.ref0_len < RANK_K) {
-        for (int k = threadIdx.x; k < n; k += blockDim.x) rank[p0 + k] = k;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) { rank[p0 + k] = k; pairs[p0 + k].pad_[0] = 0; pairs[p0 + k].pad_[1] = 0; }
         return;
     }
     auto code = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; };
-    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) table[k] = 0xFFFFFFFFu;
+    const bool bound = tighten != 0 && fu.ref1_len >= RANK_K && fu.ref1_len < 1000;
+    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) { table[k] = 0xFFFFFFFFu; table1[k] = 0xFFFFFFFFu; }
     __syncthreads();
     const uint8_t* r0 = ref_bytes + fu.ref0_off;
-    for (int x = threadIdx.x; x + RANK_K <= fu.ref0_len; x += blockDim.x) {
-        uint32_t km = 0;
+    const uint8_t* r1 = ref_bytes + fu.ref1_off;
+    auto kmer_at = [&](const uint8_t* p, uint32_t& km) {
+        km = 0;
         bool ok = true;
         for (int k = 0; k < RANK_K; ++k) {
-            const int c = code(r0[x + k]);
+            const int c = code(p[k]);
             ok = ok && c >= 0;
             km = (km << 2) | (uint32_t)(c & 3);
         }
-        if (!ok) continue;
-        const uint32_t val = (km << 10) | (uint32_t)x;
-        uint32_t h = (km * 2654435761u) >> 21;                     // 11 bits
-        for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
-            const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, val);
-            if (old == 0xFFFFFFFFu) break;
-            if ((old >> 10) == km) { atomicMin(&table[h], val); break; }     // same 11-mer: the smallest position stays
-        }
+        return ok;
+    };
+    for (int x = threadIdx.x; x + RANK_K <= fu.ref0_len; x += blockDim.x) {
+        uint32_t km;
+        if (kmer_at(r0 + x, km)) rank_table_insert(table, km, x);
     }
+    if (bound)
+        for (int x = threadIdx.x; x + RANK_K <= fu.ref1_len; x += blockDim.x) {
+            uint32_t km;
+            if (kmer_at(r1 + x, km)) rank_table_insert(table1, km, x);
+        }
     __syncthreads();
     int npad = 1;
     while (npad < n) npad <<= 1;
@@ -400,22 +437,44 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             const dsa_pair pr = pairs[p0 + k];
             const uint8_t* rd = read_bytes + pr.read_off;
             int diag = 1023;                                      // no 11-mer of window 0: junction in the first bases
-            for (int off = 0; off <= 12 && off + RANK_K <= pr.read_len && diag == 1023; off += 4) {
-                uint32_t km = 0;
-                bool ok = true;
-                for (int q = 0; q < RANK_K; ++q) {
-                    const int c = code(rd[off + q]);
-                    ok = ok && c >= 0;
-                    km = (km << 2) | (uint32_t)(c & 3);
+            const int lq = pr.read_len;
+            int d1 = 0, d2 = 0;
+            bool have1 = false, have2 = false;
+            for (int off = 0; off <= 12 && off + RANK_K <= lq && !have1; off += 4) {
+                uint32_t km;
+                if (!kmer_at(rd + off, km)) continue;
+                const int x = rank_table_find(table, km);
+                if (x >= 0) { d1 = x - off; have1 = true; diag = min(1022, max(0, d1 + 16)); }
+            }
+            uint16_t tprime = 0;
+            if (bound && have1) {
+                for (int off = 0; off <= 12 && off + RANK_K <= lq && !have2; off += 4) {     // the read's last 11-mers in window 1
+                    uint32_t km;
+                    const int at = lq - RANK_K - off;
+                    if (!kmer_at(rd + at, km)) continue;
+                    const int y = rank_table_find(table1, km);
+                    if (y >= 0) { d2 = y - at; have2 = true; }
                 }
-                if (!ok) continue;
-                uint32_t h = (km * 2654435761u) >> 21;
-                for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
-                    const uint32_t e = table[h];
-                    if (e == 0xFFFFFFFFu) break;
-                    if ((e >> 10) == km) { diag = min(1022, max(0, (int)(e & 1023u) - off + 16)); break; }
+                // read base j lies on window 0 position j + d1 (prefix side) and on window 1 position j + d2 (suffix side)
+                if (have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len) {
+                    const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
+                    const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
+                    int suf = 0;                                       // P2(a_lo) = sum over j >= a_lo of c2(j)
+                    for (int j = a_lo; j < lq; ++j) suf += rd[j] == r1[j + d2] ? DSA_MATCH : DSA_MISMATCH;
+                    int pre = 0, best = 0;                             // P1(a)
+                    for (int j = 0; j < a_lo && j < a_hi; ++j) pre += rd[j] == r0[j + d1] ? DSA_MATCH : DSA_MISMATCH;
+                    for (int a = a_lo; a <= a_hi; ++a) {
+                        if (pre >= DSA_MIN_SPLIT && suf >= DSA_MIN_SPLIT) best = max(best, pre + suf);
+                        if (a < a_hi && a < lq) {
+                            pre += rd[a] == r0[a + d1] ? DSA_MATCH : DSA_MISMATCH;
+                            suf -= rd[a] == r1[a + d2] ? DSA_MATCH : DSA_MISMATCH;
+                        }
+                    }
+                    tprime = (uint16_t)min(best, 65535);
                 }
             }
+            pairs[p0 + k].pad_[0] = (uint8_t)(tprime & 0xFF);
+            pairs[p0 + k].pad_[1] = (uint8_t)(tprime >> 8);
             const int kk = flip[f] ? 1023 - diag : diag;
             key = ((uint32_t)kk << 16) | (uint32_t)k;
             if (n > 65535) key = 0;                               // (cannot happen: n <= RANK_MAX)
@@ -437,6 +496,16 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             __syncthreads();
         }
     for (int r = threadIdx.x; r < n; r += blockDim.x) rank[p0 + (keys[r] & 0xFFFFu)] = r;
+}
+
+// the padding bytes of the device copy of the pairs carry the per-pair score bound (k_rank_in_fusion); whatever the caller
+// had in them is cleared at upload
+__global__ void k_clear_pad(dsa_pair* __restrict__ pairs, int64_t n_pairs)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    pairs[p].pad_[0] = 0;
+    pairs[p].pad_[1] = 0;
 }
 
 // the caller's order inside every fusion
@@ -1387,7 +1456,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         int lq_lane = 0, slack = 0;
         if ((int64_t)w * WAVE + lane < g.n_pairs) {
             lq_lane = pairs[p].read_len;
-            slack = 2 * lq_lane - min_score_tab[lq_lane];
+            slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pairs[p]));
         }
         auto wave_max = [](int v) {
 #pragma unroll
@@ -1479,7 +1548,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
         f = pairs[min(p, g.n_pairs - 1)].fusion_idx;
         if (p < g.n_pairs) {
             lq_lane = pairs[p].read_len;
-            slack = 2 * lq_lane - min_score_tab[lq_lane];
+            slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pairs[p]));
         }
     }
     auto wave_max = [](int v) {
