@@ -429,43 +429,82 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             if (kmer_at(r1 + x, km)) rank_table_insert(table1, km, x);
         }
     __syncthreads();
+    // (A) per read: the diagonals of its first 11-mers in window 0 (d1) and of its last ones in window 1 (d2); reads that have
+    // both vote on d2 - d1, which is the same for every read of the fusion that spans its junction (both are "junction minus
+    // read split")
+    __shared__ short s_d1[RANK_MAX], s_d2[RANK_MAX];
+    __shared__ uint8_t s_have[RANK_MAX];
+    __shared__ int s_votes[RANK_HASH];             // histogram of d2 - d1 + 1024
+    __shared__ int s_delta, s_delta_votes;
+    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) s_votes[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const dsa_pair pr = pairs[p0 + k];
+        const uint8_t* rd = read_bytes + pr.read_off;
+        const int lq = pr.read_len;
+        int d1 = 0, d2 = 0;
+        bool have1 = false, have2 = false;
+        for (int off = 0; off <= 12 && off + RANK_K <= lq && !have1; off += 4) {
+            uint32_t km;
+            if (!kmer_at(rd + off, km)) continue;
+            const int x = rank_table_find(table, km);
+            if (x >= 0) { d1 = x - off; have1 = true; }
+        }
+        if (bound)
+            for (int off = 0; off <= 12 && off + RANK_K <= lq && !have2; off += 4) {     // the read's last 11-mers in window 1
+                uint32_t km;
+                const int at = lq - RANK_K - off;
+                if (!kmer_at(rd + at, km)) continue;
+                const int y = rank_table_find(table1, km);
+                if (y >= 0) { d2 = y - at; have2 = true; }
+            }
+        s_d1[k] = (short)d1;
+        s_d2[k] = (short)d2;
+        s_have[k] = (uint8_t)((have1 ? 1 : 0) | (have2 ? 2 : 0));
+        if (have1 && have2) {
+            const int v = d2 - d1 + 1024;
+            if (v >= 0 && v < RANK_HASH) atomicAdd(&s_votes[v], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                         // the mode of the votes; ties to the smaller difference (deterministic)
+        int best = 0, arg = 0;
+        for (int v = 0; v < RANK_HASH; ++v)
+            if (s_votes[v] > best) { best = s_votes[v]; arg = v; }
+        s_delta = arg - 1024;
+        s_delta_votes = best;
+    }
+    __syncthreads();
     int npad = 1;
     while (npad < n) npad <<= 1;
     for (int k = threadIdx.x; k < npad; k += blockDim.x) {
-        uint32_t key = 0xFFFFu;                                   // padding sorts behind everything
+        uint32_t key = 0xFFFF0000u | (uint32_t)k;                 // padding sorts behind everything
         if (k < n) {
             const dsa_pair pr = pairs[p0 + k];
             const uint8_t* rd = read_bytes + pr.read_off;
-            int diag = 1023;                                      // no 11-mer of window 0: junction in the first bases
             const int lq = pr.read_len;
-            int d1 = 0, d2 = 0;
-            bool have1 = false, have2 = false;
-            for (int off = 0; off <= 12 && off + RANK_K <= lq && !have1; off += 4) {
-                uint32_t km;
-                if (!kmer_at(rd + off, km)) continue;
-                const int x = rank_table_find(table, km);
-                if (x >= 0) { d1 = x - off; have1 = true; diag = min(1022, max(0, d1 + 16)); }
+            int d1 = s_d1[k], d2 = s_d2[k];
+            bool have1 = (s_have[k] & 1) != 0, have2 = (s_have[k] & 2) != 0;
+            // (B) a read with one side only (its junction lies within a few bases of one end) takes the other diagonal from
+            // the fusion's vote; any pair of diagonals gives a VALID bound below, a wrong guess only a weak one
+            if (s_delta_votes > 0) {
+                if (have1 && !have2) { d2 = d1 + s_delta; have2 = true; }
+                else if (have2 && !have1) { d1 = d2 - s_delta; have1 = true; }
             }
+            const int diag = have1 ? min(1022, max(0, d1 + 16)) : 1023;      // no diagonal at all: sorts to the small-a* end
             uint16_t tprime = 0;
-            if (bound && have1) {
-                for (int off = 0; off <= 12 && off + RANK_K <= lq && !have2; off += 4) {     // the read's last 11-mers in window 1
-                    uint32_t km;
-                    const int at = lq - RANK_K - off;
-                    if (!kmer_at(rd + at, km)) continue;
-                    const int y = rank_table_find(table1, km);
-                    if (y >= 0) { d2 = y - at; have2 = true; }
-                }
-                // read base j lies on window 0 position j + d1 (prefix side) and on window 1 position j + d2 (suffix side)
-                if (have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len) {
-                    const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
-                    const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
-                    int suf = 0;                                       // P2(a_lo) = sum over j >= a_lo of c2(j)
+            // (C) read base j lies on window 0 position j + d1 (prefix side) and on window 1 position j + d2 (suffix side)
+            if (bound && have1 && have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len && lq > 0) {
+                const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
+                const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
+                if (a_lo <= a_hi) {
+                    int suf = 0;                                   // P2(a_lo) = sum over j >= a_lo of c2(j)
                     for (int j = a_lo; j < lq; ++j) suf += rd[j] == r1[j + d2] ? DSA_MATCH : DSA_MISMATCH;
-                    int pre = 0, best = 0;                             // P1(a)
-                    for (int j = 0; j < a_lo && j < a_hi; ++j) pre += rd[j] == r0[j + d1] ? DSA_MATCH : DSA_MISMATCH;
+                    int pre = 0, best = 0;                         // P1(a)
+                    for (int j = 0; j < a_lo; ++j) pre += rd[j] == r0[j + d1] ? DSA_MATCH : DSA_MISMATCH;
                     for (int a = a_lo; a <= a_hi; ++a) {
                         if (pre >= DSA_MIN_SPLIT && suf >= DSA_MIN_SPLIT) best = max(best, pre + suf);
-                        if (a < a_hi && a < lq) {
+                        if (a < a_hi) {                            // a < lq here: a_hi <= lq
                             pre += rd[a] == r0[a + d1] ? DSA_MATCH : DSA_MISMATCH;
                             suf -= rd[a] == r1[a + d2] ? DSA_MATCH : DSA_MISMATCH;
                         }
@@ -477,9 +516,6 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             pairs[p0 + k].pad_[1] = (uint8_t)(tprime >> 8);
             const int kk = flip[f] ? 1023 - diag : diag;
             key = ((uint32_t)kk << 16) | (uint32_t)k;
-            if (n > 65535) key = 0;                               // (cannot happen: n <= RANK_MAX)
-        } else {
-            key = 0xFFFF0000u | (uint32_t)k;
         }
         keys[k] = key;
     }
