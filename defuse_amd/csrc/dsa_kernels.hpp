@@ -434,8 +434,22 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
     // read split")
     __shared__ short s_d1[RANK_MAX], s_d2[RANK_MAX];
     __shared__ uint8_t s_have[RANK_MAX];
-    __shared__ int s_votes[RANK_HASH];             // histogram of d2 - d1 + 1024
+    int* s_votes = reinterpret_cast<int*>(keys);   // histogram of d2 - d1 + 1024 (the sort keys are written after the vote)
     __shared__ int s_delta, s_delta_votes;
+    // the windows (< 1000 bytes each) and, when they fit, the reads of the fusion are staged in LDS: the bound's loops touch
+    // every read base twice and the windows along two diagonals
+    constexpr int READS_LDS = 24576;
+    __shared__ uint8_t s_win[2][1000];
+    __shared__ uint8_t s_reads[READS_LDS];
+    const int64_t read_base = pairs[p0].read_off;                  // staged only when the reads of the run are one contiguous block
+    const int64_t read_end = (int64_t)pairs[p0 + n - 1].read_off + pairs[p0 + n - 1].read_len;
+    const bool staged = bound && read_end - read_base > 0 && read_end - read_base <= READS_LDS;
+    if (bound) {
+        for (int k = threadIdx.x; k < fu.ref0_len; k += blockDim.x) s_win[0][k] = r0[k];
+        for (int k = threadIdx.x; k < fu.ref1_len; k += blockDim.x) s_win[1][k] = r1[k];
+        if (staged)
+            for (int64_t k = threadIdx.x; k < read_end - read_base; k += blockDim.x) s_reads[k] = read_bytes[read_base + k];
+    }
     for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) s_votes[k] = 0;
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
@@ -497,16 +511,22 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             if (bound && have1 && have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len && lq > 0) {
                 const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
                 const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
+                // the read is inside the staged block only if its bytes lie in [read_base, read_end) (reads of a run need not be in order)
+                const bool in_lds = staged && pr.read_off >= read_base && (int64_t)pr.read_off + lq <= read_end;
+                const uint8_t* rb = in_lds ? s_reads + (pr.read_off - read_base) : rd;
+                const uint8_t* w0 = s_win[0] + d1;                 // w0[j] = window 0 base under read base j
+                const uint8_t* w1 = s_win[1] + d2;
                 if (a_lo <= a_hi) {
                     int suf = 0;                                   // P2(a_lo) = sum over j >= a_lo of c2(j)
-                    for (int j = a_lo; j < lq; ++j) suf += rd[j] == r1[j + d2] ? DSA_MATCH : DSA_MISMATCH;
+                    for (int j = a_lo; j < lq; ++j) suf += rb[j] == w1[j] ? DSA_MATCH : DSA_MISMATCH;
                     int pre = 0, best = 0;                         // P1(a)
-                    for (int j = 0; j < a_lo; ++j) pre += rd[j] == r0[j + d1] ? DSA_MATCH : DSA_MISMATCH;
+                    for (int j = 0; j < a_lo; ++j) pre += rb[j] == w0[j] ? DSA_MATCH : DSA_MISMATCH;
                     for (int a = a_lo; a <= a_hi; ++a) {
                         if (pre >= DSA_MIN_SPLIT && suf >= DSA_MIN_SPLIT) best = max(best, pre + suf);
                         if (a < a_hi) {                            // a < lq here: a_hi <= lq
-                            pre += rd[a] == r0[a + d1] ? DSA_MATCH : DSA_MISMATCH;
-                            suf -= rd[a] == r1[a + d2] ? DSA_MATCH : DSA_MISMATCH;
+                            const uint8_t c = rb[a];
+                            pre += c == w0[a] ? DSA_MATCH : DSA_MISMATCH;
+                            suf -= c == w1[a] ? DSA_MATCH : DSA_MISMATCH;
                         }
                     }
                     tprime = (uint16_t)min(best, 65535);
