@@ -481,12 +481,22 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {                         // the mode of the votes; ties to the smaller difference (deterministic)
-        int best = 0, arg = 0;
-        for (int v = 0; v < RANK_HASH; ++v)
-            if (s_votes[v] > best) { best = s_votes[v]; arg = v; }
-        s_delta = arg - 1024;
-        s_delta_votes = best;
+    {   // the mode of the votes; ties to the smaller difference (deterministic): every thread scans its share, then a wave
+        // and a workgroup maximum over (count, -difference)
+        unsigned mine = 0;
+        for (int v = threadIdx.x; v < RANK_HASH; v += blockDim.x) {
+            const unsigned c = (unsigned)s_votes[v];
+            if (c) mine = max(mine, (c << 12) | (unsigned)(4095 - v));
+        }
+        for (int d = 32; d >= 1; d >>= 1) mine = max(mine, (unsigned)__shfl_xor((int)mine, d, 64));
+        __shared__ unsigned s_best[4];
+        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned b = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
+            s_delta_votes = (int)(b >> 12);
+            s_delta = b ? (4095 - (int)(b & 4095u)) - 1024 : 0;
+        }
     }
     __syncthreads();
     int npad = 1;
