@@ -320,7 +320,7 @@ int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t e
     if (no_rank)
         hipLaunchKernelGGL(k_rank_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_rank.p);
     else
-        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(256), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
+        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(RANK_THREADS), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
                            ctx->d_pairs.p + begin, d_stat.p, d_tiles.p, d_rank.p, no_tighten ? 0 : 1);
     hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p, d_rank.p,
                        ctx->d_pairs_sweep.p + begin, ctx->d_orig.p + begin);

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void k_probe_wave(const uint8_t* __restrict__ r
 // s* >= T' are ever emitted, so "cannot reach minScore" becomes "cannot reach max(minScore, T')" with the same proof;
 // for a clean read T' is within a few points of 2 Lq and a tile without a real alignment dies after a handful of rows
 // instead of twenty.  T' travels to the fill kernels in the two padding bytes of the DEVICE copy of dsa_pair (0 = no bound).
-constexpr int RANK_MAX = 2048, RANK_K = 11, RANK_HASH = 2048;
+constexpr int RANK_MAX = 2048, RANK_K = 11, RANK_HASH = 2048, RANK_THREADS = 128;
 __device__ __forceinline__ void rank_table_insert(uint32_t* table, uint32_t km, int x)
 {
     const uint32_t val = (km << 10) | (uint32_t)x;
@@ -385,7 +385,7 @@ __device__ __forceinline__ int rank_table_find(const uint32_t* table, uint32_t k
     }
     return -1;
 }
-__global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
+__global__ __launch_bounds__(RANK_THREADS) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
                                                         const uint8_t* __restrict__ read_bytes, dsa_pair* __restrict__ pairs,
                                                         const FusionStat* __restrict__ st, const uint8_t* __restrict__ flip,
                                                         int32_t* __restrict__ rank, int tighten)
@@ -436,19 +436,11 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
     __shared__ uint8_t s_have[RANK_MAX];
     int* s_votes = reinterpret_cast<int*>(keys);   // histogram of d2 - d1 + 1024 (the sort keys are written after the vote)
     __shared__ int s_delta, s_delta_votes;
-    // the windows (< 1000 bytes each) and, when they fit, the reads of the fusion are staged in LDS: the bound's loops touch
-    // every read base twice and the windows along two diagonals
-    constexpr int READS_LDS = 24576;
+    // the windows (< 1000 bytes each) are staged in LDS: the bound's loops walk them along two diagonals per read
     __shared__ uint8_t s_win[2][1000];
-    __shared__ uint8_t s_reads[READS_LDS];
-    const int64_t read_base = pairs[p0].read_off;                  // staged only when the reads of the run are one contiguous block
-    const int64_t read_end = (int64_t)pairs[p0 + n - 1].read_off + pairs[p0 + n - 1].read_len;
-    const bool staged = bound && read_end - read_base > 0 && read_end - read_base <= READS_LDS;
     if (bound) {
         for (int k = threadIdx.x; k < fu.ref0_len; k += blockDim.x) s_win[0][k] = r0[k];
         for (int k = threadIdx.x; k < fu.ref1_len; k += blockDim.x) s_win[1][k] = r1[k];
-        if (staged)
-            for (int64_t k = threadIdx.x; k < read_end - read_base; k += blockDim.x) s_reads[k] = read_bytes[read_base + k];
     }
     for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) s_votes[k] = 0;
     __syncthreads();
@@ -489,11 +481,12 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             if (c) mine = max(mine, (c << 12) | (unsigned)(4095 - v));
         }
         for (int d = 32; d >= 1; d >>= 1) mine = max(mine, (unsigned)__shfl_xor((int)mine, d, 64));
-        __shared__ unsigned s_best[4];
+        __shared__ unsigned s_best[RANK_THREADS / 64];
         if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned b = max(max(s_best[0], s_best[1]), max(s_best[2], s_best[3]));
+            unsigned b = 0;
+            for (int w = 0; w < RANK_THREADS / 64; ++w) b = max(b, s_best[w]);
             s_delta_votes = (int)(b >> 12);
             s_delta = b ? (4095 - (int)(b & 4095u)) - 1024 : 0;
         }
@@ -521,9 +514,7 @@ __global__ __launch_bounds__(256) void k_rank_in_fusion(const uint8_t* __restric
             if (bound && have1 && have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len && lq > 0) {
                 const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
                 const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
-                // the read is inside the staged block only if its bytes lie in [read_base, read_end) (reads of a run need not be in order)
-                const bool in_lds = staged && pr.read_off >= read_base && (int64_t)pr.read_off + lq <= read_end;
-                const uint8_t* rb = in_lds ? s_reads + (pr.read_off - read_base) : rd;
+                const uint8_t* rb = rd;
                 const uint8_t* w0 = s_win[0] + d1;                 // w0[j] = window 0 base under read base j
                 const uint8_t* w1 = s_win[1] + d2;
                 if (a_lo <= a_hi) {
