@@ -61,11 +61,15 @@ struct HostResult {            // pinned: filled by async copies at the end of a
 struct PipeLane {
     hipStream_t stream = nullptr;
     hipEvent_t ev[7] = {};      // 0 pack start, 4 pack end, 1 fill start, 2 fill end, 3 phase-1 end, 5 emit start, 6 emit end
+    hipStream_t aux = nullptr;  // the two emit kernels of a slice run side by side: fork to aux, join back
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     HostResult* host = nullptr;
     int slice = -1;             // slice whose phase 1 is in flight
     int64_t resident_upload = -1;   // the descriptors of (resident_upload, resident_slice) are on the device
     int resident_slice = -1;
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
+    bool emit_early = false;    // phase 1 already wrote the slice's records, into room for emit_cap of them
+    uint64_t emit_cap = 0;
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
@@ -75,7 +79,7 @@ struct PipeLane {
     DevBuf<int64_t> d_rec_count, d_rec_offset;
     DevBuf<ReplayTask> d_tasks;
     DevBuf<uint64_t> d_masks;
-    DevBuf<uint32_t> d_gtasks;
+    DevBuf<uint2> d_gtasks;
     DevBuf<Counters> d_ctr;
     DevBuf<uint8_t> d_scan_tmp;
     DevBuf<int32_t> d_tstop;
@@ -106,6 +110,9 @@ struct LaneSet {
             L.release();
             for (auto& e : L.ev)
                 if (e) (void)hipEventDestroy(e);
+            if (L.ev_fork) (void)hipEventDestroy(L.ev_fork);
+            if (L.ev_join) (void)hipEventDestroy(L.ev_join);
+            if (L.aux) (void)hipStreamDestroy(L.aux);
             if (L.host) (void)hipHostFree(L.host);
         }
         for (hipStream_t st : own)
@@ -487,7 +494,33 @@ FinishBufs finish_bufs(PipeLane& L)
     fb.mask_cap = L.d_masks.cap / 2;
     fb.gtask_cap = L.d_gtasks.cap;
     fb.tstop = L.d_tstop.p;
+    fb.rec_count = L.d_rec_count.p;
     return fb;
+}
+
+// the records of a slice, behind those of the earlier slices (ev[5]..ev[6] time it): the pairs counted in the fill
+// kernel's tail by a per-pair launch, the others through the generic replay's task list
+constexpr unsigned LISTED_GRID = 1024;
+void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left)
+{
+    const int64_t np = s.g.n_pairs;
+    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
+    dsa_record* out = ctx->d_records.p + ctx->n_records;
+    (void)hipEventRecord(L.ev[5], L.stream);
+    // the listed pairs' kernel is a few latency-bound waves, the counted pairs' one streams: side by side
+    (void)hipEventRecord(L.ev_fork, L.stream);
+    (void)hipStreamWaitEvent(L.aux, L.ev_fork, 0);
+    hipLaunchKernelGGL(k_emit_listed<true>, dim3(LISTED_GRID), dim3(EMIT_BLOCK), 0, L.aux, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
+                       pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
+                       (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p, out,
+                       (uint64_t)cap_left, (int64_t)s.pair_begin, s.g);
+    (void)hipEventRecord(L.ev_join, L.aux);
+    hipLaunchKernelGGL(k_emit_counted, dim3((unsigned)((np + EMIT_BLOCK - 1) / EMIT_BLOCK)), dim3(EMIT_BLOCK), 0, L.stream, pairs, ctx->d_fusions.p,
+                       L.d_state.p, L.d_kept.p, L.d_tasks.p, L.d_masks.p, (const int64_t*)L.d_rec_offset.p, out, (uint64_t)cap_left,
+                       (int64_t)s.pair_begin, L.d_ctr.p, (uint64_t)L.d_kept.cap, (uint64_t)L.d_tasks.cap, (uint64_t)(L.d_masks.cap / 2),
+                       (uint64_t)L.d_gtasks.cap, s.g);
+    (void)hipStreamWaitEvent(L.stream, L.ev_join, 0);
+    (void)hipEventRecord(L.ev[6], L.stream);
 }
 
 // fill (with the per-workgroup combine and table-driven replay in its tail) -> generic replay ->
@@ -503,7 +536,6 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
-    const unsigned pair_grid = (unsigned)((np + 255) / 256);
     const FinishBufs fb = finish_bufs(L);
     HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
     HIPC(hipEventRecord(L.ev[1], st));
@@ -524,12 +556,22 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
                        ctx->d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
-    hipLaunchKernelGGL(k_emit<false>, dim3(pair_grid), dim3(256), 0, st, pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p,
-                       L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr, (uint64_t)0,
-                       (int64_t)s.pair_begin, g);
+    hipLaunchKernelGGL(k_emit_listed<false>, dim3(LISTED_GRID), dim3(EMIT_BLOCK), 0, st, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
+                       pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
+                       (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr,
+                       (uint64_t)0, (int64_t)s.pair_begin, g);
     HIPC(hipMemsetAsync(L.d_rec_count.p + np, 0, sizeof(int64_t), st));
     if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
     HIPC(hipEventRecord(L.ev[3], st));
+    // The first slice of a run knows where its records go: write them right away, into the room there is, without
+    // waiting for the host to read the total (phase2 runs the emit again after growing the buffer if it was short).
+    L.emit_cap = 0;
+    L.emit_early = false;
+    if (ctx->n_records == 0 && &s == &ctx->slices.front() && ctx->d_records.cap > 0) {
+        L.emit_cap = ctx->d_records.cap;
+        L.emit_early = true;
+        launch_emit(ctx, L, s, L.emit_cap);
+    }
     HIPC(hipMemcpyAsync(&L.host->ctr, L.d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIPC(hipMemcpyAsync(&L.host->n_rec, L.d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPC(hipGetLastError());
@@ -592,9 +634,6 @@ void account_emit(dsa_ctx* ctx, PipeLane& L)
 int phase2(dsa_ctx* ctx, PipeLane& L)
 {
     const Slice& s = ctx->slices[L.slice];
-    const Geom g = s.g;
-    const int64_t np = g.n_pairs;
-    const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     account_emit(ctx, L);
     for (int attempt = 0;; ++attempt) {
         HIPC(hipStreamSynchronize(L.stream));
@@ -612,19 +651,19 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     {
         unsigned long long h[16];
         HIPC(hipMemcpy(h, L.d_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu); generic replay: %llu waves, setup %llu, sweep %llu cycles, %llu row groups (lane 0)\n",
-                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11], h[13]);
+        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu); generic replay: %llu waves, setup %llu, sweep %llu cycles, %llu row groups (lane 0); swept row groups with no live lane %llu; slowest lane of the listed count: %llu cycles, %llu kept rows, %llu tasks\n",
+                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11], h[13], h[14], h[15] >> 24, (h[15] >> 8) & 0xFFFF, h[15] & 0xFF);
     }
 #endif
     const int64_t n_rec = L.host->n_rec;
-    if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
     ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
-    HIPC(hipEventRecord(L.ev[5], L.stream));
-    hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, L.stream, pairs, ctx->d_fusions.p, L.d_state.p,
-                       L.d_kept.p, L.d_tasks.p, L.d_masks.p, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p,
-                       ctx->d_records.p + ctx->n_records, (uint64_t)(ctx->d_records.cap - ctx->n_records), (int64_t)s.pair_begin, g);
-    HIPC(hipEventRecord(L.ev[6], L.stream));
+    if (!(L.emit_early && (uint64_t)n_rec <= L.emit_cap)) {
+        if (L.emit_early) ctx->timing.finish_ms += elapsed(L.ev[5], L.ev[6]);     // the short attempt was work too
+        if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
+        launch_emit(ctx, L, s, ctx->d_records.cap - ctx->n_records);
+    }
     HIPC(hipGetLastError());
+    L.emit_early = false;
     L.emit_pending = true;
     ctx->n_records += n_rec;
     ctx->timing.fill_ms += elapsed(L.ev[1], L.ev[2]);
@@ -704,6 +743,9 @@ int dsa_create(dsa_ctx** out, int device)
         ok = ok && hipStreamCreate(&ctx->lanes->own[l]) == hipSuccess;
         L.stream = ctx->lanes->own[l];
         for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
     }
     for (auto& e : ctx->ev_pack) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -858,6 +900,8 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
         HIPC(hipEventRecord(ctx->ev_pack[1], L0.stream));
         HIPC(hipStreamWaitEvent(ctx->lanes->lane[1].stream, ctx->ev_pack[1], 0));
     }
+    // room for two records per candidate before the first run, so that its first slice can write its records early too
+    if (ns > 0 && ctx->d_records.cap == 0) HIPC(ctx->d_records.reserve((size_t)ctx->n_pairs * 2 + 1024));
     for (int k = 0; k < ns; ++k) {
         PipeLane& L = ctx->lanes->lane[k & 1];
         if (L.slice >= 0)

@@ -198,19 +198,26 @@ struct ReplayTask {
     uint16_t last_row;     // largest row either matrix needs; bit 15 = replayed by the table-driven kernel
     uint8_t  chunk0;       // NO_CHUNK = nothing to replay on that side
     uint8_t  chunk1;
-    uint16_t first_a;      // min(a, lq - a) of the first kept read split: the generic replay sorts its lanes by it
-    uint16_t pad_;
+    int32_t fusion;        // the pair's fusion: the generic replay starts fetching its reference codes at once
 };
+constexpr uint32_t GTASK_OWNER = 0x80000000u;   // gtasks[].x: the pair's first task in the list (that lane counts / writes the pair's records)
 constexpr uint16_t TASK_FAST = 0x8000u;
+constexpr uint16_t TASK_ONLY = 0x4000u;   // LaneInfo only: the pair has no other task, the replaying lane also counts its records
+constexpr uint16_t TASK_ROW = 0x3FFFu;    // rows <= 7600
 
-struct PairState {
-    int32_t max_score;     // best m1+m2 (0 = no output)
-    int32_t n_kept;        // kept rows with columns on both sides
+struct alignas(8) PairState {
+    uint32_t mask_begin;   // masks[(mask_begin + t * n_kept + k) * 2 + h]: columns of kept row k in the tile of task t, matrix h
     uint32_t kept_begin;
     uint32_t task_begin;
-    uint32_t n_tasks;
-    uint32_t pad_;
+    uint16_t n_kept;       // kept rows with columns on both sides
+    uint8_t n_tasks;       // saturates at 255 (emit then walks the task list, as it does whenever STATE_TILES is not set)
+    uint8_t flags;
+    uint16_t tiles0, tiles1;   // STATE_TILES: the tiles of M1 / M2 that hold a column of a kept row; task t has the t-th set bit of each
+    uint32_t n_tasks_all;
 };
+static_assert(sizeof(PairState) == 24, "three 8-byte loads");
+constexpr uint8_t STATE_COUNTED = 1;   // rec_count already holds the pair's record count (combine: no records; fill tail: its only task)
+constexpr uint8_t STATE_TILES = 2;     // tiles0 / tiles1 are valid (windows of at most 16 tiles): emit needs no task list
 
 struct Counters {          // device-side allocation cursors (and overflow detection)
     unsigned long long n_kept, n_tasks, n_masks, n_gtasks;
@@ -787,10 +794,11 @@ struct FinishBufs {
     KeptRow* kept;
     ReplayTask* tasks;
     uint64_t* masks;
-    uint32_t* gtasks;
+    uint2* gtasks;         // {task | GTASK_OWNER, pair} of every task the table-driven replay leaves to k_replay
     Counters* ctr;
     uint64_t kept_cap, task_cap, mask_cap, gtask_cap;
     int32_t* tstop;        // [wave][tile]: row groups of the tile whose bnd / cmax were stored (the rest is dead)
+    int64_t* rec_count;    // [pair in the caller's order]: records of the pair
 };
 
 // tstop is read in the kernel that writes it, by other lanes and waves of the workgroup: bypass the
@@ -853,7 +861,7 @@ __device__ __forceinline__ void combine_wg(
     PairState* __restrict__ state = fb.state;
     KeptRow* __restrict__ kept = fb.kept;
     ReplayTask* __restrict__ tasks = fb.tasks;
-    uint32_t* __restrict__ gtasks = fb.gtasks;
+    uint2* __restrict__ gtasks = fb.gtasks;
     const uint64_t kept_cap = fb.kept_cap, task_cap = fb.task_cap, mask_cap = fb.mask_cap, gtask_cap = fb.gtask_cap;
     const int tid = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * WG_LANES + tid;
@@ -1055,7 +1063,7 @@ __device__ __forceinline__ void combine_wg(
         const int c0 = (key >> 8) & 0xFF, c1 = key & 0xFF;
         const bool here = ok && fast;
         const int r0 = c0 != NO_CHUNK ? last_a : 0, r1 = c1 != NO_CHUNK ? lq - first_a : 0;
-        li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST) : (uint16_t)0;
+        li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST | (n_tasks == 1 ? TASK_ONLY : 0)) : (uint16_t)0;
         li.c0 = here ? (uint8_t)c0 : NO_CHUNK;
         li.c1 = here ? (uint8_t)c1 : NO_CHUNK;
         li.key_group = (uint16_t)((fold_a < 255 ? fold_a : 255) | ((gsel >= 0 ? gsel : 0) << 8));
@@ -1067,14 +1075,22 @@ __device__ __forceinline__ void combine_wg(
     }
     if (!active) return;
     PairState st;
-    st.max_score = max_score;
-    st.n_kept = ok ? n_kept : 0;
+    st.mask_begin = (uint32_t)mb;
     st.kept_begin = (uint32_t)kb;
     st.task_begin = (uint32_t)tb;
-    st.n_tasks = n_tasks;
-    st.pad_ = 0;
+    st.n_kept = (uint16_t)(ok ? n_kept : 0);
+    st.n_tasks = (uint8_t)(n_tasks < 255u ? n_tasks : 255u);
+    const bool tiles_fit = small && g.nch <= 16;
+    // no kept row: no records, said here; a pair whose only task is replayed by this workgroup is counted by that lane
+    st.flags = (uint8_t)(((!ok || (HANDOFF && fast && n_tasks == 1)) ? STATE_COUNTED : 0) | (tiles_fit ? STATE_TILES : 0));
+    st.tiles0 = (uint16_t)(tiles_fit ? tiles0 : 0);
+    st.tiles1 = (uint16_t)(tiles_fit ? tiles1 : 0);
+    st.n_tasks_all = n_tasks;
     state[p] = st;
-    if (!ok) return;
+    if (!ok) {
+        fb.rec_count[g.orig ? g.orig[p] : p] = 0;
+        return;
+    }
     // kept rows: the first ones are still in registers, the rest is re-read
     int k = 0, a_next = first_a;
     for (; k < n_cached; ++k) {
@@ -1106,12 +1122,13 @@ __device__ __forceinline__ void combine_wg(
         rt.last_row = (uint16_t)(r0 > r1 ? r0 : r1);
         rt.chunk0 = c0 >= 0 ? (uint8_t)c0 : NO_CHUNK;
         rt.chunk1 = c1 >= 0 ? (uint8_t)c1 : NO_CHUNK;
-        rt.first_a = (uint16_t)fold_a;
-        rt.pad_ = 0;
+        rt.fusion = fidx;
         if (t == 0 && fast)
             rt.last_row |= TASK_FAST;
-        else
-            gtasks[gb + gi++] = (uint32_t)(tb + t);
+        else {
+            gtasks[gb + gi] = make_uint2((uint32_t)(tb + t) | (gi == 0 ? GTASK_OWNER : 0u), (uint32_t)p);
+            ++gi;
+        }
         tasks[tb + t] = rt;
     }
 }
@@ -1163,29 +1180,33 @@ __device__ __forceinline__ HitCursor cursor_init(const KeptRow* __restrict__ kr,
     return hc;
 }
 
-// Columns of the tile whose value at this row equals the given targets, both fields in one pass: per
-// column sub (drift) + xor (0 <=> equal) + pk_min(.,1) + shift-or into a miss-bit accumulator.
+// Columns of the tile whose value at this row equals the given targets, both fields in one pass.  A target
+// is the row maximum (no column exceeds it) or NO_TARGET16 (above every value), so per column
+// sat(X - (target - 1 + drift)) is 1 exactly on a hit: one add (drift), one saturating packed subtract
+// and one shift-or into a hit-bit accumulator.
+constexpr uint32_t NO_TARGET16 = 0x7F00u;   // above BIAS16 + 4 * 7600 + drift, and + drift still fits the field
 __device__ __forceinline__ void equal_columns(const uint32_t (&X)[W], uint32_t target2, uint64_t& m0, uint64_t& m1)
 {
-    uint32_t miss[W / 16];
-    const uint32_t one2 = 0x00010001u;
+    uint32_t hit[W / 16];
+    const uint32_t below = target2 - 0x00010001u;
 #pragma unroll
     for (int q = 0; q < W / 16; ++q) {
         uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 15; k >= 0; --k) {
             const int i = 16 * q + k;
-            const uint32_t e = (X[i] - drift2(i)) ^ target2;
-            uint32_t y;            // min(e, 1) per field; spelled out: the compiler would expand the C form
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(y) : "v"(e), "v"(one2));   // into two compares and two selects
-            acc |= y << k;         // bit k: lo field differs, bit 16+k: hi field differs
+            const uint32_t c = below + drift2(i);
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, X[i]), __builtin_bit_cast(us2, c)));   // v_pk_sub_u16 clamp
+            asm("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(acc) : "v"(y));   // bit k: lo field hits, bit 16+k: hi field hits (left to
+                                                                        // itself the compiler builds shift + or3 trees, 1.3 per column)
         }
-        miss[q] = acc;
+        hit[q] = acc;
     }
-    const uint32_t lo_a = (miss[0] & 0xFFFFu) | (miss[1] << 16), lo_b = (miss[2] & 0xFFFFu) | (miss[3] << 16);
-    const uint32_t hi_a = (miss[0] >> 16) | (miss[1] & 0xFFFF0000u), hi_b = (miss[2] >> 16) | (miss[3] & 0xFFFF0000u);
-    m0 = ~((uint64_t)lo_a | ((uint64_t)lo_b << 32));
-    m1 = ~((uint64_t)hi_a | ((uint64_t)hi_b << 32));
+    const uint32_t lo_a = (hit[0] & 0xFFFFu) | (hit[1] << 16), lo_b = (hit[2] & 0xFFFFu) | (hit[3] << 16);
+    const uint32_t hi_a = (hit[0] >> 16) | (hit[1] & 0xFFFF0000u), hi_b = (hit[2] >> 16) | (hit[3] & 0xFFFF0000u);
+    m0 = (uint64_t)lo_a | ((uint64_t)lo_b << 32);
+    m1 = (uint64_t)hi_a | ((uint64_t)hi_b << 32);
 }
 
 // At row j: report, for the kept rows met here, the valid columns that attain the row maximum.
@@ -1196,7 +1217,7 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
     const bool hit0 = hc.row0 == j, hit1 = hc.row1 == j;
     if (!(hit0 || hit1)) return;
     uint64_t m0, m1;
-    equal_columns(X, (hit0 ? hc.t0 : 0xFFFFu) | ((hit1 ? hc.t1 : 0xFFFFu) << 16), m0, m1);
+    equal_columns(X, (hit0 ? hc.t0 : NO_TARGET16) | ((hit1 ? hc.t1 : NO_TARGET16) << 16), m0, m1);
     if (hit0) {
         masks[((uint64_t)mask_begin + hc.k0) * 2] = m0 & hc.valid0;
         ++hc.k0;
@@ -1207,6 +1228,29 @@ __device__ __forceinline__ void record_hits(const uint32_t (&X)[W], int j, int l
         --hc.k1;
         cursor_next1(hc, kr, kc, lq, has1);
     }
+}
+
+// Records of a pair whose columns all lie in one tile pair: per kept split the cross product of the two column
+// sets minus the refSplits an earlier kept split already has (tools/SplitAlignment.cpp:381-391); mk[2k + h] is
+// the column mask of kept row k in matrix h.  Same count as k_emit<false>.
+__device__ __forceinline__ int64_t count_one_tile_pair(const uint64_t* mk, int n_kept)
+{
+    int64_t n = 0;
+    for (int k = 0; k < n_kept; ++k) {
+        const uint64_t m0 = mk[2 * k], m1 = mk[2 * k + 1];
+        if (k == 0) {
+            n += (int64_t)__builtin_popcountll(m0) * __builtin_popcountll(m1);
+            continue;
+        }
+        for (uint64_t r0 = m0; r0; r0 &= r0 - 1)
+            for (uint64_t r1 = m1; r1; r1 &= r1 - 1) {
+                const int i1 = __builtin_ctzll(r0), i2 = __builtin_ctzll(r1);
+                bool dup = false;
+                for (int k2 = 0; k2 < k && !dup; ++k2) dup = ((mk[2 * k2] >> i1) & 1ull) && ((mk[2 * k2 + 1] >> i2) & 1ull);
+                n += dup ? 0 : 1;
+            }
+    }
+    return n;
 }
 
 // Table-driven replay (second tail of the fast fill kernel).  The first task of every pair of the
@@ -1265,7 +1309,7 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
     const int lane = (int)(p & 63);
     const int64_t w = p >> 6;
     const bool has = (li.last_row & TASK_FAST) != 0;
-    const int R = has ? (li.last_row & 0x7FFF) : 0;
+    const int R = has ? (li.last_row & TASK_ROW) : 0;
     int Rw = R;                                          // wave maximum
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) Rw = max(Rw, __shfl_xor(Rw, d, 64));
@@ -1347,6 +1391,9 @@ __device__ __forceinline__ void replay_fast_wg(uint32_t* T, FinishLds* fl, const
         for (int k = 0; k < n_kept; ++k) masks[((uint64_t)li.mask_begin + k) * 2] = 0;
     if (has && !has1)
         for (int k = 0; k < n_kept; ++k) masks[((uint64_t)li.mask_begin + k) * 2 + 1] = 0;
+    // a pair with no other task has all its columns here: count its records now (k_emit<false> skips it)
+    if (has && (li.last_row & TASK_ONLY) && p < g.n_pairs)
+        fb.rec_count[g.orig ? g.orig[p] : p] = count_one_tile_pair(masks + (uint64_t)li.mask_begin * 2, n_kept);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1672,6 +1719,9 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
         uint4 b_n = (c == 0) ? bias4 : bi4[0];              // every tile stores at least its first row group
         int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
         int gq = 0;
+#ifdef DSA_PRUNE_STATS
+        int n_dead_groups = 0;
+#endif
         for (; gq < ngq; ++gq) {
             const uint4 rc = rc_n, b = b_n;
             const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
@@ -1767,12 +1817,16 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
 #ifdef DSA_ABLATE_STORES
             }
 #endif
+#ifdef DSA_PRUNE_STATS
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) ++n_dead_groups;
+#endif
 #ifndef DSA_NO_PRUNE
             if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
 #endif
         }
 #ifdef DSA_PRUNE_STATS
         if (lane == 0) {
+            atomicAdd(&g.stats[14], (unsigned long long)n_dead_groups);
             atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
             atomicAdd(&g.stats[1], (unsigned long long)ngq);
             atomicAdd(&g.stats[2], (unsigned long long)l_in);
@@ -1821,11 +1875,12 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
 // every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
 // maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Covers the device list of tasks the
 // table-driven replay left over.  A block takes REPLAY_BLOCK consecutive tasks and hands them to its
-// lanes in order of their first kept read split (counting sort in LDS), so that the lanes of a wave
-// reach their kept rows — where the column masks are extracted — in the same few rows.
+// lanes in order of their last row (counting sort in LDS): two tasks in three are the second tile of a
+// tie on a short side and need a dozen rows, and a wave sweeps as many rows as its longest lane; a
+// one-sided task also meets its kept row in its last row, so the lanes of a wave extract together.
 constexpr int REPLAY_BLOCK = 256;
 __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
-                                                   const uint32_t* __restrict__ gtasks, uint64_t gtask_cap,
+                                                   const uint2* __restrict__ gtasks, uint64_t gtask_cap,
                                                    const Counters* __restrict__ ctr,
                                                    const PairState* __restrict__ state,
                                                    const KeptRow* __restrict__ kept, uint64_t kept_cap,
@@ -1848,9 +1903,9 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         __syncthreads();
         int my_key = 256, my_rank = 0;
         if (base + threadIdx.x < n_g) {
-            const ReplayTask mine = tasks[gtasks[base + threadIdx.x]];
+            const ReplayTask mine = tasks[gtasks[base + threadIdx.x].x & ~GTASK_OWNER];
             s_task[threadIdx.x] = mine;
-            my_key = min((int)mine.first_a, 255);
+            my_key = min((int)(mine.last_row & TASK_ROW), 255);
         }
         my_rank = atomicAdd(&s_hist[my_key], 1);
         __syncthreads();
@@ -1876,11 +1931,10 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         const int lane = (int)(p & 63);
         const bool has0 = rt.chunk0 != NO_CHUNK, has1 = rt.chunk1 != NO_CHUNK;
         const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
-        const dsa_pair pr = pairs[p];
-        const dsa_fusion fu = fusions[pr.fusion_idx];
+        const uint32_t* rc = refcodes + (int64_t)rt.fusion * g.lrp;      // the 64 loads below need nothing but the task
+        const dsa_fusion fu = fusions[rt.fusion];
         const PairState st = state[p];
-        const int lq = pr.read_len;
-        const uint32_t* rc = refcodes + (int64_t)pr.fusion_idx * g.lrp;
+        const int lq = pairs[p].read_len;
         const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
         const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
         const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
@@ -1897,7 +1951,7 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
 #pragma unroll
         for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
         uint32_t bprev = BIAS2;
-        const int R = rt.last_row & 0x7FFF;
+        const int R = rt.last_row & TASK_ROW;
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
@@ -1916,16 +1970,19 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                               (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
         };
         const int ngq = (R >> 2) + 1;
-        uint4 rc_n = rows4[0];
-        uint4 b_n = boundary(0);
+        // the lanes of a wave read different planes (64 cache lines per load): operands are fetched two steps ahead
+        uint4 rc_n = rows4[0], rc_nn = rows4[(int64_t)(1 < ngq ? 1 : 0) * WAVE];
+        uint4 b_n = boundary(0), b_nn = boundary(1 < ngq ? 1 : 0);
 #ifdef DSA_PRUNE_STATS
         const unsigned long long tr1 = __builtin_readcyclecounter();
 #endif
         for (int gq = 0; gq < ngq; ++gq) {
             const uint4 rcq = rc_n, b = b_n;
-            const int gn = gq + 1 < ngq ? gq + 1 : gq;
-            rc_n = rows4[(int64_t)gn * WAVE];
-            b_n = boundary(gn);
+            const int gn = gq + 2 < ngq ? gq + 2 : ngq - 1;
+            rc_n = rc_nn;
+            b_n = b_nn;
+            rc_nn = rows4[(int64_t)gn * WAVE];
+            b_nn = boundary(gn);
             const uint32_t rcv[4] = {rcq.x, rcq.y, rcq.z, rcq.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
@@ -1968,25 +2025,151 @@ __device__ __forceinline__ bool col_in(const ReplayTask* tasks, const uint64_t* 
     return false;
 }
 
-template <bool WRITE>
-__global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
-                       const PairState* __restrict__ state, const KeptRow* __restrict__ kept,
-                       const ReplayTask* __restrict__ tasks, const uint64_t* __restrict__ masks,
-                       int64_t* __restrict__ rec_count, const int64_t* __restrict__ rec_offset,
-                       dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base, Geom g)
+constexpr int EMIT_BLOCK = 128;
+// (task, kept row) mask pairs a lane stages in LDS, all loads in flight at once; a pair with more walks global memory, a
+// chain of dependent loads per column pair.  Few pairs have many, but the slowest lane sets the time of these kernels.
+constexpr int EMIT_SLOTS_COUNTED = 1, EMIT_SLOTS_LISTED = 16;
+constexpr int EMIT_REG_ROWS = 4;   // kept rows of a one-tile-pair pair that are handled in registers
+template <int SLOTS>
+struct EmitLds {
+    uint4 mask[SLOTS][EMIT_BLOCK];   // [task * n_kept + kept row]: {M1 mask, M2 mask}
+    uint2 kept[SLOTS][EMIT_BLOCK];   // the kept rows
+};
+
+// The records of one pair (WRITE) or their number.
+template <bool WRITE, int SLOTS>
+__device__ __forceinline__ int64_t emit_pair(EmitLds<SLOTS>* lds, int64_t p, int64_t o, const PairState& st, const dsa_pair* __restrict__ pairs,
+                                             const dsa_fusion* __restrict__ fusions, const KeptRow* __restrict__ kept,
+                                             const ReplayTask* __restrict__ tasks, const uint64_t* __restrict__ masks,
+                                             const int64_t* __restrict__ rec_offset, dsa_record* __restrict__ out, uint64_t out_cap,
+                                             int64_t pair_base)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= g.n_pairs) return;
-    const int64_t o = g.orig ? g.orig[p] : p;      // records are counted and written in the caller's pair order
-    const PairState st = state[p];
+    const int tid = threadIdx.x;
     int64_t n = 0;
-    if (st.n_kept > 0) {
-        const dsa_pair pr = pairs[p];
+    int64_t wr = 0;
+    dsa_record rec = {};
+    int ref1_len = 0;
+    if (WRITE) {
+        const dsa_pair pr = pairs[p];                // issued together with the offsets: the chain is pair -> fusion
+        wr = rec_offset[o];
+        const int64_t wr_end = rec_offset[o + 1];
         const dsa_fusion fu = fusions[pr.fusion_idx];
-        const uint32_t tb = st.task_begin, te = tb + st.n_tasks;
-        int64_t wr = WRITE ? rec_offset[o] : 0;
-        if (WRITE && (uint64_t)rec_offset[o + 1] > out_cap) return;   // host grows the buffer and reruns emit
-        for (int k = 0; k < st.n_kept; ++k) {
+        if ((uint64_t)wr_end > out_cap) return 0;    // host grows the buffer and reruns emit
+        rec.fusion_id = fu.fusion_id;
+        rec.frag = pr.frag;
+        rec.read_end = pr.read_end;
+        rec.revcomp = pr.revcomp;
+        rec.read_second = pr.read_len;               // minus a below
+        rec.pair_idx = (int32_t)(pair_base + o);
+        ref1_len = fu.ref1_len;
+    }
+    // 40-byte records at a multiple of 40 bytes from a 256-byte aligned base: five 8-byte stores
+    auto put = [&](int i1, int i2, const KeptRow& kr) {
+        if (WRITE) {
+            dsa_record r = rec;
+            r.ref_first = i1;
+            r.ref_second = ref1_len - i2 - 1;
+            r.read_first = kr.a;
+            r.read_second = rec.read_second - kr.a;
+            r.score = kr.m1 < kr.m2 ? kr.m1 : kr.m2;
+            uint2* dst = reinterpret_cast<uint2*>(out + wr);
+            const uint2* src = reinterpret_cast<const uint2*>(&r);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) dst[q] = src[q];
+        }
+        ++wr;
+        ++n;
+    };
+    const int K = st.n_kept, T = (int)st.n_tasks;
+    const bool tiles = (st.flags & STATE_TILES) != 0;
+    if (tiles && T == 1 && K <= EMIT_REG_ROWS) {
+        // one tile pair and a few kept rows - nearly every pair: masks and rows in registers, two loads deep
+        const uint4* masks4 = reinterpret_cast<const uint4*>(masks) + st.mask_begin;
+        const uint2* kept2 = reinterpret_cast<const uint2*>(kept) + st.kept_begin;
+        uint4 m[EMIT_REG_ROWS];
+        uint2 kr2[EMIT_REG_ROWS];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            m[e] = masks4[e < K ? e : K - 1];
+            kr2[e] = kept2[e < K ? e : K - 1];
+        }
+#pragma unroll
+        for (int e = 2; e < EMIT_REG_ROWS; ++e) {
+            m[e] = m[1];
+            kr2[e] = kr2[1];
+        }
+        if (K > 2) {
+#pragma unroll
+            for (int e = 2; e < EMIT_REG_ROWS; ++e) {
+                m[e] = masks4[e < K ? e : K - 1];
+                kr2[e] = kept2[e < K ? e : K - 1];
+            }
+        }
+        const bool both = st.tiles0 != 0 && st.tiles1 != 0;
+        const int base1 = __builtin_ctz(st.tiles0 | 0x10000u) * W + 1, base2 = __builtin_ctz(st.tiles1 | 0x10000u) * W + 1;
+        auto lo64 = [](const uint4& v) -> uint64_t { return ((uint64_t)v.y << 32) | v.x; };
+        auto hi64 = [](const uint4& v) -> uint64_t { return ((uint64_t)v.w << 32) | v.z; };
+#pragma unroll
+        for (int k = 0; k < EMIT_REG_ROWS; ++k) {
+            if (both && k < K) {
+                const KeptRow kr = __builtin_bit_cast(KeptRow, kr2[k]);
+                for (uint64_t r1 = lo64(m[k]); r1; r1 &= r1 - 1) {
+                    const int b1 = __builtin_ctzll(r1);
+                    for (uint64_t r2 = hi64(m[k]); r2; r2 &= r2 - 1) {
+                        const int b2 = __builtin_ctzll(r2);
+                        bool dup = false;     // same refSplit <=> same (i1,i2) at an earlier kept a
+#pragma unroll
+                        for (int k2 = 0; k2 < k; ++k2) dup = dup || (((lo64(m[k2]) >> b1) & 1ull) && ((hi64(m[k2]) >> b2) & 1ull));
+                        if (!dup) put(base1 + b1, base2 + b2, kr);
+                    }
+                }
+            }
+        }
+    } else if (tiles && K * T <= SLOTS) {
+        // Task t holds the t-th tile of either bitmap, so column i1 of task t1 can only recur in task t1's mask of an
+        // earlier kept row: the de-dup (same refSplit <=> same (i1,i2) at an earlier kept a) is two bit tests per
+        // earlier row.  The masks of the pair are one block of memory.
+        const uint4* masks4 = reinterpret_cast<const uint4*>(masks) + st.mask_begin;
+        const int slots = K * T;
+        const uint2* kept2 = reinterpret_cast<const uint2*>(kept) + st.kept_begin;
+        // in growing groups, each with all its loads in flight: most pairs have one or two
+#pragma unroll
+        for (int e0 = 0, e1 = 2; e0 < SLOTS; e0 = e1, e1 *= 2) {
+            if (e0 == 0 || slots > e0) {
+#pragma unroll
+                for (int e = e0; e < e1 && e < SLOTS; ++e) {
+                    lds->mask[e][tid] = masks4[e < slots ? e : slots - 1];
+                    lds->kept[e][tid] = kept2[e < K ? e : K - 1];
+                }
+            }
+        }
+        auto mask_of = [&](int k, int t, int h) -> uint64_t {
+            const uint4 v = lds->mask[t * K + k][tid];
+            return h ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
+        };
+        for (int k = 0; k < K; ++k) {
+            const KeptRow kr = __builtin_bit_cast(KeptRow, lds->kept[k][tid]);
+            int t1 = 0;
+            for (uint32_t w0 = st.tiles0; w0; w0 &= w0 - 1, ++t1) {
+                const int c0 = __builtin_ctz(w0);
+                for (uint64_t r1 = mask_of(k, t1, 0); r1; r1 &= r1 - 1) {
+                    const int b1 = __builtin_ctzll(r1);
+                    int t2 = 0;
+                    for (uint32_t w1 = st.tiles1; w1; w1 &= w1 - 1, ++t2) {
+                        const int c1 = __builtin_ctz(w1);
+                        for (uint64_t r2 = mask_of(k, t2, 1); r2; r2 &= r2 - 1) {
+                            const int b2 = __builtin_ctzll(r2);
+                            bool dup = false;
+                            for (int k2 = 0; k2 < k && !dup; ++k2) dup = ((mask_of(k2, t1, 0) >> b1) & 1ull) && ((mask_of(k2, t2, 1) >> b2) & 1ull);
+                            if (!dup) put(c0 * W + b1 + 1, c1 * W + b2 + 1, kr);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const uint32_t tb = st.task_begin, te = tb + st.n_tasks_all;
+        for (int k = 0; k < K; ++k) {
             const KeptRow kr = kept[st.kept_begin + k];
             for (uint32_t q1 = tb; q1 < te; ++q1) {        // tasks hold M1 tiles in ascending order
                 if (tasks[q1].chunk0 == NO_CHUNK) continue;
@@ -2003,30 +2186,209 @@ __global__ void k_emit(const dsa_pair* __restrict__ pairs, const dsa_fusion* __r
                             bool dup = false;     // same refSplit <=> same (i1,i2) at an earlier kept a
                             for (int k2 = 0; k2 < k && !dup; ++k2)
                                 dup = col_in(tasks, masks, tb, te, k2, 0, i1) && col_in(tasks, masks, tb, te, k2, 1, i2);
-                            if (dup) continue;
-                            if (WRITE) {
-                                dsa_record rec;
-                                rec.fusion_id = fu.fusion_id;
-                                rec.frag = pr.frag;
-                                rec.read_end = pr.read_end;
-                                rec.revcomp = pr.revcomp;
-                                rec.ref_first = i1;
-                                rec.ref_second = fu.ref1_len - i2 - 1;
-                                rec.read_first = kr.a;
-                                rec.read_second = pr.read_len - kr.a;
-                                rec.score = kr.m1 < kr.m2 ? kr.m1 : kr.m2;
-                                rec.pair_idx = (int32_t)(pair_base + o);
-                                out[wr] = rec;
-                            }
-                            ++wr;
-                            ++n;
+                            if (!dup) put(i1, i2, kr);
                         }
                     }
                 }
             }
         }
     }
-    if (!WRITE) rec_count[o] = n;
+    return n;
+}
+
+// A pair with more (task, kept row) mask pairs than a lane stages: the whole wave takes it.  Its lanes copy the masks
+// and kept rows into the wave's part of the staging area (SLOTS entries per lane, so 64 * SLOTS in all), then lane k
+// counts kept row k (the de-dup only reads earlier rows' masks), a prefix sum places the rows, and every lane writes
+// its row's records: the order is that of emit_pair.  Called by all 64 lanes with the same arguments.
+template <bool WRITE, int SLOTS>
+__device__ __forceinline__ int64_t emit_pair_wave(EmitLds<SLOTS>* lds, int64_t p, int64_t o, uint32_t mask_begin, uint32_t kept_begin, int K, int T,
+                                                  uint32_t tiles0, uint32_t tiles1, const dsa_pair* __restrict__ pairs,
+                                                  const dsa_fusion* __restrict__ fusions, const KeptRow* __restrict__ kept,
+                                                  const uint64_t* __restrict__ masks, const int64_t* __restrict__ rec_offset,
+                                                  dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base)
+{
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    auto slot_m = [&](int e) -> uint4& { return lds->mask[e >> 6][wbase + (e & 63)]; };
+    auto slot_k = [&](int e) -> uint2& { return lds->kept[e >> 6][wbase + (e & 63)]; };
+    const uint4* masks4 = reinterpret_cast<const uint4*>(masks) + mask_begin;
+    const uint2* kept2 = reinterpret_cast<const uint2*>(kept) + kept_begin;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < K * T; e += 64) slot_m(e) = masks4[e];
+    for (int e = lane; e < K; e += 64) slot_k(e) = kept2[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto mask_of = [&](int k, int t, int h) -> uint64_t {
+        const uint4 v = slot_m(t * K + k);
+        return h ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
+    };
+    int64_t wr = 0;
+    dsa_record rec = {};
+    int ref1_len = 0;
+    if (WRITE) {
+        wr = rec_offset[o];
+        if ((uint64_t)rec_offset[o + 1] > out_cap) return 0;   // uniform: host grows the buffer and reruns emit
+        const dsa_pair pr = pairs[p];
+        const dsa_fusion fu = fusions[pr.fusion_idx];
+        rec.fusion_id = fu.fusion_id;
+        rec.frag = pr.frag;
+        rec.read_end = pr.read_end;
+        rec.revcomp = pr.revcomp;
+        rec.read_second = pr.read_len;
+        rec.pair_idx = (int32_t)(pair_base + o);
+        ref1_len = fu.ref1_len;
+    }
+    // the records of kept row k, handed to fn(i1, i2) in output order
+    auto row = [&](int k, auto&& fn) {
+        int t1 = 0;
+        for (uint32_t w0 = tiles0; w0; w0 &= w0 - 1, ++t1) {
+            const int c0 = __builtin_ctz(w0);
+            for (uint64_t r1 = mask_of(k, t1, 0); r1; r1 &= r1 - 1) {
+                const int b1 = __builtin_ctzll(r1);
+                int t2 = 0;
+                for (uint32_t w1 = tiles1; w1; w1 &= w1 - 1, ++t2) {
+                    const int c1 = __builtin_ctz(w1);
+                    for (uint64_t r2 = mask_of(k, t2, 1); r2; r2 &= r2 - 1) {
+                        const int b2 = __builtin_ctzll(r2);
+                        bool dup = false;
+                        for (int k2 = 0; k2 < k && !dup; ++k2) dup = ((mask_of(k2, t1, 0) >> b1) & 1ull) && ((mask_of(k2, t2, 1) >> b2) & 1ull);
+                        if (!dup) fn(c0 * W + b1 + 1, c1 * W + b2 + 1);
+                    }
+                }
+            }
+        }
+    };
+    int64_t total = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {           // uniform
+        const int k = k0 + lane;
+        int n_row = 0;
+        if (k < K) row(k, [&](int, int) { ++n_row; });
+        int incl = n_row;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (WRITE && k < K) {
+            const KeptRow kr = __builtin_bit_cast(KeptRow, slot_k(k));
+            int64_t at = wr + total + (incl - n_row);
+            row(k, [&](int i1, int i2) {
+                dsa_record r = rec;
+                r.ref_first = i1;
+                r.ref_second = ref1_len - i2 - 1;
+                r.read_first = kr.a;
+                r.read_second = rec.read_second - kr.a;
+                r.score = kr.m1 < kr.m2 ? kr.m1 : kr.m2;
+                uint2* dst = reinterpret_cast<uint2*>(out + at);
+                const uint2* src = reinterpret_cast<const uint2*>(&r);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dst[q] = src[q];
+                ++at;
+            });
+        }
+        total += __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
+
+// does the wave take the pair (emit_pair_wave) rather than its lane?
+template <int SLOTS>
+__device__ __forceinline__ bool emit_is_heavy(const PairState& st)
+{
+    const int slots = (int)st.n_kept * (int)st.n_tasks;
+    if (st.n_tasks == 1 && st.n_kept <= EMIT_REG_ROWS) return false;
+    return (st.flags & STATE_TILES) != 0 && slots > SLOTS && slots <= 64 * SLOTS;
+}
+
+// the heavy pairs of a wave, one after the other; fn_done(lane's own pair result) is told the count of the lane's pair
+template <bool WRITE, int SLOTS>
+__device__ __forceinline__ int64_t emit_heavy_of_wave(EmitLds<SLOTS>* lds, bool heavy, int64_t p, int64_t o, const PairState& st,
+                                                      const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
+                                                      const KeptRow* __restrict__ kept, const uint64_t* __restrict__ masks,
+                                                      const int64_t* __restrict__ rec_offset, dsa_record* __restrict__ out, uint64_t out_cap,
+                                                      int64_t pair_base)
+{
+    int64_t mine = 0;
+    uint64_t todo = __builtin_amdgcn_ballot_w64(heavy);
+    while (todo) {                                   // uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t sp = __shfl((int)p, src, 64), so = __shfl((int)o, src, 64);       // pair indices are below 2^31
+        const uint32_t mb = (uint32_t)__shfl((int)st.mask_begin, src, 64), kb = (uint32_t)__shfl((int)st.kept_begin, src, 64);
+        const int packed = __shfl((int)st.n_kept | ((int)st.n_tasks << 16), src, 64);
+        const int tl = __shfl((int)st.tiles0 | ((int)st.tiles1 << 16), src, 64);
+        const int64_t n = emit_pair_wave<WRITE, SLOTS>(lds, sp, so, mb, kb, packed & 0xFFFF, (packed >> 16) & 0xFF, (uint32_t)tl & 0xFFFFu,
+                                                        (uint32_t)tl >> 16, pairs, fusions, kept, masks, rec_offset, out, out_cap, pair_base);
+        if ((int)(threadIdx.x & 63) == src) mine = n;
+    }
+    return mine;
+}
+
+// K4a: the records of the pairs the fill kernel's tail has counted (one tile pair, replayed there) - one lane per pair.
+__global__ __launch_bounds__(EMIT_BLOCK) void k_emit_counted(const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
+                       const PairState* __restrict__ state, const KeptRow* __restrict__ kept,
+                       const ReplayTask* __restrict__ tasks, const uint64_t* __restrict__ masks,
+                       const int64_t* __restrict__ rec_offset, dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base,
+                       const Counters* __restrict__ ctr, uint64_t kept_cap, uint64_t task_cap, uint64_t mask_cap, uint64_t gtask_cap, Geom g)
+{
+    __shared__ EmitLds<EMIT_SLOTS_COUNTED> lds;
+    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || ctr->n_gtasks > gtask_cap) return;   // counts are void: the host reruns the slice
+    const int64_t p = (int64_t)blockIdx.x * EMIT_BLOCK + threadIdx.x;
+    PairState st = {};
+    int64_t o = 0;                                   // records are counted and written in the caller's pair order
+    if (p < g.n_pairs) {
+        st = state[p];
+        o = g.orig ? g.orig[p] : p;
+    }
+    const bool mine = p < g.n_pairs && (st.flags & STATE_COUNTED) && st.n_kept != 0;
+    // Pairs with more kept rows than the register path takes come in runs (a repeat in one fusion's window gives all its
+    // reads the same ties): handing them to the whole wave one after the other (emit_pair_wave) would serialise a run
+    // that sits in one wave, so here they stay with their lanes and walk global memory.
+    if (mine) emit_pair<true, EMIT_SLOTS_COUNTED>(&lds, p, o, st, pairs, fusions, kept, tasks, masks, rec_offset, out, out_cap, pair_base);
+}
+
+// K4b: the other pairs - every one of them has a task in the generic replay's list, and the lane that finds the pair's
+// first such task there counts (WRITE = false) or writes the pair's records.  These lanes all work through several
+// tiles, which one lane in ten of a per-pair launch would do while the rest of its wave waits.
+template <bool WRITE>
+__global__ __launch_bounds__(EMIT_BLOCK) void k_emit_listed(const uint2* __restrict__ gtasks, uint64_t gtask_cap, const Counters* __restrict__ ctr,
+                       const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions,
+                       const PairState* __restrict__ state, const KeptRow* __restrict__ kept,
+                       const ReplayTask* __restrict__ tasks, uint64_t task_cap, const uint64_t* __restrict__ masks, uint64_t mask_cap,
+                       uint64_t kept_cap, int64_t* __restrict__ rec_count, const int64_t* __restrict__ rec_offset,
+                       dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base, Geom g)
+{
+    __shared__ EmitLds<EMIT_SLOTS_LISTED> lds;
+    const unsigned long long n_g = ctr->n_gtasks;
+    if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;   // the host reruns the slice
+    // Consecutive list entries go to different blocks (entry = thread * blocks + block within a round of the grid): the
+    // pairs with many kept rows come in runs, and a wave takes its heavy pairs one after the other.
+    const unsigned long long stride = (unsigned long long)gridDim.x * EMIT_BLOCK;
+    for (unsigned long long e0 = 0; e0 < n_g; e0 += stride) {      // uniform
+        const unsigned long long e = e0 + (unsigned long long)threadIdx.x * gridDim.x + blockIdx.x;
+        uint2 entry = make_uint2(0u, 0u);
+        if (e < n_g) entry = gtasks[e];
+        const bool mine = (entry.x & GTASK_OWNER) != 0;
+        const int64_t p = entry.y;
+        PairState st = {};
+        if (mine) st = state[p];
+        const int64_t o = mine ? (g.orig ? g.orig[p] : p) : 0;
+        const bool heavy = mine && emit_is_heavy<EMIT_SLOTS_LISTED>(st);
+#ifdef DSA_PRUNE_STATS
+        const unsigned long long te0 = __builtin_readcyclecounter();
+#endif
+        int64_t n = 0;
+        if (mine && !heavy) n = emit_pair<WRITE, EMIT_SLOTS_LISTED>(&lds, p, o, st, pairs, fusions, kept, tasks, masks, rec_offset, out, out_cap, pair_base);
+        const int64_t nh = emit_heavy_of_wave<WRITE, EMIT_SLOTS_LISTED>(&lds, heavy, p, o, st, pairs, fusions, kept, masks, rec_offset, out, out_cap, pair_base);
+        if (!WRITE && mine) rec_count[o] = heavy ? nh : n;
+#ifdef DSA_PRUNE_STATS
+        if (!WRITE && mine) {      // slowest lane: cycles << 24 | n_kept << 8 | n_tasks
+            const unsigned long long dt = __builtin_readcyclecounter() - te0;
+            atomicMax(&g.stats[15], (dt << 24) | ((unsigned long long)st.n_kept << 8) | st.n_tasks);
+        }
+#endif
+    }
 }
 
 }  // namespace dsa
