@@ -210,11 +210,19 @@ struct alignas(8) PairState {
     uint32_t kept_begin;
     uint32_t task_begin;
     uint16_t n_kept;       // kept rows with columns on both sides
-    uint8_t n_tasks;       // saturates at 255 (emit then walks the task list, as it does whenever STATE_TILES is not set)
+    uint8_t n_tasks;       // a window has at most 255 tiles
     uint8_t flags;
-    uint16_t tiles0, tiles1;   // STATE_TILES: the tiles of M1 / M2 that hold a column of a kept row; task t has the t-th set bit of each
-    uint32_t n_tasks_all;
+    uint16_t tiles0, tiles1;   // STATE_TILES: the tiles of M1 / M2 that hold a column of a kept row
+    uint8_t first0, first1;    // tiles of task 0 (NO_CHUNK: none); task t > 0 has the (t-1)-th set bit of the other tiles
+    uint16_t pad_;
 };
+// task index of tile c of a side whose tiles are `tiles` and whose task 0 has tile `first`
+__device__ __forceinline__ int task_of_tile(uint32_t tiles, int first, int c)
+{
+    if (c == first) return 0;
+    const uint32_t rest = first < 16 ? tiles & ~(1u << first) : tiles;
+    return 1 + __builtin_popcount(rest & ((1u << c) - 1u));
+}
 static_assert(sizeof(PairState) == 24, "three 8-byte loads");
 constexpr uint8_t STATE_COUNTED = 1;   // rec_count already holds the pair's record count (combine: no records; fill tail: its only task)
 constexpr uint8_t STATE_TILES = 2;     // tiles0 / tiles1 are valid (windows of at most 16 tiles): emit needs no task list
@@ -999,49 +1007,68 @@ __device__ __forceinline__ void combine_wg(
             n_t1 = small ? (unsigned)__builtin_popcountll(tiles1) : (unsigned)nc1;
         }
     }
-    const unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
-    // offer the first tile pair to the table-driven replay
+    unsigned n_tasks = n_t0 > n_t1 ? n_t0 : n_t1;
+    // Which tile pair does the table-driven replay of this workgroup take for each of its fusions?  All reads of a
+    // fusion have the junction's tiles among theirs, a tie elsewhere is a matter of one read: every pair votes for
+    // each of its tiles, per side, and the pairs that have both winners replay them as their task 0 (any choice
+    // gives the same records: what is left goes to the generic replay, and a tie's tile alone is a short task there).
+    // Votes are 16-bit counters in the LDS words that later serve the replay's counting sort; windows of more
+    // than VOTE_TILES tiles take the first offer of a (lowest M1 tile, lowest M2 tile) instead.
     const int gsel = group_of(wgi, fidx);
-    int key = -1;
-    if (n_tasks > 0 && small && fast_wg && gsel >= 0) {
-        const int c0 = nth_set_bit(tiles0, 0), c1 = nth_set_bit(tiles1, 0);
-        key = ((c0 >= 0 ? c0 : (int)NO_CHUNK) << 8) | (c1 >= 0 ? c1 : (int)NO_CHUNK);
-    }
-    // Per fusion group the most frequent tile pair wins (any choice gives the same records: the pairs that
-    // lose go to the generic replay).  Votes are 16-bit counters in the LDS words that later serve the
-    // replay's counting sort; windows of more than VOTE_TILES tiles take the first offer instead.
-    constexpr int VOTE_TILES = 8, VOTE_KEYS = (VOTE_TILES + 1) * (VOTE_TILES + 1);
-    static_assert(GMAX * VOTE_KEYS <= 2 * 258, "votes must fit the histogram words");
+    int f0 = small ? nth_set_bit(tiles0, 0) : (n_t0 > 0 ? 0 : -1), f1 = small ? nth_set_bit(tiles1, 0) : (n_t1 > 0 ? 0 : -1);   // tiles of task 0
+    const bool eligible = n_tasks > 0 && small && fast_wg && gsel >= 0 && f0 >= 0 && f1 >= 0;
+    const int key = eligible ? ((f0 << 8) | f1) : -1;
+    constexpr int VOTE_TILES = 8;
+    static_assert(GMAX * 2 * VOTE_TILES <= 2 * 258, "votes must fit the histogram words");
     const bool vote = g.nch <= VOTE_TILES && wgi.n_groups <= GMAX;   // uniform
-    auto vote_slot = [&](int k) -> int {
-        const int c0 = k >> 8, c1 = k & 0xFF;
-        return (c0 == (int)NO_CHUNK ? VOTE_TILES : c0) * (VOTE_TILES + 1) + (c1 == (int)NO_CHUNK ? VOTE_TILES : c1);
-    };
     if (vote)
         for (int e = tid; e < 258; e += WG_LANES) fl->hist[e] = 0;
     __syncthreads();
-    if (key >= 0) {
+    if (eligible) {
         if (vote) {
-            const int slot = gsel * VOTE_KEYS + vote_slot(key);
-            atomicAdd(&fl->hist[slot >> 1], 1 << (16 * (slot & 1)));
+            for (uint64_t r = tiles0; r; r &= r - 1) {
+                const int slot = (gsel * 2 + 0) * VOTE_TILES + __builtin_ctzll(r);
+                atomicAdd(&fl->hist[slot >> 1], 1 << (16 * (slot & 1)));
+            }
+            for (uint64_t r = tiles1; r; r &= r - 1) {
+                const int slot = (gsel * 2 + 1) * VOTE_TILES + __builtin_ctzll(r);
+                atomicAdd(&fl->hist[slot >> 1], 1 << (16 * (slot & 1)));
+            }
         } else
             atomicCAS(&fl->tile[gsel], -1, key);
     }
     __syncthreads();
-    if (vote && tid < GMAX) {                                  // one thread per group picks its winner
-        int best = 0, best_slot = -1;
-        for (int e = 0; e < VOTE_KEYS; ++e) {
-            const int slot = tid * VOTE_KEYS + e;
-            const int n = (fl->hist[slot >> 1] >> (16 * (slot & 1))) & 0xFFFF;
-            if (n > best) { best = n; best_slot = e; }
+    if (vote && tid < GMAX) {                                  // one thread per group picks its winners
+        int win[2] = {-1, -1};
+        for (int h = 0; h < 2; ++h) {
+            int best = 0;
+            for (int c = 0; c < VOTE_TILES; ++c) {
+                const int slot = (tid * 2 + h) * VOTE_TILES + c;
+                const int n = (fl->hist[slot >> 1] >> (16 * (slot & 1))) & 0xFFFF;
+                if (n > best) { best = n; win[h] = c; }
+            }
         }
-        if (best_slot >= 0) {
-            const int c0 = best_slot / (VOTE_TILES + 1), c1 = best_slot % (VOTE_TILES + 1);
-            fl->tile[tid] = ((c0 == VOTE_TILES ? (int)NO_CHUNK : c0) << 8) | (c1 == VOTE_TILES ? (int)NO_CHUNK : c1);
-        }
+        if (win[0] >= 0 && win[1] >= 0) fl->tile[tid] = (win[0] << 8) | win[1];
     }
     if (vote) __syncthreads();
-    bool fast = key >= 0 && fl->tile[gsel] == key;
+    bool fast = false;
+    if (eligible) {
+        const int agreed = fl->tile[gsel];
+        if (vote) {
+            // One agreed tile is enough: the side that lacks its tile (a read whose anchor on that side is a few bases and
+            // scores best somewhere else) sits out task 0, and its tiles follow as tasks of their own - short ones, where a
+            // task that pairs them with the other side's junction tile would run the whole read.
+            const bool h0 = agreed >= 0 && ((tiles0 >> (agreed >> 8)) & 1ull), h1 = agreed >= 0 && ((tiles1 >> (agreed & 0xFF)) & 1ull);
+            fast = h0 || h1;
+            if (fast) {
+                f0 = h0 ? agreed >> 8 : -1;
+                f1 = h1 ? agreed & 0xFF : -1;
+                const unsigned s0 = n_t0 + (h0 ? 0u : 1u), s1 = n_t1 + (h1 ? 0u : 1u);
+                n_tasks = s0 > s1 ? s0 : s1;
+            }
+        } else
+            fast = agreed == key;
+    }
     const unsigned n_gen = n_tasks - (fast ? 1u : 0u);
 
     // Sort key of the replays: a pair meets its kept rows at row a in M1 and at row lq - a in M2, so lanes
@@ -1060,7 +1087,7 @@ __device__ __forceinline__ void combine_wg(
         li.kept_begin = (uint32_t)kb;
         li.mask_begin = (uint32_t)mb;
         li.n_kept = (uint16_t)(ok ? n_kept : 0);
-        const int c0 = (key >> 8) & 0xFF, c1 = key & 0xFF;
+        const int c0 = f0 >= 0 ? f0 : (int)NO_CHUNK, c1 = f1 >= 0 ? f1 : (int)NO_CHUNK;
         const bool here = ok && fast;
         const int r0 = c0 != NO_CHUNK ? last_a : 0, r1 = c1 != NO_CHUNK ? lq - first_a : 0;
         li.last_row = here ? (uint16_t)((r0 > r1 ? r0 : r1) | TASK_FAST | (n_tasks == 1 ? TASK_ONLY : 0)) : (uint16_t)0;
@@ -1085,7 +1112,9 @@ __device__ __forceinline__ void combine_wg(
     st.flags = (uint8_t)(((!ok || (HANDOFF && fast && n_tasks == 1)) ? STATE_COUNTED : 0) | (tiles_fit ? STATE_TILES : 0));
     st.tiles0 = (uint16_t)(tiles_fit ? tiles0 : 0);
     st.tiles1 = (uint16_t)(tiles_fit ? tiles1 : 0);
-    st.n_tasks_all = n_tasks;
+    st.first0 = f0 >= 0 ? (uint8_t)f0 : NO_CHUNK;
+    st.first1 = f1 >= 0 ? (uint8_t)f1 : NO_CHUNK;
+    st.pad_ = 0;
     state[p] = st;
     if (!ok) {
         fb.rec_count[g.orig ? g.orig[p] : p] = 0;
@@ -1112,9 +1141,11 @@ __device__ __forceinline__ void combine_wg(
         ++k;
     }
     unsigned gi = 0;
+    const uint64_t rest0 = f0 >= 0 && small ? tiles0 & ~(1ull << f0) : tiles0, rest1 = f1 >= 0 && small ? tiles1 & ~(1ull << f1) : tiles1;
     for (unsigned t = 0; t < n_tasks; ++t) {
-        const int c0 = small ? nth_set_bit(tiles0, (int)t) : (t < n_t0 ? (int)t : -1);
-        const int c1 = small ? nth_set_bit(tiles1, (int)t) : (t < n_t1 ? (int)t : -1);
+        // task 0 has the pair's first tiles (the agreed ones if it has them), the others follow in ascending order
+        const int c0 = small ? (t == 0 ? f0 : nth_set_bit(rest0, (int)t - 1)) : (t < n_t0 ? (int)t : -1);
+        const int c1 = small ? (t == 0 ? f1 : nth_set_bit(rest1, (int)t - 1)) : (t < n_t1 ? (int)t : -1);
         ReplayTask rt;
         rt.pair = (uint32_t)p;
         rt.mask_begin = (uint32_t)(mb + (unsigned long long)t * n_kept);
@@ -1720,7 +1751,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
         int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
         int gq = 0;
 #ifdef DSA_PRUNE_STATS
-        int n_dead_groups = 0;
+        int n_dead_groups = 0, n_immediate = 0, n_immediate_diag = 0;
 #endif
         for (; gq < ngq; ++gq) {
             const uint4 rc = rc_n, b = b_n;
@@ -1817,19 +1848,57 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
 #ifdef DSA_ABLATE_STORES
             }
 #endif
-#ifdef DSA_PRUNE_STATS
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) ++n_dead_groups;
-#endif
 #ifndef DSA_NO_PRUNE
-            if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) {          // wave-uniform
+                if (4 * gq + 3 > l_in) { ++gq; break; }             // a live boundary at row l_in also enters row l_in + 1 (diagonal)
+#ifndef DSA_NO_GAP_SKIP
+                // Nothing in these four rows is alive, so rows further down can only come alive through the boundary
+                // column (a live cell's best predecessor is alive: within the tile that chain would cross these rows).
+                // Until a row group has a live incoming boundary value the sweep is skipped: those groups are all dead
+                // and store V = 0, the lower bound every reader substitutes for dead cells anyway.
+                int g2 = gq + 1;
+                bool resume = false;
+                uint4 bb = b_n;                                     // group gq + 1, already on its way
+                uint32_t in_prev = bv[3];                           // the boundary value of the row above the group: it enters by the diagonal
+                for (; g2 < ngq; ++g2) {
+                    if (g2 > gq + 1) bb = g2 < stop_prev ? bi4[(int64_t)g2 * WAVE] : bias4;
+                    const uint32_t bbv[5] = {in_prev, bb.x, bb.y, bb.z, bb.w};
+                    uint32_t in_bits = 0;
+#pragma unroll
+                    for (int sidx = 0; sidx < 5; ++sidx) {
+                        const int j = 4 * g2 + sidx - 1;
+                        const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
+                        const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
+                        in_bits |= pk_max_u16(bbv[sidx], tm2) ^ tm2;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(in_bits != 0u) != 0) { resume = true; break; }
+                    cm4[(int64_t)g2 * WAVE] = bias4;
+                    bo4[(int64_t)g2 * WAVE] = bias4;
+                    in_prev = bb.w;
+                    if (4 * g2 + 3 > l_in) { ++g2; break; }
+                }
+#ifdef DSA_PRUNE_STATS
+                n_dead_groups += g2 - (gq + 1);
+                if (resume && g2 == gq + 1) ++n_immediate;
+                if (resume && g2 == gq + 1 && __builtin_amdgcn_ballot_w64((pk_max_u16(in_prev, (uint32_t)max(4 * (4 * g2 - 1) - slack + (int)BIAS16 - 1, 0) * 0x00010001u) ^ ((uint32_t)max(4 * (4 * g2 - 1) - slack + (int)BIAS16 - 1, 0) * 0x00010001u)) != 0u) != 0) ++n_immediate_diag;
+#endif
+                if (!resume) { gq = g2; break; }                    // g2 groups are stored
+#pragma unroll
+                for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+                bprev = in_prev;
+                b_n = bb;
+                rc_n = rows4[(int64_t)g2 * WAVE];
+                gq = g2 - 1;
+#endif
+            }
 #endif
         }
 #ifdef DSA_PRUNE_STATS
         if (lane == 0) {
             atomicAdd(&g.stats[14], (unsigned long long)n_dead_groups);
+            atomicAdd(&g.stats[2], (unsigned long long)n_immediate | ((unsigned long long)n_immediate_diag << 32));
             atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
             atomicAdd(&g.stats[1], (unsigned long long)ngq);
-            atomicAdd(&g.stats[2], (unsigned long long)l_in);
         }
 #endif
         // the dead remainder of the tile is not stored: its readers substitute V = 0 past the stop
@@ -1889,11 +1958,14 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                                                    const uint32_t* __restrict__ refcodes,
                                                    const uint32_t* __restrict__ rowcodes,
                                                    const uint32_t* __restrict__ bnd, const int32_t* __restrict__ tstop,
+                                                   const int32_t* __restrict__ min_score_tab,
                                                    uint64_t* __restrict__ masks, uint64_t mask_cap, Geom g)
 {
     __shared__ int s_hist[258];
     __shared__ unsigned short s_order[REPLAY_BLOCK];
     __shared__ ReplayTask s_task[REPLAY_BLOCK];
+    __shared__ uint64_t s_kc[KCACHE * REPLAY_BLOCK];   // the first kept rows of every lane's pair: the cursors advance without a global load
+    static_assert(REPLAY_BLOCK == WG_LANES, "kept_row() strides the cache by WG_LANES");
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
     for (unsigned long long base = (unsigned long long)blockIdx.x * REPLAY_BLOCK; base < n_g;
@@ -1921,8 +1993,10 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
         __syncthreads();
         const int src = s_order[threadIdx.x];
-        if (base + src >= n_g) continue;                  // sorted last: whole waves drop out together
-        const ReplayTask rt = s_task[src];
+        const bool valid = base + src < n_g;              // sorted last; a lane without a task walks along idle (the wave's decisions below are uniform)
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        ReplayTask rt = s_task[valid ? src : s_order[0]];
+        if (!valid) { rt.last_row = 0; rt.chunk0 = rt.chunk1 = NO_CHUNK; }
 #ifdef DSA_PRUNE_STATS
         const unsigned long long tr0 = __builtin_readcyclecounter();
 #endif
@@ -1933,8 +2007,11 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
         const uint32_t* rc = refcodes + (int64_t)rt.fusion * g.lrp;      // the 64 loads below need nothing but the task
         const dsa_fusion fu = fusions[rt.fusion];
-        const PairState st = state[p];
-        const int lq = pairs[p].read_len;
+        PairState st = state[p];
+        if (!valid) st.n_kept = 0;
+        const dsa_pair pr = pairs[p];
+        const int lq = pr.read_len;
+        const int slack = 2 * lq - max(min_score_tab[lq], pair_bound(pr));     // as in the fill kernels
         const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
         const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
         const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
@@ -1955,7 +2032,16 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
         // kept rows ascend in a: M1 (row a) meets them in order k=0.., M2 (row lq-a) in reverse
-        HitCursor hc = cursor_init(kr, nullptr, st.n_kept, lq, has0, has1, nv0, nv1);
+        {
+            const uint2* kr2 = reinterpret_cast<const uint2*>(kr);
+            uint2 first[KCACHE];
+#pragma unroll
+            for (int k = 0; k < KCACHE; ++k) first[k] = kr2[k < (int)st.n_kept ? k : (int)st.n_kept - 1];
+#pragma unroll
+            for (int k = 0; k < KCACHE; ++k) s_kc[k * REPLAY_BLOCK + threadIdx.x] = ((uint64_t)first[k].y << 32) | first[k].x;
+        }
+        const uint64_t* kc = s_kc + threadIdx.x;
+        HitCursor hc = cursor_init(kr, kc, st.n_kept, lq, has0, has1, nv0, nv1);
         const int stop0 = c0 > 0 ? tstop[w * g.nch + (c0 - 1)] : 0;   // stored row groups of the tiles to the left
         const int stop1 = c1 > 0 ? tstop[w * g.nch + (c1 - 1)] : 0;
         // four rows per step: one dwordx4 of row codes and of either boundary, fetched one step ahead
@@ -1970,19 +2056,42 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                               (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
         };
         const int ngq = (R >> 2) + 1;
+        int ngq_w = ngq;                                  // the wave sweeps as many row groups as its longest lane
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ngq_w = max(ngq_w, __shfl_xor(ngq_w, d, 64));
         // the lanes of a wave read different planes (64 cache lines per load): operands are fetched two steps ahead
-        uint4 rc_n = rows4[0], rc_nn = rows4[(int64_t)(1 < ngq ? 1 : 0) * WAVE];
-        uint4 b_n = boundary(0), b_nn = boundary(1 < ngq ? 1 : 0);
+        auto grp = [&](int gq) -> int { return gq < ngq ? gq : ngq - 1; };
+        uint4 rc_n = rows4[0], rc_nn = rows4[(int64_t)grp(1) * WAVE];
+        uint4 b_n = boundary(0), b_nn = boundary(grp(1));
+        // per field: the liveness threshold of row j (fill kernels, exact pruning), 0xFFFF where the lane has nothing to replay
+        auto thr2 = [&](int j) -> uint32_t {
+            const uint32_t t1 = (uint32_t)max(4 * j - slack + (int)BIAS16 - 1, 0);
+            const bool on = j <= R;
+            return ((on && has0) ? t1 : 0xFFFFu) | (((on && has1) ? t1 : 0xFFFFu) << 16);
+        };
+        // kept rows of skipped rows have no column in this tile pair
+        auto skip_hits = [&](int hi_row) {
+            while (hc.row0 >= 0 && hc.row0 <= hi_row) {
+                masks[((uint64_t)rt.mask_begin + hc.k0) * 2] = 0;
+                ++hc.k0;
+                cursor_next0(hc, kr, kc, st.n_kept, has0);
+            }
+            while (hc.row1 >= 0 && hc.row1 <= hi_row) {
+                masks[((uint64_t)rt.mask_begin + hc.k1) * 2 + 1] = 0;
+                --hc.k1;
+                cursor_next1(hc, kr, kc, lq, has1);
+            }
+        };
 #ifdef DSA_PRUNE_STATS
         const unsigned long long tr1 = __builtin_readcyclecounter();
+        int n_swept = 0;
 #endif
-        for (int gq = 0; gq < ngq; ++gq) {
+        for (int gq = 0; gq < ngq_w; ++gq) {              // uniform
             const uint4 rcq = rc_n, b = b_n;
-            const int gn = gq + 2 < ngq ? gq + 2 : ngq - 1;
             rc_n = rc_nn;
             b_n = b_nn;
-            rc_nn = rows4[(int64_t)gn * WAVE];
-            b_nn = boundary(gn);
+            rc_nn = rows4[(int64_t)grp(gq + 2) * WAVE];
+            b_nn = boundary(grp(gq + 2));
             const uint32_t rcv[4] = {rcq.x, rcq.y, rcq.z, rcq.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx) {
@@ -1990,23 +2099,66 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                 const uint32_t bcur = bv[sidx];
                 if (j >= 1 && j <= R) {
                     row_step(X, r, rcv[sidx], bprev, bcur);
-                    record_hits(X, j, lq, kr, nullptr, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+                    record_hits(X, j, lq, kr, kc, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
                 }
                 bprev = bcur;
             }
+#ifdef DSA_PRUNE_STATS
+            ++n_swept;
+#endif
+#ifndef DSA_NO_GAP_SKIP
+            // As in the fill kernels: once the last of these rows is dead in every lane, rows further down only come alive
+            // through the boundary column, and the sweep resumes (from V = 0) at the first row group with a live incoming
+            // value.  A tie's tile next to the junction tile is dead until the alignment reaches it in its last rows.
+            if (gq + 1 < ngq_w) {
+                const uint32_t tm2 = thr2(4 * gq + 3);
+                const bool alive = (pk_max_u16(tile_row_max<false>(X, W, W), tm2) ^ tm2) != 0u;
+                if (__builtin_amdgcn_ballot_w64(alive) == 0) {      // uniform
+                    int g2 = gq + 1;
+                    bool resume = false;
+                    uint4 bb = b_n;
+                    uint32_t in_prev = bv[3];
+                    for (; g2 < ngq_w; ++g2) {
+                        if (g2 > gq + 1) bb = boundary(grp(g2));
+                        const uint32_t bbv[5] = {in_prev, bb.x, bb.y, bb.z, bb.w};
+                        uint32_t in_bits = 0;
+#pragma unroll
+                        for (int sidx = 0; sidx < 5; ++sidx) {
+                            const uint32_t t2 = thr2(4 * g2 + sidx - 1);
+                            in_bits |= pk_max_u16(bbv[sidx], t2) ^ t2;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(in_bits != 0u) != 0) { resume = true; break; }
+                        skip_hits(4 * g2 + 3);
+                        in_prev = bb.w;
+                    }
+                    if (!resume) break;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
+                    bprev = in_prev;
+                    rc_n = rows4[(int64_t)grp(g2) * WAVE];
+                    rc_nn = rows4[(int64_t)grp(g2 + 1) * WAVE];
+                    b_n = bb;
+                    b_nn = boundary(grp(g2 + 1));
+                    gq = g2 - 1;
+                }
+            }
+#endif
         }
         // sides that were not replayed report no columns
-        if (!has0)
+        if (valid && !has0)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
-        if (!has1)
+        if (valid && !has1)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
 #ifdef DSA_PRUNE_STATS
-        if ((threadIdx.x & 63) == 0) {
-            const unsigned long long tr2 = __builtin_readcyclecounter();
-            atomicAdd(&g.stats[10], tr1 - tr0);
-            atomicAdd(&g.stats[11], tr2 - tr1);
-            atomicAdd(&g.stats[12], 1ull);
-            atomicAdd(&g.stats[13], (unsigned long long)ngq);
+        {
+            const int ngq_wave = n_swept;
+            if ((threadIdx.x & 63) == 0) {
+                const unsigned long long tr2 = __builtin_readcyclecounter();
+                atomicAdd(&g.stats[10], tr1 - tr0);
+                atomicAdd(&g.stats[11], tr2 - tr1);
+                atomicAdd(&g.stats[12], 1ull);
+                atomicAdd(&g.stats[13], (unsigned long long)ngq_wave);
+            }
         }
 #endif
     }
@@ -2125,38 +2277,40 @@ __device__ __forceinline__ int64_t emit_pair(EmitLds<SLOTS>* lds, int64_t p, int
                 }
             }
         }
-    } else if (tiles && K * T <= SLOTS) {
-        // Task t holds the t-th tile of either bitmap, so column i1 of task t1 can only recur in task t1's mask of an
-        // earlier kept row: the de-dup (same refSplit <=> same (i1,i2) at an earlier kept a) is two bit tests per
-        // earlier row.  The masks of the pair are one block of memory.
+    } else if (tiles) {
+        // Every tile is in one task only, so column i1 of a tile can only recur in the same task's mask of an earlier
+        // kept row: the de-dup (same refSplit <=> same (i1,i2) at an earlier kept a) is two bit tests per earlier
+        // row.  The masks of the pair are one block of memory, [task][kept row]; tiles are walked in ascending order.
         const uint4* masks4 = reinterpret_cast<const uint4*>(masks) + st.mask_begin;
-        const int slots = K * T;
         const uint2* kept2 = reinterpret_cast<const uint2*>(kept) + st.kept_begin;
-        // in growing groups, each with all its loads in flight: most pairs have one or two
+        const int slots = K * T;
+        const bool staged = slots <= SLOTS;
+        if (staged) {
+            // in growing groups, each with all its loads in flight: most pairs have one or two
 #pragma unroll
-        for (int e0 = 0, e1 = 2; e0 < SLOTS; e0 = e1, e1 *= 2) {
-            if (e0 == 0 || slots > e0) {
+            for (int e0 = 0, e1 = 2; e0 < SLOTS; e0 = e1, e1 *= 2) {
+                if (e0 == 0 || slots > e0) {
 #pragma unroll
-                for (int e = e0; e < e1 && e < SLOTS; ++e) {
-                    lds->mask[e][tid] = masks4[e < slots ? e : slots - 1];
-                    lds->kept[e][tid] = kept2[e < K ? e : K - 1];
+                    for (int e = e0; e < e1 && e < SLOTS; ++e) {
+                        lds->mask[e][tid] = masks4[e < slots ? e : slots - 1];
+                        lds->kept[e][tid] = kept2[e < K ? e : K - 1];
+                    }
                 }
             }
         }
+        // pairs with more masks than a lane stages (and that no wave took) walk global memory
         auto mask_of = [&](int k, int t, int h) -> uint64_t {
-            const uint4 v = lds->mask[t * K + k][tid];
+            const uint4 v = staged ? lds->mask[t * K + k][tid] : masks4[t * K + k];
             return h ? ((uint64_t)v.w << 32) | v.z : ((uint64_t)v.y << 32) | v.x;
         };
         for (int k = 0; k < K; ++k) {
-            const KeptRow kr = __builtin_bit_cast(KeptRow, lds->kept[k][tid]);
-            int t1 = 0;
-            for (uint32_t w0 = st.tiles0; w0; w0 &= w0 - 1, ++t1) {
-                const int c0 = __builtin_ctz(w0);
+            const KeptRow kr = __builtin_bit_cast(KeptRow, staged ? lds->kept[k][tid] : kept2[k]);
+            for (uint32_t w0 = st.tiles0; w0; w0 &= w0 - 1) {
+                const int c0 = __builtin_ctz(w0), t1 = task_of_tile(st.tiles0, st.first0, c0);
                 for (uint64_t r1 = mask_of(k, t1, 0); r1; r1 &= r1 - 1) {
                     const int b1 = __builtin_ctzll(r1);
-                    int t2 = 0;
-                    for (uint32_t w1 = st.tiles1; w1; w1 &= w1 - 1, ++t2) {
-                        const int c1 = __builtin_ctz(w1);
+                    for (uint32_t w1 = st.tiles1; w1; w1 &= w1 - 1) {
+                        const int c1 = __builtin_ctz(w1), t2 = task_of_tile(st.tiles1, st.first1, c1);
                         for (uint64_t r2 = mask_of(k, t2, 1); r2; r2 &= r2 - 1) {
                             const int b2 = __builtin_ctzll(r2);
                             bool dup = false;
@@ -2168,7 +2322,8 @@ __device__ __forceinline__ int64_t emit_pair(EmitLds<SLOTS>* lds, int64_t p, int
             }
         }
     } else {
-        const uint32_t tb = st.task_begin, te = tb + st.n_tasks_all;
+        // windows of more than 16 tiles: the task list, whose tiles ascend (task 0 has the lowest of either side)
+        const uint32_t tb = st.task_begin, te = tb + st.n_tasks;
         for (int k = 0; k < K; ++k) {
             const KeptRow kr = kept[st.kept_begin + k];
             for (uint32_t q1 = tb; q1 < te; ++q1) {        // tasks hold M1 tiles in ascending order
@@ -2202,7 +2357,7 @@ __device__ __forceinline__ int64_t emit_pair(EmitLds<SLOTS>* lds, int64_t p, int
 // its row's records: the order is that of emit_pair.  Called by all 64 lanes with the same arguments.
 template <bool WRITE, int SLOTS>
 __device__ __forceinline__ int64_t emit_pair_wave(EmitLds<SLOTS>* lds, int64_t p, int64_t o, uint32_t mask_begin, uint32_t kept_begin, int K, int T,
-                                                  uint32_t tiles0, uint32_t tiles1, const dsa_pair* __restrict__ pairs,
+                                                  uint32_t tiles0, uint32_t tiles1, int first0, int first1, const dsa_pair* __restrict__ pairs,
                                                   const dsa_fusion* __restrict__ fusions, const KeptRow* __restrict__ kept,
                                                   const uint64_t* __restrict__ masks, const int64_t* __restrict__ rec_offset,
                                                   dsa_record* __restrict__ out, uint64_t out_cap, int64_t pair_base)
@@ -2240,14 +2395,12 @@ __device__ __forceinline__ int64_t emit_pair_wave(EmitLds<SLOTS>* lds, int64_t p
     }
     // the records of kept row k, handed to fn(i1, i2) in output order
     auto row = [&](int k, auto&& fn) {
-        int t1 = 0;
-        for (uint32_t w0 = tiles0; w0; w0 &= w0 - 1, ++t1) {
-            const int c0 = __builtin_ctz(w0);
+        for (uint32_t w0 = tiles0; w0; w0 &= w0 - 1) {
+            const int c0 = __builtin_ctz(w0), t1 = task_of_tile(tiles0, first0, c0);
             for (uint64_t r1 = mask_of(k, t1, 0); r1; r1 &= r1 - 1) {
                 const int b1 = __builtin_ctzll(r1);
-                int t2 = 0;
-                for (uint32_t w1 = tiles1; w1; w1 &= w1 - 1, ++t2) {
-                    const int c1 = __builtin_ctz(w1);
+                for (uint32_t w1 = tiles1; w1; w1 &= w1 - 1) {
+                    const int c1 = __builtin_ctz(w1), t2 = task_of_tile(tiles1, first1, c1);
                     for (uint64_t r2 = mask_of(k, t2, 1); r2; r2 &= r2 - 1) {
                         const int b2 = __builtin_ctzll(r2);
                         bool dup = false;
@@ -2297,6 +2450,9 @@ template <int SLOTS>
 __device__ __forceinline__ bool emit_is_heavy(const PairState& st)
 {
     const int slots = (int)st.n_kept * (int)st.n_tasks;
+#ifdef DSA_NO_HEAVY
+    return false;
+#endif
     if (st.n_tasks == 1 && st.n_kept <= EMIT_REG_ROWS) return false;
     return (st.flags & STATE_TILES) != 0 && slots > SLOTS && slots <= 64 * SLOTS;
 }
@@ -2318,8 +2474,9 @@ __device__ __forceinline__ int64_t emit_heavy_of_wave(EmitLds<SLOTS>* lds, bool 
         const uint32_t mb = (uint32_t)__shfl((int)st.mask_begin, src, 64), kb = (uint32_t)__shfl((int)st.kept_begin, src, 64);
         const int packed = __shfl((int)st.n_kept | ((int)st.n_tasks << 16), src, 64);
         const int tl = __shfl((int)st.tiles0 | ((int)st.tiles1 << 16), src, 64);
+        const int firsts = __shfl((int)st.first0 | ((int)st.first1 << 8), src, 64);
         const int64_t n = emit_pair_wave<WRITE, SLOTS>(lds, sp, so, mb, kb, packed & 0xFFFF, (packed >> 16) & 0xFF, (uint32_t)tl & 0xFFFFu,
-                                                        (uint32_t)tl >> 16, pairs, fusions, kept, masks, rec_offset, out, out_cap, pair_base);
+                                                        (uint32_t)tl >> 16, firsts & 0xFF, (firsts >> 8) & 0xFF, pairs, fusions, kept, masks, rec_offset, out, out_cap, pair_base);
         if ((int)(threadIdx.x & 63) == src) mine = n;
     }
     return mine;
