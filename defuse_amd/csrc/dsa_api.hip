@@ -70,6 +70,8 @@ struct PipeLane {
     bool emit_pending = false;  // phase 2 launched, its time not yet accounted
     bool emit_early = false;    // phase 1 already wrote the slice's records, into room for emit_cap of them
     uint64_t emit_cap = 0;
+    int emit_from = 5;          // event that marks the start of the emit in flight
+    bool copied_descriptors = false;   // phase 1 of the slice in flight uploaded its descriptors (ev[0]..ev[4] time that)
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
     DevBuf<uint32_t> d_wg_generic;
@@ -128,6 +130,13 @@ struct Slice {
     std::vector<WgInfo> wgs;         // one per 256 pairs
     std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GSPLIT2 fusions)
     Geom g{};
+    // workgroups per table tier of k_fill_fast (an instantiation without workgroups is not launched)
+    void tiers(int64_t (&n)[3]) const
+    {
+        n[0] = n[1] = n[2] = 0;
+        for (size_t k = 0; k < wgs.size(); ++k)
+            if (!wg_flags[k]) ++n[tier_of(wgs[k].n_groups)];
+    }
 };
 
 }  // namespace
@@ -501,12 +510,13 @@ FinishBufs finish_bufs(PipeLane& L)
 // the records of a slice, behind those of the earlier slices (ev[5]..ev[6] time it): the pairs counted in the fill
 // kernel's tail by a per-pair launch, the others through the generic replay's task list
 constexpr unsigned LISTED_GRID = 1024;
-void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left)
+void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, bool record_start = true)
 {
     const int64_t np = s.g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     dsa_record* out = ctx->d_records.p + ctx->n_records;
-    (void)hipEventRecord(L.ev[5], L.stream);
+    L.emit_from = record_start ? 5 : 3;
+    if (record_start) (void)hipEventRecord(L.ev[5], L.stream);      // (every event between two kernels is a gap of a few microseconds)
     // the listed pairs' kernel is a few latency-bound waves, the counted pairs' one streams: side by side
     (void)hipEventRecord(L.ev_fork, L.stream);
     (void)hipStreamWaitEvent(L.aux, L.ev_fork, 0);
@@ -537,18 +547,25 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     const int64_t np = g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     const FinishBufs fb = finish_bufs(L);
-    HIPC(hipMemsetAsync(L.d_ctr.p, 0, sizeof(Counters), st));
+    // (own kernels rather than hipMemsetAsync for the words that must be zero, and rather than copy commands for the
+    // results: every command between two kernels costs a gap of its own on the stream)
+    hipLaunchKernelGGL(k_reset_finish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_count.p + np);
     HIPC(hipEventRecord(L.ev[1], st));
-    // every workgroup is run by exactly one of the two fill kernels
-    hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                       L.d_tmask.p, fb, g);
-    hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                       L.d_tmask.p, fb, g);
-    hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                       ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                       L.d_tmask.p, fb, g);
+    // every workgroup is run by exactly one of the fill kernels
+    int64_t n_tier[3];
+    s.tiers(n_tier);
+    if (n_tier[0])
+        hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                           L.d_tmask.p, fb, g);
+    if (n_tier[1])
+        hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                           L.d_tmask.p, fb, g);
+    if (n_tier[2])
+        hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
+                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
+                           L.d_tmask.p, fb, g);
     hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,
                        L.d_wg_generic.p, ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
                        L.d_tmask.p, fb, g);
@@ -560,8 +577,9 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr,
                        (uint64_t)0, (int64_t)s.pair_begin, g);
-    HIPC(hipMemsetAsync(L.d_rec_count.p + np, 0, sizeof(int64_t), st));
     if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
+    // the cursors and the record total go to the lane's pinned result words
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_offset.p + np, &L.host->ctr, &L.host->n_rec);
     HIPC(hipEventRecord(L.ev[3], st));
     // The first slice of a run knows where its records go: write them right away, into the room there is, without
     // waiting for the host to read the total (phase2 runs the emit again after growing the buffer if it was short).
@@ -570,10 +588,8 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     if (ctx->n_records == 0 && &s == &ctx->slices.front() && ctx->d_records.cap > 0) {
         L.emit_cap = ctx->d_records.cap;
         L.emit_early = true;
-        launch_emit(ctx, L, s, L.emit_cap);
+        launch_emit(ctx, L, s, L.emit_cap, false);        // ev[3] just recorded is its start
     }
-    HIPC(hipMemcpyAsync(&L.host->ctr, L.d_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(&L.host->n_rec, L.d_rec_offset.p + np, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPC(hipGetLastError());
     return DSA_OK;
 }
@@ -604,18 +620,19 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_tasks.reserve((size_t)np * 4 + 1024));
     HIPC(L.d_masks.reserve((size_t)np * 8 + 1024));
     HIPC(L.d_gtasks.reserve((size_t)np * 2 + 1024));
-    HIPC(hipEventRecord(L.ev[0], st));
     // The wave / workgroup descriptors are inputs of the batch like the pairs themselves: a batch that is run
     // again finds them on the device (the generic flags the fill kernel may have set for it stay valid too).
     // All packing (reference codes here, row codes inside the fill) is redone by every run.
-    if (L.resident_upload != ctx->upload_serial || L.resident_slice != slice_idx) {
+    L.copied_descriptors = L.resident_upload != ctx->upload_serial || L.resident_slice != slice_idx;
+    if (L.copied_descriptors) {
+        HIPC(hipEventRecord(L.ev[0], st));
         HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
         HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
         HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         L.resident_upload = ctx->upload_serial;
         L.resident_slice = slice_idx;
+        HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
     }
-    HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
     if (int rc = launch_compute(ctx, L, s)) return rc;
     L.slice = slice_idx;
     return DSA_OK;
@@ -625,7 +642,7 @@ void account_emit(dsa_ctx* ctx, PipeLane& L)
 {
     if (!L.emit_pending) return;
     (void)hipEventSynchronize(L.ev[6]);
-    ctx->timing.finish_ms += elapsed(L.ev[5], L.ev[6]);
+    ctx->timing.finish_ms += elapsed(L.ev[L.emit_from], L.ev[6]);
     L.emit_pending = false;
 }
 
@@ -698,9 +715,9 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     }
 #endif
     const int64_t n_rec = L.host->n_rec;
-    ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
+    if (L.copied_descriptors) ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
     if (!(L.emit_early && (uint64_t)n_rec <= L.emit_cap)) {
-        if (L.emit_early) ctx->timing.finish_ms += elapsed(L.ev[5], L.ev[6]);     // the short attempt was work too
+        if (L.emit_early) ctx->timing.finish_ms += elapsed(L.ev[L.emit_from], L.ev[6]);     // the short attempt was work too
         if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
         launch_emit(ctx, L, s, ctx->d_records.cap - ctx->n_records);
     }

@@ -2164,6 +2164,25 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
     }
 }
 
+// the device cursors of a slice and the slot behind its last record count, zeroed before the fill
+__global__ void k_reset_finish(Counters* ctr, int64_t* rec_count_end)
+{
+    if (threadIdx.x == 0) {
+        ctr->n_kept = ctr->n_tasks = ctr->n_masks = ctr->n_gtasks = 0;
+        *rec_count_end = 0;
+    }
+}
+
+// the cursors and the record total of a slice, stored into pinned host memory at the end of its phase 1
+__global__ void k_publish(const Counters* __restrict__ ctr, const int64_t* __restrict__ n_rec, Counters* host_ctr, int64_t* host_n_rec)
+{
+    if (threadIdx.x == 0) {
+        *host_ctr = *ctr;
+        *host_n_rec = *n_rec;
+        __threadfence_system();
+    }
+}
+
 // K4: emit.  For every kept split a (ascending) the cross product columns1 x columns2 in ascending
 // order (tools/SplitReadAligner.cpp:233-269), then the refSplit de-duplication of
 // tools/SplitAlignment.cpp:381-391 (first occurrence wins).  WRITE=false counts.
