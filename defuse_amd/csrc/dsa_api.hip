@@ -572,7 +572,7 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     HIPC(hipEventRecord(L.ev[2], st));
     hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
-                       ctx->d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, ctx->d_min_score.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
+                       ctx->d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
     hipLaunchKernelGGL(k_emit_listed<false>, dim3(LISTED_GRID), dim3(EMIT_BLOCK), 0, st, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr,

@@ -1940,15 +1940,57 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
 #endif
 }
 
-// K3g: replay one tile pair per lane from the stored boundaries (generic scoring, any pair mix); for
-// every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row
-// maximum (lo field: M1 tile chunk0, hi field: M2 tile chunk1).  Covers the device list of tasks the
-// table-driven replay left over.  A block takes REPLAY_BLOCK consecutive tasks and hands them to its
-// lanes in order of their last row (counting sort in LDS): two tasks in three are the second tile of a
-// tie on a short side and need a dozen rows, and a wave sweeps as many rows as its longest lane; a
-// one-sided task also meets its kept row in its last row, so the lanes of a wave extract together.
+// K3g: replay the tile pairs the table-driven replay left over, from the stored boundaries (generic scoring, any pair
+// mix); for every kept row of the pair report, as 64-bit masks, the valid columns whose value equals the row maximum
+// (lo field: M1 tile chunk0, hi field: M2 tile chunk1).
+// FOUR LANES PER TASK: the kernel is as long as its longest task (a junction on a tile boundary needs the neighbour tile up
+// to the read's last rows), and one lane sweeping 64 columns takes 1.7 us per row.  Lane q of a task holds columns
+// 16q..16q+15 and runs one row behind lane q-1, whose last column it receives through a cross-lane move: a quarter is a
+// 16-column tile whose left boundary comes from its neighbour (quarter 0: from the stored boundary column), so the
+// recurrence is that of the fill, and a task of R rows takes R + 3 steps of a quarter of the work.
+// A block takes REPLAY_TASKS consecutive tasks and hands them to its lane groups in order of their last row (counting
+// sort in LDS): two tasks in three are the second tile of a tie on a short side and need a dozen rows, and a wave steps
+// as long as its longest task.
 constexpr int REPLAY_BLOCK = 256;
-__global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+constexpr int RQ = 4;                          // lanes per task
+constexpr int RW = W / RQ;                     // columns per lane
+constexpr int REPLAY_TASKS = REPLAY_BLOCK / RQ;
+
+// row step of RW columns, generic scoring (row_step of the fill's generic kernel, narrower)
+__device__ __forceinline__ void row_step_quarter(uint32_t (&X)[RW], const uint32_t (&r)[RW], uint32_t cj, uint32_t bprev, uint32_t bcur)
+{
+    cj &= CODE_MASK;
+    uint32_t d[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) d[k] = k + 1 < RW ? SIX2 - min3u(cj ^ r[k + 1]) : 0u;
+    uint32_t a = (bprev + FOUR2) - min3u(cj ^ r[0]);
+    uint32_t up = bcur - TWO2;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const uint32_t a_next = X[i] + d[i];
+        X[i] = max3(a, X[i], up);
+        up = X[i];
+        a = a_next;
+    }
+}
+
+// hit bits of the quarter's columns: bit k = column k equals the lo target, bit 16 + k = the hi target (equal_columns)
+__device__ __forceinline__ uint32_t equal_columns_quarter(const uint32_t (&X)[RW], uint32_t target2)
+{
+    static_assert(RW == 16, "one accumulator word");
+    const uint32_t below = target2 - 0x00010001u;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = RW - 1; k >= 0; --k) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const uint32_t c = below + drift2(k);
+        const uint32_t y = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, X[k]), __builtin_bit_cast(us2, c)));
+        asm("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(acc) : "v"(y));
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(REPLAY_BLOCK) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
                                                    const uint2* __restrict__ gtasks, uint64_t gtask_cap,
                                                    const Counters* __restrict__ ctr,
                                                    const PairState* __restrict__ state,
@@ -1958,28 +2000,31 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
                                                    const uint32_t* __restrict__ refcodes,
                                                    const uint32_t* __restrict__ rowcodes,
                                                    const uint32_t* __restrict__ bnd, const int32_t* __restrict__ tstop,
-                                                   const int32_t* __restrict__ min_score_tab,
                                                    uint64_t* __restrict__ masks, uint64_t mask_cap, Geom g)
 {
     __shared__ int s_hist[258];
-    __shared__ unsigned short s_order[REPLAY_BLOCK];
-    __shared__ ReplayTask s_task[REPLAY_BLOCK];
+    __shared__ unsigned short s_order[REPLAY_TASKS];
+    __shared__ ReplayTask s_task[REPLAY_TASKS];
     __shared__ uint64_t s_kc[KCACHE * REPLAY_BLOCK];   // the first kept rows of every lane's pair: the cursors advance without a global load
     static_assert(REPLAY_BLOCK == WG_LANES, "kept_row() strides the cache by WG_LANES");
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * REPLAY_BLOCK; base < n_g;
-         base += (unsigned long long)gridDim.x * REPLAY_BLOCK) {                 // uniform per block
+    const int q = threadIdx.x & (RQ - 1);             // quarter of the tile
+    const int slot = threadIdx.x / RQ;                // task slot of the block
+    for (unsigned long long base = (unsigned long long)blockIdx.x * REPLAY_TASKS; base < n_g;
+         base += (unsigned long long)gridDim.x * REPLAY_TASKS) {                 // uniform per block
         __syncthreads();                                  // previous round's LDS no longer in use
         for (int e = threadIdx.x; e < 258; e += REPLAY_BLOCK) s_hist[e] = 0;
         __syncthreads();
         int my_key = 256, my_rank = 0;
-        if (base + threadIdx.x < n_g) {
-            const ReplayTask mine = tasks[gtasks[base + threadIdx.x].x & ~GTASK_OWNER];
-            s_task[threadIdx.x] = mine;
-            my_key = min((int)(mine.last_row & TASK_ROW), 255);
+        if (threadIdx.x < REPLAY_TASKS) {
+            if (base + threadIdx.x < n_g) {
+                const ReplayTask mine = tasks[gtasks[base + threadIdx.x].x & ~GTASK_OWNER];
+                s_task[threadIdx.x] = mine;
+                my_key = min((int)(mine.last_row & TASK_ROW), 255);
+            }
+            my_rank = atomicAdd(&s_hist[my_key], 1);
         }
-        my_rank = atomicAdd(&s_hist[my_key], 1);
         __syncthreads();
         if (threadIdx.x == 0) {
             int run = 0;
@@ -1990,10 +2035,10 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
             }
         }
         __syncthreads();
-        s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
+        if (threadIdx.x < REPLAY_TASKS) s_order[s_hist[my_key] + my_rank] = (unsigned short)threadIdx.x;
         __syncthreads();
-        const int src = s_order[threadIdx.x];
-        const bool valid = base + src < n_g;              // sorted last; a lane without a task walks along idle (the wave's decisions below are uniform)
+        const int src = s_order[slot];
+        const bool valid = base + src < n_g;              // sorted last; a lane group without a task steps along idle
         if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
         ReplayTask rt = s_task[valid ? src : s_order[0]];
         if (!valid) { rt.last_row = 0; rt.chunk0 = rt.chunk1 = NO_CHUNK; }
@@ -2005,29 +2050,26 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
         const int lane = (int)(p & 63);
         const bool has0 = rt.chunk0 != NO_CHUNK, has1 = rt.chunk1 != NO_CHUNK;
         const int c0 = has0 ? rt.chunk0 : 0, c1 = has1 ? rt.chunk1 : 0;
-        const uint32_t* rc = refcodes + (int64_t)rt.fusion * g.lrp;      // the 64 loads below need nothing but the task
+        const uint32_t* rc = refcodes + (int64_t)rt.fusion * g.lrp;      // the loads below need nothing but the task
         const dsa_fusion fu = fusions[rt.fusion];
         PairState st = state[p];
         if (!valid) st.n_kept = 0;
-        const dsa_pair pr = pairs[p];
-        const int lq = pr.read_len;
-        const int slack = 2 * lq - max(min_score_tab[lq], pair_bound(pr));     // as in the fill kernels
+        const int lq = pairs[p].read_len;
         const uint32_t* rows = rowcodes + w * g.lq1 * WAVE;
         const uint32_t* bi0 = bnd + (w * g.nch + (c0 - 1)) * g.lq1 * WAVE;
         const uint32_t* bi1 = bnd + (w * g.nch + (c1 - 1)) * g.lq1 * WAVE;
         const KeptRow* kr = kept + st.kept_begin;
 
-        uint32_t r[W];
+        uint32_t r[RW];
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            const uint32_t lo = has0 ? (rc[c0 * W + i] & 0xFFFFu) : REF_PAD16;
-            const uint32_t hi = has1 ? (rc[c1 * W + i] & 0xFFFF0000u) : (REF_PAD16 << 16);
+        for (int i = 0; i < RW; ++i) {
+            const uint32_t lo = has0 ? (rc[c0 * W + q * RW + i] & 0xFFFFu) : REF_PAD16;
+            const uint32_t hi = has1 ? (rc[c1 * W + q * RW + i] & 0xFFFF0000u) : (REF_PAD16 << 16);
             r[i] = lo | hi;
         }
-        uint32_t X[W];
+        uint32_t X[RW];
 #pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-        uint32_t bprev = BIAS2;
+        for (int i = 0; i < RW; ++i) X[i] = BIAS2 + drift2(i);
         const int R = rt.last_row & TASK_ROW;
         const int nv0 = has0 ? min(W, fu.ref0_len - c0 * W) : 0;
         const int nv1 = has1 ? min(W, fu.ref1_len - c1 * W) : 0;
@@ -2036,129 +2078,76 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 2) void k_replay(const ReplayTask* __
             const uint2* kr2 = reinterpret_cast<const uint2*>(kr);
             uint2 first[KCACHE];
 #pragma unroll
-            for (int k = 0; k < KCACHE; ++k) first[k] = kr2[k < (int)st.n_kept ? k : (int)st.n_kept - 1];
+            for (int k = 0; k < KCACHE; ++k) first[k] = kr2[k < (int)st.n_kept ? k : (st.n_kept ? (int)st.n_kept - 1 : 0)];
 #pragma unroll
             for (int k = 0; k < KCACHE; ++k) s_kc[k * REPLAY_BLOCK + threadIdx.x] = ((uint64_t)first[k].y << 32) | first[k].x;
         }
         const uint64_t* kc = s_kc + threadIdx.x;
         HitCursor hc = cursor_init(kr, kc, st.n_kept, lq, has0, has1, nv0, nv1);
+        const uint32_t my_valid0 = (uint32_t)(hc.valid0 >> (q * RW)) & 0xFFFFu, my_valid1 = (uint32_t)(hc.valid1 >> (q * RW)) & 0xFFFFu;
         const int stop0 = c0 > 0 ? tstop[w * g.nch + (c0 - 1)] : 0;   // stored row groups of the tiles to the left
         const int stop1 = c1 > 0 ? tstop[w * g.nch + (c1 - 1)] : 0;
-        // four rows per step: one dwordx4 of row codes and of either boundary, fetched one step ahead
-        const uint4* rows4 = reinterpret_cast<const uint4*>(rows) + lane;
-        const uint4* bi0_4 = reinterpret_cast<const uint4*>(bi0) + lane;
-        const uint4* bi1_4 = reinterpret_cast<const uint4*>(bi1) + lane;
-        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-        auto boundary = [&](int gq) -> uint4 {
-            const uint4 x0 = gq < stop0 ? bi0_4[(int64_t)gq * WAVE] : bias4;
-            const uint4 x1 = gq < stop1 ? bi1_4[(int64_t)gq * WAVE] : bias4;
-            return make_uint4((x0.x & 0xFFFFu) | (x1.x & 0xFFFF0000u), (x0.y & 0xFFFFu) | (x1.y & 0xFFFF0000u),
-                              (x0.z & 0xFFFFu) | (x1.z & 0xFFFF0000u), (x0.w & 0xFFFFu) | (x1.w & 0xFFFF0000u));
+        // the planes hold four rows per 16-byte word: row j of this pair is word (j / 4) * 64 + lane, element j % 4
+        auto plane_at = [&](int j) -> int64_t { return ((int64_t)(j >> 2) * WAVE + lane) * 4 + (j & 3); };
+        auto row_code = [&](int j) -> uint32_t { return rows[plane_at(j < 0 ? 0 : j > R ? R : j)]; };
+        auto boundary = [&](int j) -> uint32_t {          // quarter 0 only: the tiles to the left (V = 0 past their stop)
+            const int jj = j < 0 ? 0 : j > R ? R : j;
+            const uint32_t x0 = (jj >> 2) < stop0 ? bi0[plane_at(jj)] : BIAS2;
+            const uint32_t x1 = (jj >> 2) < stop1 ? bi1[plane_at(jj)] : BIAS2;
+            return (x0 & 0xFFFFu) | (x1 & 0xFFFF0000u);
         };
-        const int ngq = (R >> 2) + 1;
-        int ngq_w = ngq;                                  // the wave sweeps as many row groups as its longest lane
+        int Rw = R;                                        // the wave steps as long as its longest task
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ngq_w = max(ngq_w, __shfl_xor(ngq_w, d, 64));
-        // the lanes of a wave read different planes (64 cache lines per load): operands are fetched two steps ahead
-        auto grp = [&](int gq) -> int { return gq < ngq ? gq : ngq - 1; };
-        uint4 rc_n = rows4[0], rc_nn = rows4[(int64_t)grp(1) * WAVE];
-        uint4 b_n = boundary(0), b_nn = boundary(grp(1));
-        // per field: the liveness threshold of row j (fill kernels, exact pruning), 0xFFFF where the lane has nothing to replay
-        auto thr2 = [&](int j) -> uint32_t {
-            const uint32_t t1 = (uint32_t)max(4 * j - slack + (int)BIAS16 - 1, 0);
-            const bool on = j <= R;
-            return ((on && has0) ? t1 : 0xFFFFu) | (((on && has1) ? t1 : 0xFFFFu) << 16);
-        };
-        // kept rows of skipped rows have no column in this tile pair
-        auto skip_hits = [&](int hi_row) {
-            while (hc.row0 >= 0 && hc.row0 <= hi_row) {
-                masks[((uint64_t)rt.mask_begin + hc.k0) * 2] = 0;
-                ++hc.k0;
-                cursor_next0(hc, kr, kc, st.n_kept, has0);
-            }
-            while (hc.row1 >= 0 && hc.row1 <= hi_row) {
-                masks[((uint64_t)rt.mask_begin + hc.k1) * 2 + 1] = 0;
-                --hc.k1;
-                cursor_next1(hc, kr, kc, lq, has1);
-            }
-        };
+        for (int d = 32; d >= 1; d >>= 1) Rw = max(Rw, __shfl_xor(Rw, d, 64));
+        // lane q is at row t - q in step t; operands are fetched two steps ahead
+        uint32_t rc_n = row_code(1 - q), rc_nn = row_code(2 - q);
+        uint32_t b_n = q == 0 ? boundary(1) : BIAS2, b_nn = q == 0 ? boundary(2) : BIAS2;
+        uint32_t bprev = BIAS2;                            // V(left neighbour column, row 0) = 0
+        uint32_t xlast = BIAS2;                            // this lane's last column after its latest row, drift removed (row 0: V = 0)
 #ifdef DSA_PRUNE_STATS
         const unsigned long long tr1 = __builtin_readcyclecounter();
-        int n_swept = 0;
 #endif
-        for (int gq = 0; gq < ngq_w; ++gq) {              // uniform
-            const uint4 rcq = rc_n, b = b_n;
+        for (int t = 1; t <= Rw + RQ - 1; ++t) {           // uniform
+            const int j = t - q;
+            const uint32_t cj = rc_n;
+            const uint32_t from_left = __shfl_up(xlast, 1, RQ);     // lane q-1 finished row j in the step before
+            const uint32_t bcur = q == 0 ? b_n : from_left;
             rc_n = rc_nn;
             b_n = b_nn;
-            rc_nn = rows4[(int64_t)grp(gq + 2) * WAVE];
-            b_nn = boundary(grp(gq + 2));
-            const uint32_t rcv[4] = {rcq.x, rcq.y, rcq.z, rcq.w}, bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int j = 4 * gq + sidx;
-                const uint32_t bcur = bv[sidx];
-                if (j >= 1 && j <= R) {
-                    row_step(X, r, rcv[sidx], bprev, bcur);
-                    record_hits(X, j, lq, kr, kc, st.n_kept, has0, has1, hc, masks, rt.mask_begin);
+            rc_nn = row_code(j + 2);
+            if (q == 0) b_nn = boundary(j + 2);
+            if (j >= 1 && j <= R) {
+                row_step_quarter(X, r, cj, bprev, bcur);
+                const bool hit0 = hc.row0 == j, hit1 = hc.row1 == j;
+                if (hit0 || hit1) {
+                    const uint32_t bits = equal_columns_quarter(X, (hit0 ? hc.t0 : NO_TARGET16) | ((hit1 ? hc.t1 : NO_TARGET16) << 16));
+                    if (hit0) {
+                        reinterpret_cast<unsigned short*>(masks + ((uint64_t)rt.mask_begin + hc.k0) * 2)[q] = (unsigned short)(bits & my_valid0);
+                        ++hc.k0;
+                        cursor_next0(hc, kr, kc, st.n_kept, has0);
+                    }
+                    if (hit1) {
+                        reinterpret_cast<unsigned short*>(masks + ((uint64_t)rt.mask_begin + hc.k1) * 2 + 1)[q] = (unsigned short)((bits >> 16) & my_valid1);
+                        --hc.k1;
+                        cursor_next1(hc, kr, kc, lq, has1);
+                    }
                 }
                 bprev = bcur;
+                xlast = X[RW - 1] - drift2(RW - 1);
             }
-#ifdef DSA_PRUNE_STATS
-            ++n_swept;
-#endif
-#ifndef DSA_NO_GAP_SKIP
-            // As in the fill kernels: once the last of these rows is dead in every lane, rows further down only come alive
-            // through the boundary column, and the sweep resumes (from V = 0) at the first row group with a live incoming
-            // value.  A tie's tile next to the junction tile is dead until the alignment reaches it in its last rows.
-            if (gq + 1 < ngq_w) {
-                const uint32_t tm2 = thr2(4 * gq + 3);
-                const bool alive = (pk_max_u16(tile_row_max<false>(X, W, W), tm2) ^ tm2) != 0u;
-                if (__builtin_amdgcn_ballot_w64(alive) == 0) {      // uniform
-                    int g2 = gq + 1;
-                    bool resume = false;
-                    uint4 bb = b_n;
-                    uint32_t in_prev = bv[3];
-                    for (; g2 < ngq_w; ++g2) {
-                        if (g2 > gq + 1) bb = boundary(grp(g2));
-                        const uint32_t bbv[5] = {in_prev, bb.x, bb.y, bb.z, bb.w};
-                        uint32_t in_bits = 0;
-#pragma unroll
-                        for (int sidx = 0; sidx < 5; ++sidx) {
-                            const uint32_t t2 = thr2(4 * g2 + sidx - 1);
-                            in_bits |= pk_max_u16(bbv[sidx], t2) ^ t2;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(in_bits != 0u) != 0) { resume = true; break; }
-                        skip_hits(4 * g2 + 3);
-                        in_prev = bb.w;
-                    }
-                    if (!resume) break;
-#pragma unroll
-                    for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-                    bprev = in_prev;
-                    rc_n = rows4[(int64_t)grp(g2) * WAVE];
-                    rc_nn = rows4[(int64_t)grp(g2 + 1) * WAVE];
-                    b_n = bb;
-                    b_nn = boundary(grp(g2 + 1));
-                    gq = g2 - 1;
-                }
-            }
-#endif
         }
         // sides that were not replayed report no columns
-        if (valid && !has0)
+        if (valid && q == 0 && !has0)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
-        if (valid && !has1)
+        if (valid && q == 0 && !has1)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
 #ifdef DSA_PRUNE_STATS
-        {
-            const int ngq_wave = n_swept;
-            if ((threadIdx.x & 63) == 0) {
-                const unsigned long long tr2 = __builtin_readcyclecounter();
-                atomicAdd(&g.stats[10], tr1 - tr0);
-                atomicAdd(&g.stats[11], tr2 - tr1);
-                atomicAdd(&g.stats[12], 1ull);
-                atomicAdd(&g.stats[13], (unsigned long long)ngq_wave);
-            }
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long tr2 = __builtin_readcyclecounter();
+            atomicAdd(&g.stats[10], tr1 - tr0);
+            atomicAdd(&g.stats[11], tr2 - tr1);
+            atomicAdd(&g.stats[12], 1ull);
+            atomicAdd(&g.stats[13], (unsigned long long)(Rw + RQ - 1));
         }
 #endif
     }
