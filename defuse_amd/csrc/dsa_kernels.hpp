@@ -1990,7 +1990,7 @@ __device__ __forceinline__ uint32_t equal_columns_quarter(const uint32_t (&X)[RW
     return acc;
 }
 
-__global__ __launch_bounds__(REPLAY_BLOCK) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
+__global__ __launch_bounds__(REPLAY_BLOCK, 5) void k_replay(const ReplayTask* __restrict__ tasks, uint64_t task_cap,
                                                    const uint2* __restrict__ gtasks, uint64_t gtask_cap,
                                                    const Counters* __restrict__ ctr,
                                                    const PairState* __restrict__ state,
