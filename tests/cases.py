@@ -125,6 +125,55 @@ def tie_batch(seed):
     return bb.arrays()
 
 
+def repeat_batch(seed, n_fusions=40, reads_per_fusion=100, lq=60):
+    """Full workgroups of repeat-rich fusions: windows of several tiles that hold a tandem repeat, a duplicated segment or a
+    junction on a tile boundary, with a hundred reads each, so that pairs have many kept splits in several tiles (the emit
+    paths for many masks, runs of such pairs in one wave, many generic replay tasks, device buffers that overflow and make the
+    host re-run the slice) next to ordinary fusions."""
+    rng = np.random.default_rng(seed)
+    bb = BatchBuilder()
+    for f in range(n_fusions):
+        kind = f % 5
+        if kind == 0:                      # tandem repeat across two tiles of window 0, plain window 1
+            unit = rnd(rng, int(rng.integers(2, 7)))
+            ref0 = rnd(rng, 40) + (unit * 60)[:150] + rnd(rng, 30)
+            ref1 = rnd(rng, 200)
+        elif kind == 1:                    # window 1 holds a segment three times, tiles apart
+            seg = rnd(rng, 30)
+            ref0 = rnd(rng, 230)
+            ref1 = seg + rnd(rng, 50) + seg + rnd(rng, 70) + seg + rnd(rng, 20)
+        elif kind == 2:                    # junction on a tile boundary, both sides continue alike (several kept splits)
+            shared = rnd(rng, 6)
+            ref0 = rnd(rng, 128 - 3) + shared + rnd(rng, 80)
+            ref1 = shared + rnd(rng, 180)
+        elif kind == 3:                    # homopolymer stretches on both sides
+            ref0 = rnd(rng, 70) + b"A" * 80 + rnd(rng, 60)
+            ref1 = b"A" * 40 + rnd(rng, 160)
+        else:
+            ref0, ref1 = rnd(rng, 389), rnd(rng, 389)
+        fi = bb.add_fusion(ref0, ref1)
+        for r in range(reads_per_fusion):
+            if kind == 2:
+                a = int(rng.integers(8, lq - 8))
+                read = ref0[125 + 3 - a:125 + 3] + ref1[3:3 + lq - a] if r % 3 else split_read(rng, ref0, ref1, lq)
+            elif kind == 1 and r % 2:
+                a = int(rng.integers(6, lq - 20))
+                s0 = int(rng.integers(a, len(ref0)))
+                read = ref0[s0 - a:s0] + ref1[:lq - a]       # the suffix starts with the repeated segment
+            elif kind == 0 and r % 2:
+                a = int(rng.integers(10, lq - 10))
+                read = ref0[40 + 150 - a:40 + 150] + ref1[:lq - a]      # the prefix lies in the repeat
+            elif kind == 3 and r % 2:
+                a = int(rng.integers(10, lq - 10))
+                read = (b"A" * a) + ref1[40 - (lq - a) // 3:][:lq - a]
+            else:
+                read = split_read(rng, ref0, ref1, lq)
+            if r % 7 == 0:
+                read = mutate(rng, read, 0.03)
+            bb.add_read(fi, read, read_end=int(r & 1), revcomp=int((r >> 1) & 1))
+    return bb.arrays()
+
+
 def edge_batch():
     """Degenerate shapes: empty read, read shorter than the 4-base anchor, empty window, window
     shorter than one tile, window of exactly one/two tiles, ungrouped pairs."""

@@ -170,6 +170,18 @@ def test_parity_ties(gpu_ctx, ora):
     assert counts.max() > 10
 
 
+def test_parity_repeat_rich_full_workgroups(gpu_ctx, ora):
+    """Many kept splits in several tiles, in runs of a hundred pairs: the emit paths beyond registers (LDS staging, a whole
+    wave per pair, the walk through global memory), long generic replay tasks, and finish buffers that overflow."""
+    batch = cases.repeat_batch(11)
+    got = check_batch(gpu_ctx, ora, batch)
+    per_pair = np.bincount(got["pair_idx"], minlength=len(batch[3]))
+    assert per_pair.max() > 40                       # really heavy pairs
+    assert (per_pair > 8).sum() > 200                # and runs of them
+    t = gpu_ctx.timing()
+    assert t.n_generic_tasks > 500
+
+
 def test_parity_edges(gpu_ctx, ora):
     check_batch(gpu_ctx, ora, cases.edge_batch())
 
