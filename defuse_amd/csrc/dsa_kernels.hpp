@@ -33,8 +33,10 @@
 //     boundary the next tile starts from).  In its tail the same workgroup picks the winning rows
 //     (combine_wg) and replays only the winning tile pair from the stored boundaries to enumerate tied
 //     columns (replay_fast_wg) — exact, at a fraction of the fill work instead of a second full pass,
-//     and in the shadow of the other resident workgroups' sweeps.  k_replay takes the left-over tiles,
-//     k_emit writes the records.
+//     and in the shadow of the other resident workgroups' sweeps; a pair with no other tile also gets its
+//     record count there.  k_replay takes the left-over tiles (four lanes per task), k_emit_listed<false>
+//     counts the pairs that had some, a scan places the records, and k_emit_counted / k_emit_listed<true>
+//     write them side by side.
 //
 // Everything here is integer; results are bit-exact with the reference by construction.
 #pragma once
