@@ -71,6 +71,7 @@ struct PipeLane {
     bool emit_early = false;    // phase 1 already wrote the slice's records, into room for emit_cap of them
     uint64_t emit_cap = 0;
     int emit_from = 5;          // event that marks the start of the emit in flight
+    uint64_t last_gtasks = 0;   // entries of the generic replay's list the last time this lane finished a slice
     bool copied_descriptors = false;   // phase 1 of the slice in flight uploaded its descriptors (ev[0]..ev[4] time that)
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
@@ -509,7 +510,15 @@ FinishBufs finish_bufs(PipeLane& L)
 
 // the records of a slice, behind those of the earlier slices (ev[5]..ev[6] time it): the pairs counted in the fill
 // kernel's tail by a per-pair launch, the others through the generic replay's task list
-constexpr unsigned LISTED_GRID = 1024;
+// The listed pairs' kernels map one list entry to a thread; blocks without entries and second rounds both cost (they are
+// latency-bound kernels of a few hundred blocks), so the grid follows the length the list had the last time this lane ran
+// (the same batch run again: exact; another upload of the job: close), or a tenth of the pairs before anything is known.
+unsigned listed_grid(const PipeLane& L, int64_t n_pairs)
+{
+    const uint64_t expect = L.last_gtasks ? L.last_gtasks : (uint64_t)n_pairs / 10 + 1;
+    const uint64_t blocks = (expect + expect / 64 + EMIT_BLOCK - 1) / EMIT_BLOCK + 1;
+    return (unsigned)std::min<uint64_t>(std::max<uint64_t>(blocks, 16), 16384);
+}
 void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, bool record_start = true)
 {
     const int64_t np = s.g.n_pairs;
@@ -520,7 +529,7 @@ void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, boo
     // the listed pairs' kernel is a few latency-bound waves, the counted pairs' one streams: side by side
     (void)hipEventRecord(L.ev_fork, L.stream);
     (void)hipStreamWaitEvent(L.aux, L.ev_fork, 0);
-    hipLaunchKernelGGL(k_emit_listed<true>, dim3(LISTED_GRID), dim3(EMIT_BLOCK), 0, L.aux, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
+    hipLaunchKernelGGL(k_emit_listed<true>, dim3(listed_grid(L, np)), dim3(EMIT_BLOCK), 0, L.aux, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p, out,
                        (uint64_t)cap_left, (int64_t)s.pair_begin, s.g);
@@ -573,7 +582,7 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
                        ctx->d_refcodes.p, L.d_rowcodes.p, L.d_bnd.p, L.d_tstop.p, L.d_masks.p, (uint64_t)(L.d_masks.cap / 2), g);
-    hipLaunchKernelGGL(k_emit_listed<false>, dim3(LISTED_GRID), dim3(EMIT_BLOCK), 0, st, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
+    hipLaunchKernelGGL(k_emit_listed<false>, dim3(listed_grid(L, np)), dim3(EMIT_BLOCK), 0, st, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr,
                        (uint64_t)0, (int64_t)s.pair_begin, g);
@@ -714,6 +723,7 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
                 h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11], h[13], h[14], h[2] & 0xFFFFFFFFull, h[2] >> 32, h[15] >> 24, (h[15] >> 8) & 0xFFFF, h[15] & 0xFF);
     }
 #endif
+    L.last_gtasks = L.host->ctr.n_gtasks;
     const int64_t n_rec = L.host->n_rec;
     if (L.copied_descriptors) ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
     if (!(L.emit_early && (uint64_t)n_rec <= L.emit_cap)) {
