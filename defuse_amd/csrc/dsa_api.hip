@@ -72,6 +72,7 @@ struct PipeLane {
     uint64_t emit_cap = 0;
     int emit_from = 5;          // event that marks the start of the emit in flight
     uint64_t last_gtasks = 0;   // entries of the generic replay's list the last time this lane finished a slice
+    bool phase1_end_recorded = false;  // ev[3] marks the end of the slice's phase 1 (not recorded when the emit follows at once)
     bool copied_descriptors = false;   // phase 1 of the slice in flight uploaded its descriptors (ev[0]..ev[4] time that)
     DevBuf<WaveInfo> d_waves;
     DevBuf<WgInfo> d_wgs;
@@ -524,7 +525,7 @@ void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, boo
     const int64_t np = s.g.n_pairs;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     dsa_record* out = ctx->d_records.p + ctx->n_records;
-    L.emit_from = record_start ? 5 : 3;
+    L.emit_from = record_start ? 5 : 2;
     if (record_start) (void)hipEventRecord(L.ev[5], L.stream);      // (every event between two kernels is a gap of a few microseconds)
     // the listed pairs' kernel is a few latency-bound waves, the counted pairs' one streams: side by side
     (void)hipEventRecord(L.ev_fork, L.stream);
@@ -589,15 +590,18 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
     // the cursors and the record total go to the lane's pinned result words
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_offset.p + np, &L.host->ctr, &L.host->n_rec);
-    HIPC(hipEventRecord(L.ev[3], st));
     // The first slice of a run knows where its records go: write them right away, into the room there is, without
     // waiting for the host to read the total (phase2 runs the emit again after growing the buffer if it was short).
     L.emit_cap = 0;
     L.emit_early = false;
+    L.phase1_end_recorded = false;
     if (ctx->n_records == 0 && &s == &ctx->slices.front() && ctx->d_records.cap > 0) {
         L.emit_cap = ctx->d_records.cap;
         L.emit_early = true;
-        launch_emit(ctx, L, s, L.emit_cap, false);        // ev[3] just recorded is its start
+        launch_emit(ctx, L, s, L.emit_cap, false);        // timed from ev[2], the end of the fill, with the rest of the finish stage
+    } else {
+        HIPC(hipEventRecord(L.ev[3], st));
+        L.phase1_end_recorded = true;
     }
     HIPC(hipGetLastError());
     return DSA_OK;
@@ -736,7 +740,7 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     L.emit_pending = true;
     ctx->n_records += n_rec;
     ctx->timing.fill_ms += elapsed(L.ev[1], L.ev[2]);
-    ctx->timing.finish_ms += elapsed(L.ev[2], L.ev[3]);
+    if (L.phase1_end_recorded) ctx->timing.finish_ms += elapsed(L.ev[2], L.ev[3]);
     ctx->timing.fill_launches += 1;
     ctx->timing.n_replay_tasks += (int64_t)L.host->ctr.n_tasks;
     ctx->timing.n_generic_tasks += (int32_t)L.host->ctr.n_gtasks;
@@ -966,8 +970,10 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
         HIPC(hipEventRecord(ctx->ev_pack[0], L0.stream));
         hipLaunchKernelGGL(k_pack_refs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L0.stream, ctx->d_ref.p, ctx->d_fusions.p,
                            ctx->d_refcodes.p, g);
-        HIPC(hipEventRecord(ctx->ev_pack[1], L0.stream));
-        HIPC(hipStreamWaitEvent(ctx->lanes->lane[1].stream, ctx->ev_pack[1], 0));
+        if (ns > 1) {       // lane 1 waits for the codes; a run of one slice times the pack up to the start of its fill instead
+            HIPC(hipEventRecord(ctx->ev_pack[1], L0.stream));
+            HIPC(hipStreamWaitEvent(ctx->lanes->lane[1].stream, ctx->ev_pack[1], 0));
+        }
     }
     // room for two records per candidate before the first run, so that its first slice can write its records early too
     if (ns > 0 && ctx->d_records.cap == 0) HIPC(ctx->d_records.reserve((size_t)ctx->n_pairs * 2 + 1024));
@@ -986,7 +992,7 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
         account_emit(ctx, L);
         HIPC(hipStreamSynchronize(L.stream));
     }
-    if (ns > 0 && ctx->n_fusions > 0) ctx->timing.pack_ms += elapsed(ctx->ev_pack[0], ctx->ev_pack[1]);
+    if (ns > 0 && ctx->n_fusions > 0) ctx->timing.pack_ms += elapsed(ctx->ev_pack[0], ns > 1 ? ctx->ev_pack[1] : ctx->lanes->lane[0].ev[1]);
     // stage times are per-stream sums and overlap between the lanes; total_ms is the elapsed time
     ctx->timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.n_records = ctx->n_records;
