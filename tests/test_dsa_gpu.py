@@ -243,6 +243,27 @@ def test_slicing_gives_same_records(built, ora):
     assert got.tobytes() == exp.tobytes()
 
 
+def test_slices_of_heavy_pairs_run_twice(built, ora):
+    """Several slices of the repeat-rich batch (finish buffers overflow in every slice, only the first one writes its records
+    before the host has the total), and the batch is run a second time in the same context (descriptors resident, buffers
+    grown, the listed kernels' grids taken from the first run)."""
+    from defuse_amd import dsa
+    batch = cases.repeat_batch(12, n_fusions=15)
+    exp = ora.align_batch(*batch)
+    os.environ["DEFUSE_DSA_SCRATCH_MB"] = "3"
+    try:
+        ctx = dsa.Context(0)
+    finally:
+        del os.environ["DEFUSE_DSA_SCRATCH_MB"]
+    ctx.upload(*batch)
+    for _ in range(2):
+        ctx.run()
+        got = ctx.download()
+        assert ctx.timing().fill_launches > 1
+        assert got.tobytes() == exp.tobytes()
+    ctx.close()
+
+
 def test_full_size_properties(gpu_ctx, ora):
     """BASELINE config 2 at full size (10k fusions x 100 reads, 2x76): size-independent properties
     plus an oracle check on a random sample of fusions."""
