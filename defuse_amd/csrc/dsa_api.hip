@@ -53,9 +53,10 @@ struct DevBuf {
     }
 };
 
-struct HostResult {            // pinned: filled by async copies at the end of a slice's first phase
+struct HostResult {            // pinned: filled by k_publish at the end of a slice's first phase
     Counters ctr;
     int64_t n_rec;
+    PlanGlobals plan;          // of the slice's latest planning
 };
 
 struct PipeLane {
@@ -73,10 +74,9 @@ struct PipeLane {
     int emit_from = 5;          // event that marks the start of the emit in flight
     uint64_t last_gtasks = 0;   // entries of the generic replay's list the last time this lane finished a slice
     bool phase1_end_recorded = false;  // ev[3] marks the end of the slice's phase 1 (not recorded when the emit follows at once)
-    bool copied_descriptors = false;   // phase 1 of the slice in flight uploaded its descriptors (ev[0]..ev[4] time that)
-    DevBuf<WaveInfo> d_waves;
-    DevBuf<WgInfo> d_wgs;
-    DevBuf<uint32_t> d_wg_generic;
+    unsigned tier_hint = 0xFu;  // fill kernels the lane's last slice needed (bit t: k_fill_fast<t>, bit 3: k_fill_generic): the ones launched
+    unsigned tiers_launched = 0;    // ... for the slice in flight
+    DevBuf<uint8_t> d_wg_tier;  // which fill kernel owns each workgroup (written by k_fill_fast<0>)
     DevBuf<uint32_t> d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
     DevBuf<PairState> d_state;
     DevBuf<KeptRow> d_kept;
@@ -92,7 +92,7 @@ struct PipeLane {
 #endif
     void release()
     {
-        d_waves.release(); d_wgs.release(); d_wg_generic.release(); d_rowcodes.release();
+        d_wg_tier.release(); d_rowcodes.release();
         d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
         d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
         d_ctr.release(); d_scan_tmp.release(); d_tstop.release();
@@ -126,19 +126,9 @@ struct LaneSet {
 
 std::atomic<int64_t> g_upload_serial{0};      // unique over all contexts: lanes may be shared
 
-struct Slice {
+struct Slice {                       // a contiguous range of the caller's pair order that fits the scratch budget
     int64_t pair_begin = 0, pair_end = 0;
-    std::vector<WaveInfo> waves;     // one per 64 pairs
-    std::vector<WgInfo> wgs;         // one per 256 pairs
-    std::vector<uint32_t> wg_flags;  // initial generic flag (1 = more than GSPLIT2 fusions)
     Geom g{};
-    // workgroups per table tier of k_fill_fast (an instantiation without workgroups is not launched)
-    void tiers(int64_t (&n)[3]) const
-    {
-        n[0] = n[1] = n[2] = 0;
-        for (size_t k = 0; k < wgs.size(); ++k)
-            if (!wg_flags[k]) ++n[tier_of(wgs[k].n_groups)];
-    }
 };
 
 }  // namespace
@@ -159,15 +149,22 @@ struct dsa_ctx {
     int nch_all = 1;                 // tiles of the widest window of the upload: refcodes stride = nch_all * W
     DevBuf<uint32_t> d_refcodes;     // packed once per run for the whole upload
     hipEvent_t ev_pack[2] = {};      // around k_pack_refs
-    DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig), when pairs were reordered
-    DevBuf<dsa_pair> d_pairs_sweep;  // second pair buffer: the permutation is written here, then the two are swapped
-    DevBuf<dsa_pair> d_pairs;
+    DevBuf<int32_t> d_orig;          // sweep order -> caller's pair index (Geom::orig)
+    DevBuf<dsa_pair> d_pairs_in;     // the pairs in the caller's order, as uploaded
+    DevBuf<dsa_pair> d_pairs;        // the pairs in sweep order, with the per-pair score bound in the padding bytes (k_plan_permute)
     DevBuf<int32_t> d_min_score;
-    DevBuf<FusionStat> plan_stat;    // sweep planning (plan_sweep): per-fusion statistics, probe votes, tiles / flips, starts, ranks
-    DevBuf<int32_t> plan_votes, plan_start, plan_rank;
-    DevBuf<uint8_t> plan_tiles;
+    // sweep planning (dsa_plan.hpp), all on the device: runs per fusion, sort keys and order of the fusions, starts, ranks, bounds
+    DevBuf<PlanRun> plan_runs;
+    DevBuf<uint32_t> plan_key, plan_key_sorted;
+    DevBuf<int32_t> plan_fidx, plan_order, plan_bsum, plan_start, plan_rank;
+    DevBuf<uint16_t> plan_bound;
+    DevBuf<uint8_t> plan_flip, plan_sort_tmp;
+    DevBuf<PlanGlobals> plan_glob;   // one per slice
+    PlanParams plan_prm{};
+    hipEvent_t ev_plan[2] = {};      // around the planning kernels
+    bool plan_timed = false;         // ev_plan was recorded since the last run read it
     std::vector<Slice> slices;
-    int64_t total_cells = 0;
+    float last_plan_ms = 0.f;        // device time of the latest planning (upload's or dsa_plan's)
 
     // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
     // slice overlaps the fill of the next (separate HIP streams)
@@ -216,248 +213,108 @@ size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
     return 3 * rows + 2 * rows * (size_t)nch;
 }
 
-// Slices bound the scratch footprint; inside a slice pair p lives in wave p/64, lane p%64.
-// Per wave the loop bounds, per workgroup (256 pairs) the distinct fusions for the fast path.
-int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs);
-
-// Sweep plan (speed only; records always come out in the caller's pair order).  Workgroups are 256
-// consecutive pairs, waves 64: fusions with many reads go first (table tiers), and inside a size class
-// fusions whose alignments end in the same tiles (device probe) sit next to each other, so the lanes of a
-// wave that straddles two fusions are alive in the same tiles.  Everything that touches pairs runs on the
-// device (statistics per fusion, probe, permutation); the host sorts the fusions and derives the wave and
-// workgroup descriptors from the runs.  A batch larger than the scratch budget is cut into contiguous ranges
-// of the caller's order, each planned on its own (records of a slice follow those of the slices before it, so
-// the offsets of a reordered slice only need the scan over that slice).  Needs the pairs of every fusion to
-// be one run inside a slice; otherwise, and with DEFUSE_DSA_NO_REORDER=1, the caller's order is swept.
-// Returns 1 if the plan was made, 0 if not.
-// plans pairs [begin, end) of the caller's order as one slice; 0 = some fusion is not one run in it
-int plan_chunk(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t begin, int64_t end, int lq1, DevBuf<FusionStat>& d_stat,
-               DevBuf<int32_t>& d_votes, DevBuf<uint8_t>& d_tiles, DevBuf<int32_t>& d_start, DevBuf<int32_t>& d_rank, Slice& cur)
+// Slices bound the scratch footprint: contiguous ranges of the caller's pair order that fit the budget (and
+// DEFUSE_DSA_SLICE_PAIRS); inside a slice pair p of the SWEEP order lives in wave p/64, lane p%64.  Host work is
+// O(slices): the geometry depends on the sizes of the upload only, everything that depends on the pairs themselves is
+// planned on the device (enqueue_plan) or found by the fill kernels (rows and tiles per wave, fusions per workgroup).
+void make_slices(dsa_ctx* ctx, int64_t n_pairs, int lqmax)
 {
-    const int nf = ctx->n_fusions;
-    const int64_t n = end - begin;
-    hipStream_t st = ctx->stream;
-    const dsa_pair* pairs = ctx->d_pairs.p + begin;
-    std::vector<FusionStat> stat((size_t)nf);
-    std::vector<uint8_t> tiles((size_t)2 * nf);
-    HIPC(hipMemsetAsync(d_votes.p, 0, (size_t)nf * 2 * PROBE_TILES * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_fusion_stats_init, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, d_stat.p, nf);
-    hipLaunchKernelGGL(k_fusion_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p);
-    hipLaunchKernelGGL(k_probe_wave, dim3((unsigned)nf * PROBE_READS), dim3(WAVE), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
-                       pairs, d_stat.p, d_votes.p);
-    hipLaunchKernelGGL(k_probe_pick, dim3((unsigned)((2 * nf + 255) / 256)), dim3(256), 0, st, d_votes.p, 2 * nf, d_tiles.p);
-    HIPC(hipMemcpyAsync(stat.data(), d_stat.p, (size_t)nf * sizeof(FusionStat), hipMemcpyDeviceToHost, st));
-    HIPC(hipMemcpyAsync(tiles.data(), d_tiles.p, tiles.size(), hipMemcpyDeviceToHost, st));
-    HIPC(hipStreamSynchronize(st));
-    HIPC(hipGetLastError());
-    for (int f = 0; f < nf; ++f)
-        if (stat[f].count > 0 && stat[f].last - stat[f].first + 1 != stat[f].count) return 0;     // not one run per fusion
-
-    auto window_tiles = [&](int f) { return std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)); };
-    auto size_class = [&](int f) {
-        const int c = stat[f].count;
-        return c >= WAVE ? 0 : c >= WG_LANES / GSPLIT ? 1 : c >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
-    };
-    std::vector<int32_t> forder;
-    for (int f = 0; f < nf; ++f)
-        if (stat[f].count > 0) forder.push_back(f);
-    // inside a size class the expensive fusions first (longest-processing-time order: the workgroups that are still
-    // running when the launch drains are then the cheap ones).  Cost proxy: the number of distinct tiles in which either
-    // matrix is alive, {t1-1, t1} and {t2-1, t2} with t1, t2 the probed end tiles — 2 when they coincide, up to 4.
-    auto alive_tiles = [&](int f) {
-        const int t1 = tiles[2 * f], t2 = tiles[2 * f + 1];
-        if (t1 == 255 || t2 == 255) return 4;                  // no vote: assume the worst
-        const int d = t1 > t2 ? t1 - t2 : t2 - t1;
-        return d == 0 ? 2 : d == 1 ? 3 : 4;
-    };
-    static const bool lpt = [] { const char* e = getenv("DEFUSE_DSA_NO_LPT"); return !(e && atoi(e) != 0); }();
-    std::stable_sort(forder.begin(), forder.end(), [&](int a, int b) {
-        const int ca = size_class(a), cb = size_class(b);
-        if (ca != cb) return ca < cb;
-        if (lpt) {
-            const int ka = alive_tiles(a), kb = alive_tiles(b);
-            if (ka != kb) return ka > kb;
-        }
-        return tiles[2 * a] * 256 + tiles[2 * a + 1] < tiles[2 * b] * 256 + tiles[2 * b + 1];
-    });
-
-    // geometry and descriptors from the runs
-    cur.pair_begin = begin;
-    cur.pair_end = end;
-    int nch = 1;
-    for (int f : forder) nch = std::max(nch, window_tiles(f));
-    const int64_t n_waves = (n + WAVE - 1) / WAVE, n_wgs = (n + WG_LANES - 1) / WG_LANES;
-    cur.waves.assign((size_t)n_waves, WaveInfo{0, 0});
-    cur.wgs.assign((size_t)n_wgs, WgInfo{});
-    cur.wg_flags.assign((size_t)n_wgs, 0u);
-    std::vector<int32_t> new_start((size_t)nf, 0);
-    int64_t pos = 0;
-    for (int f : forder) {
-        const int64_t c = stat[f].count;
-        new_start[f] = (int32_t)pos;
-        const int tl = window_tiles(f);
-        for (int64_t w = pos / WAVE; w <= (pos + c - 1) / WAVE; ++w) {
-            cur.waves[w].lq_max = std::max(cur.waves[w].lq_max, stat[f].max_lq);    // upper bound of the wave's reads
-            cur.waves[w].nch_max = std::max(cur.waves[w].nch_max, tl);
-        }
-        for (int64_t g = pos / WG_LANES; g <= (pos + c - 1) / WG_LANES; ++g) {
-            WgInfo& wg = cur.wgs[g];
-            if (cur.wg_flags[g]) continue;
-            if (wg.n_groups < GSPLIT2)
-                wg.group_f[wg.n_groups++] = f;
-            else {
-                wg.n_groups = 0;
-                cur.wg_flags[g] = 1u;
-            }
-        }
-        ctx->total_cells += (int64_t)(fusions[f].ref0_len + 1 + fusions[f].ref1_len + 1) * (stat[f].sum_lq + c);
-        pos += c;
-    }
-    cur.g.n_waves = (int32_t)n_waves;
-    cur.g.n_wgs = (int32_t)n_wgs;
-    cur.g.lq1 = lq1;
-    cur.g.nch = nch;
-    cur.g.lrp = ctx->nch_all * W;
-    cur.g.n_fusions = nf;
-    cur.g.n_pairs = n;
-    cur.g.orig = ctx->d_orig.p + begin;        // slice-relative indices of the caller's order
-
-    // pairs into sweep order on the device: the fusions in the order just made, the pairs of a fusion by the estimated
-    // read split (k_rank_in_fusion), alternate fusions in opposite directions (DEFUSE_DSA_NO_RANK=1: caller's order inside)
-    std::vector<uint8_t> flip((size_t)nf, 0);
-    {
-        int pos_in_order = 0;
-        for (int f : forder) flip[f] = (uint8_t)(pos_in_order++ & 1);
-    }
-    static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
-    // DEFUSE_DSA_NO_TIGHTEN=1: no per-pair score bound, pruning against minScore alone (round 1's behaviour)
-    static const bool no_tighten = [] { const char* e = getenv("DEFUSE_DSA_NO_TIGHTEN"); return e && atoi(e) != 0; }();
-    HIPC(hipMemcpyAsync(d_start.p, new_start.data(), (size_t)nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpyAsync(d_tiles.p, flip.data(), (size_t)nf, hipMemcpyHostToDevice, st));        // the tile votes were read above: the buffer is free
-    HIPC(d_rank.reserve((size_t)n));
-    if (no_rank)
-        hipLaunchKernelGGL(k_rank_identity, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_rank.p);
-    else
-        hipLaunchKernelGGL(k_rank_in_fusion, dim3((unsigned)nf), dim3(RANK_THREADS), 0, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p,
-                           ctx->d_pairs.p + begin, d_stat.p, d_tiles.p, d_rank.p, no_tighten ? 0 : 1);
-    hipLaunchKernelGGL(k_permute_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pairs, n, d_stat.p, d_start.p, d_rank.p,
-                       ctx->d_pairs_sweep.p + begin, ctx->d_orig.p + begin);
-    HIPC(hipStreamSynchronize(st));             // new_start is reused by the next chunk
-    HIPC(hipGetLastError());
-    return 1;
-}
-
-int plan_sweep(dsa_ctx* ctx, const dsa_fusion* fusions, int64_t n_pairs, int lqmax)
-{
-    const int nf = ctx->n_fusions;
-    const char* off = getenv("DEFUSE_DSA_NO_REORDER");
-    if (nf < 2 || n_pairs < 2 * WG_LANES || (off && atoi(off) != 0)) return 0;
-    // slices: contiguous ranges of the caller's order that fit the scratch budget (and DEFUSE_DSA_SLICE_PAIRS)
-    int nch_all = 1;
-    for (int f = 0; f < nf; ++f) nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
-    const int lq1 = (lqmax + 1 + 3) & ~3;
-    const size_t per_wg = slice_scratch_bytes(WG_WAVES, lq1, nch_all);
+    ctx->slices.clear();
+    const int lq1 = (lqmax + 1 + 3) & ~3;          // row planes are stored four rows per 16-byte word
+    const size_t per_wg = slice_scratch_bytes(WG_WAVES, lq1, ctx->nch_all);
     int64_t chunk = (int64_t)std::min<size_t>((size_t)1 << 40, ctx->scratch_budget / std::max<size_t>(per_wg, 1)) * WG_LANES;
     // A batch that fits one slice runs as ONE fill launch.  Cutting it in two so that the latency-bound finish kernels of the
-    // first half run beside the fill of the second (DEFUSE_DSA_SPLIT_LARGE=1) measured +1 % aligns/s on BASELINE configs[1]
-    // (4.04 against 4.08 ms per step) with the two fills overlapping on the two lanes — which blurs the per-launch times the
-    // roofline is computed from — and -10 % with the fills serialised (4.52 ms: two launch tails instead of one); four or
-    // eight slices lose as well (4.66, 5.61 ms).  So it stays off.
+    // first half run beside the fill of the second (DEFUSE_DSA_SPLIT_LARGE=1) measured +1..2 % aligns/s on BASELINE configs[1]
+    // with the two fills overlapping on the two lanes — which blurs the per-launch times the roofline is computed from — and
+    // -10 % with the fills serialised; four or eight slices lose as well.  So it stays off.
     if (const char* e = getenv("DEFUSE_DSA_SPLIT_LARGE"))
         if (atoi(e) != 0 && chunk >= n_pairs && n_pairs >= ((int64_t)1 << 19)) chunk = ((n_pairs + 1) / 2 + WG_LANES - 1) / WG_LANES * WG_LANES;
     if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) chunk = std::min<int64_t>(chunk, std::max<int64_t>(WG_LANES, atoll(e) / WG_LANES * WG_LANES));
-    if (chunk < 2 * WG_LANES) return 0;
-    // planning buffers live in the context: an upload after the first finds them allocated
-    DevBuf<FusionStat>& d_stat = ctx->plan_stat;
-    DevBuf<int32_t>&d_votes = ctx->plan_votes, &d_start = ctx->plan_start, &d_rank = ctx->plan_rank;
-    DevBuf<uint8_t>& d_tiles = ctx->plan_tiles;
-    HIPC(d_stat.reserve((size_t)nf));
-    HIPC(d_votes.reserve((size_t)nf * 2 * PROBE_TILES));
-    HIPC(d_tiles.reserve((size_t)nf * 2));
-    HIPC(d_start.reserve((size_t)nf));
-    HIPC(ctx->d_orig.reserve((size_t)n_pairs));
-    HIPC(ctx->d_pairs_sweep.reserve((size_t)n_pairs + 1));
-    HIPC(d_rank.reserve((size_t)std::min<int64_t>(n_pairs, chunk)));
-    std::vector<Slice> slices;
-    ctx->total_cells = 0;
+    chunk = std::max<int64_t>(chunk, WG_LANES);
     for (int64_t b = 0; b < n_pairs; b += chunk) {
         Slice cur;
-        const int rc = plan_chunk(ctx, fusions, b, std::min(n_pairs, b + chunk), lq1, d_stat, d_votes, d_tiles, d_start, d_rank, cur);
-        if (rc != 1) return rc;                 // the caller's pairs are untouched: the unplanned path takes over
-        slices.push_back(std::move(cur));
-    }
-    std::swap(ctx->d_pairs.p, ctx->d_pairs_sweep.p);
-    std::swap(ctx->d_pairs.cap, ctx->d_pairs_sweep.cap);
-    ctx->slices = std::move(slices);
-    return 1;
-}
-
-int build_slices(dsa_ctx* ctx, const dsa_fusion* fusions, const dsa_pair* pairs, int64_t n_pairs)
-{
-    ctx->slices.clear();
-    ctx->total_cells = 0;
-    // Slices are cut by the scratch budget only: cutting finer to overlap two slices on the two lanes
-    // measured no faster than one big slice (the finish work already hides inside the fill kernel).
-    // DEFUSE_DSA_SLICE_PAIRS caps the pairs per slice (tests, experiments).
-    int64_t slice_pair_cap = n_pairs + 1;
-    if (const char* e = getenv("DEFUSE_DSA_SLICE_PAIRS")) slice_pair_cap = std::max<int64_t>(WG_LANES, atoll(e));
-    int64_t p = 0;
-    while (p < n_pairs) {
-        Slice cur;
-        cur.pair_begin = p;
-        int lq1 = 1, nch = 1;
-        while (p < n_pairs) {
-            // one workgroup worth of pairs at a time
-            const int64_t e = std::min<int64_t>(n_pairs, p + WG_LANES);
-            int nlq1 = lq1, nnch = nch;
-            for (int64_t q = p; q < e; ++q) {
-                const dsa_fusion& fu = fusions[pairs[q].fusion_idx];
-                nlq1 = std::max(nlq1, (int)pairs[q].read_len + 1);
-                nnch = std::max(nnch, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
-            }
-            const int64_t waves_after = (int64_t)cur.waves.size() + cdiv((int)(e - p), WAVE);
-            if (!cur.waves.empty() && slice_scratch_bytes(waves_after, (nlq1 + 3) & ~3, nnch) > ctx->scratch_budget) break;
-            if (!cur.waves.empty() && (int64_t)cur.waves.size() * WAVE >= slice_pair_cap) break;
-            lq1 = nlq1;
-            nch = nnch;
-            WgInfo wg{};
-            bool too_many = false;
-            for (int64_t wq = p; wq < e; wq += WAVE) {
-                WaveInfo wi{0, 0};
-                const int64_t we = std::min<int64_t>(e, wq + WAVE);
-                for (int64_t q = wq; q < we; ++q) {
-                    const int f = pairs[q].fusion_idx;
-                    const dsa_fusion& fu = fusions[f];
-                    wi.lq_max = std::max(wi.lq_max, (int)pairs[q].read_len);
-                    wi.nch_max = std::max(wi.nch_max, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
-                    ctx->total_cells += (int64_t)(fu.ref0_len + 1 + fu.ref1_len + 1) * (pairs[q].read_len + 1);
-                    bool found = false;
-                    for (int k = 0; k < wg.n_groups; ++k) found |= wg.group_f[k] == f;
-                    if (!found) {
-                        if (wg.n_groups < GSPLIT2)
-                            wg.group_f[wg.n_groups++] = f;
-                        else
-                            too_many = true;
-                    }
-                }
-                cur.waves.push_back(wi);
-            }
-            if (too_many) wg.n_groups = 0;
-            cur.wgs.push_back(wg);
-            cur.wg_flags.push_back(too_many ? 1u : 0u);
-            p = e;
-        }
-        cur.pair_end = p;
-        cur.g.n_waves = (int32_t)cur.waves.size();
-        cur.g.n_wgs = (int32_t)cur.wgs.size();
-        cur.g.lq1 = (lq1 + 3) & ~3;     // row planes are stored four rows per 16-byte word
-        cur.g.nch = nch;
+        cur.pair_begin = b;
+        cur.pair_end = std::min(n_pairs, b + chunk);
+        const int64_t n = cur.pair_end - cur.pair_begin;
+        cur.g.n_waves = (int32_t)((n + WAVE - 1) / WAVE);
+        cur.g.n_wgs = (int32_t)((n + WG_LANES - 1) / WG_LANES);
+        cur.g.lq1 = lq1;
+        cur.g.nch = ctx->nch_all;
         cur.g.lrp = ctx->nch_all * W;
         cur.g.n_fusions = ctx->n_fusions;
-        cur.g.n_pairs = cur.pair_end - cur.pair_begin;
-        cur.g.orig = nullptr;
-        ctx->slices.push_back(std::move(cur));
+        cur.g.n_pairs = n;
+        cur.g.orig = nullptr;                       // set when the buffers are known (enqueue_plan)
+        ctx->slices.push_back(cur);
     }
+}
+
+// The sweep plan of the resident upload (dsa_plan.hpp), queued on the context's stream: no host round trip, nothing the host
+// waits for.  Per slice: runs per fusion, one workgroup per fusion (diagonals, bounds, ranks, tiles, sort key), radix sort
+// of the fusion keys, starts, permutation.  DEFUSE_DSA_NO_REORDER=1 keeps the caller's order (and drops the bounds),
+// DEFUSE_DSA_NO_RANK / _NO_TIGHTEN / _NO_LPT switch the parts of the plan off one by one.
+int enqueue_plan(dsa_ctx* ctx)
+{
+    const int nf = ctx->n_fusions;
+    const int64_t n_pairs = ctx->n_pairs;
+    if (n_pairs == 0 || nf == 0 || ctx->slices.empty()) return DSA_OK;
+    hipStream_t st = ctx->stream;
+    static const bool no_reorder = [] { const char* e = getenv("DEFUSE_DSA_NO_REORDER"); return e && atoi(e) != 0; }();
+    static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
+    static const bool no_tighten = [] { const char* e = getenv("DEFUSE_DSA_NO_TIGHTEN"); return e && atoi(e) != 0; }();
+    static const bool no_lpt = [] { const char* e = getenv("DEFUSE_DSA_NO_LPT"); return e && atoi(e) != 0; }();
+    int64_t max_chunk = 0;
+    for (const Slice& sl : ctx->slices) max_chunk = std::max(max_chunk, sl.pair_end - sl.pair_begin);
+    const int nb = (nf + PLACE_BLOCK - 1) / PLACE_BLOCK;
+    HIPC(ctx->plan_runs.reserve((size_t)nf));
+    HIPC(ctx->plan_key.reserve((size_t)nf));
+    HIPC(ctx->plan_key_sorted.reserve((size_t)nf));
+    HIPC(ctx->plan_fidx.reserve((size_t)nf));
+    HIPC(ctx->plan_order.reserve((size_t)nf));
+    HIPC(ctx->plan_bsum.reserve((size_t)nb));
+    HIPC(ctx->plan_start.reserve((size_t)nf));
+    HIPC(ctx->plan_flip.reserve((size_t)nf));
+    HIPC(ctx->plan_rank.reserve((size_t)max_chunk));
+    HIPC(ctx->plan_bound.reserve((size_t)max_chunk));
+    HIPC(ctx->plan_glob.reserve(ctx->slices.size()));
+    HIPC(ctx->d_orig.reserve((size_t)n_pairs));
+    HIPC(ctx->d_pairs.reserve((size_t)n_pairs + 1));
+    size_t sort_tmp = 0;
+    HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, ctx->plan_key.p, ctx->plan_key_sorted.p, ctx->plan_fidx.p, ctx->plan_order.p, nf, 0, 20, st));
+    HIPC(ctx->plan_sort_tmp.reserve(sort_tmp));
+    const PlanParams prm = ctx->plan_prm;
+    const size_t lds = plan_lds_bytes(prm.wc, prm.slots);
+    HIPC(hipEventRecord(ctx->ev_plan[0], st));
+    HIPC(hipMemsetAsync(ctx->plan_glob.p, 0, ctx->slices.size() * sizeof(PlanGlobals), st));
+    for (size_t k = 0; k < ctx->slices.size(); ++k) {
+        Slice& sl = ctx->slices[k];
+        const int64_t n = sl.pair_end - sl.pair_begin;
+        const dsa_pair* in = ctx->d_pairs_in.p + sl.pair_begin;
+        sl.g.orig = ctx->d_orig.p + sl.pair_begin;          // slice-relative indices of the caller's order
+        PlanGlobals* glob = ctx->plan_glob.p + k;
+        if (!no_reorder) {
+            HIPC(hipMemsetAsync(ctx->plan_runs.p, 0, (size_t)nf * sizeof(PlanRun), st));
+            hipLaunchKernelGGL(k_plan_runs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, ctx->plan_runs.p);
+            PlanParams pp = prm;
+            pp.use_rank = no_rank ? 0 : 1;
+            pp.use_bound = no_tighten ? 0 : 1;
+            pp.use_lpt = no_lpt ? 0 : 1;
+            hipLaunchKernelGGL(k_plan_fusion, dim3((unsigned)nf), dim3(PLAN_THREADS), lds, st, ctx->d_ref.p, ctx->d_fusions.p, ctx->d_reads.p, in,
+                               ctx->plan_runs.p, ctx->plan_key.p, ctx->plan_fidx.p, ctx->plan_rank.p, ctx->plan_bound.p, glob, pp);
+            size_t tmp = ctx->plan_sort_tmp.cap;
+            HIPC(hipcub::DeviceRadixSort::SortPairs(ctx->plan_sort_tmp.p, tmp, ctx->plan_key.p, ctx->plan_key_sorted.p, ctx->plan_fidx.p,
+                                                    ctx->plan_order.p, nf, 0, 20, st));
+            hipLaunchKernelGGL(k_plan_place_a, dim3((unsigned)nb), dim3(PLACE_BLOCK), 0, st, ctx->plan_order.p, ctx->plan_runs.p, nf, ctx->plan_bsum.p);
+            hipLaunchKernelGGL(k_plan_place_b, dim3((unsigned)nb), dim3(PLACE_BLOCK), 0, st, ctx->plan_order.p, ctx->plan_runs.p, nf, ctx->plan_bsum.p,
+                               ctx->plan_start.p, ctx->plan_flip.p);
+        }
+        hipLaunchKernelGGL(k_plan_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, ctx->plan_runs.p, ctx->plan_start.p,
+                           ctx->plan_flip.p, ctx->plan_rank.p, ctx->plan_bound.p, glob, no_reorder ? 1 : 0, ctx->d_pairs.p + sl.pair_begin,
+                           ctx->d_orig.p + sl.pair_begin);
+    }
+    HIPC(hipEventRecord(ctx->ev_plan[1], st));
+    HIPC(hipGetLastError());
+    ctx->plan_timed = true;
+    for (PipeLane& L : ctx->lanes->lane) L.resident_upload = -1;
     return DSA_OK;
 }
 
@@ -523,6 +380,8 @@ unsigned listed_grid(const PipeLane& L, int64_t n_pairs)
 void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, bool record_start = true)
 {
     const int64_t np = s.g.n_pairs;
+    Geom g = s.g;
+    g.tiers_launched = L.tiers_launched;
     const dsa_pair* pairs = ctx->d_pairs.p + s.pair_begin;
     dsa_record* out = ctx->d_records.p + ctx->n_records;
     L.emit_from = record_start ? 5 : 2;
@@ -533,12 +392,12 @@ void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, boo
     hipLaunchKernelGGL(k_emit_listed<true>, dim3(listed_grid(L, np)), dim3(EMIT_BLOCK), 0, L.aux, L.d_gtasks.p, (uint64_t)L.d_gtasks.cap, L.d_ctr.p,
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)L.d_rec_offset.p, out,
-                       (uint64_t)cap_left, (int64_t)s.pair_begin, s.g);
+                       (uint64_t)cap_left, (int64_t)s.pair_begin, g);
     (void)hipEventRecord(L.ev_join, L.aux);
     hipLaunchKernelGGL(k_emit_counted, dim3((unsigned)((np + EMIT_BLOCK - 1) / EMIT_BLOCK)), dim3(EMIT_BLOCK), 0, L.stream, pairs, ctx->d_fusions.p,
                        L.d_state.p, L.d_kept.p, L.d_tasks.p, L.d_masks.p, (const int64_t*)L.d_rec_offset.p, out, (uint64_t)cap_left,
                        (int64_t)s.pair_begin, L.d_ctr.p, (uint64_t)L.d_kept.cap, (uint64_t)L.d_tasks.cap, (uint64_t)(L.d_masks.cap / 2),
-                       (uint64_t)L.d_gtasks.cap, s.g);
+                       (uint64_t)L.d_gtasks.cap, g);
     (void)hipStreamWaitEvent(L.stream, L.ev_join, 0);
     (void)hipEventRecord(L.ev[6], L.stream);
 }
@@ -561,24 +420,24 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     // results: every command between two kernels costs a gap of its own on the stream)
     hipLaunchKernelGGL(k_reset_finish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_count.p + np);
     HIPC(hipEventRecord(L.ev[1], st));
-    // every workgroup is run by exactly one of the fill kernels
-    int64_t n_tier[3];
-    s.tiers(n_tier);
-    if (n_tier[0])
-        hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                           L.d_tmask.p, fb, g);
-    if (n_tier[1])
-        hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                           L.d_tmask.p, fb, g);
-    if (n_tier[2])
-        hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, L.d_wg_generic.p,
-                           ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                           L.d_tmask.p, fb, g);
-    hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_waves.p, L.d_wgs.p, ctx->d_fusions.p,
-                       L.d_wg_generic.p, ctx->d_refcodes.p, ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p,
-                       L.d_tmask.p, fb, g);
+    // Every workgroup is run by exactly one of the fill kernels: k_fill_fast<0> finds the owner of each (its table tier,
+    // or the generic kernel) and is always launched; the others only if the lane's last slice needed them (an empty launch
+    // is a gap of its own on the stream).  The slice says what it needed (Counters::need_tiers): phase2 runs it again with
+    // every kernel if one was missing.
+    const unsigned mask = L.tier_hint | 1u;
+    L.tiers_launched = mask;
+    g.tiers_launched = mask;
+    hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
+                       L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
+    if (mask & 2u)
+        hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
+                           L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
+    if (mask & 4u)
+        hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
+                           L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
+    if (mask & 8u)
+        hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p, L.d_wg_tier.p, ctx->d_refcodes.p,
+                           ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
     HIPC(hipEventRecord(L.ev[2], st));
     hipLaunchKernelGGL(k_replay, dim3(2048), dim3(REPLAY_BLOCK), 0, st, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_gtasks.p,
                        (uint64_t)L.d_gtasks.cap, L.d_ctr.p, L.d_state.p, L.d_kept.p, (uint64_t)L.d_kept.cap, pairs, ctx->d_fusions.p,
@@ -589,7 +448,8 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
                        (uint64_t)0, (int64_t)s.pair_begin, g);
     if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
     // the cursors and the record total go to the lane's pinned result words
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_offset.p + np, &L.host->ctr, &L.host->n_rec);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_offset.p + np, reinterpret_cast<const unsigned long long*>(ctx->plan_glob.p + (&s - ctx->slices.data())),
+                       &L.host->ctr, &L.host->n_rec, reinterpret_cast<unsigned long long*>(&L.host->plan));
     // The first slice of a run knows where its records go: write them right away, into the room there is, without
     // waiting for the host to read the total (phase2 runs the emit again after growing the buffer if it was short).
     L.emit_cap = 0;
@@ -616,9 +476,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     const int64_t np = g.n_pairs;
     if (g.lq1 > ((7600 + 1 + 3) & ~3)) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");   // lq1 is padded to a multiple of 4
     const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
-    HIPC(L.d_waves.reserve(s.waves.size()));
-    HIPC(L.d_wgs.reserve(s.wgs.size()));
-    HIPC(L.d_wg_generic.reserve(s.wg_flags.size()));
+    HIPC(L.d_wg_tier.reserve((size_t)g.n_wgs));
     HIPC(L.d_rowcodes.reserve(n_rows));
     HIPC(L.d_bnd.reserve(n_rows * g.nch));
     HIPC(L.d_cmax.reserve(n_rows * g.nch));
@@ -633,19 +491,6 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     HIPC(L.d_tasks.reserve((size_t)np * 4 + 1024));
     HIPC(L.d_masks.reserve((size_t)np * 8 + 1024));
     HIPC(L.d_gtasks.reserve((size_t)np * 2 + 1024));
-    // The wave / workgroup descriptors are inputs of the batch like the pairs themselves: a batch that is run
-    // again finds them on the device (the generic flags the fill kernel may have set for it stay valid too).
-    // All packing (reference codes here, row codes inside the fill) is redone by every run.
-    L.copied_descriptors = L.resident_upload != ctx->upload_serial || L.resident_slice != slice_idx;
-    if (L.copied_descriptors) {
-        HIPC(hipEventRecord(L.ev[0], st));
-        HIPC(hipMemcpyAsync(L.d_waves.p, s.waves.data(), s.waves.size() * sizeof(WaveInfo), hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(L.d_wgs.p, s.wgs.data(), s.wgs.size() * sizeof(WgInfo), hipMemcpyHostToDevice, st));
-        HIPC(hipMemcpyAsync(L.d_wg_generic.p, s.wg_flags.data(), s.wg_flags.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        L.resident_upload = ctx->upload_serial;
-        L.resident_slice = slice_idx;
-        HIPC(hipEventRecord(L.ev[4], st));      // end of the slice's descriptor copies (ev[1] is re-recorded by every launch_compute)
-    }
     if (int rc = launch_compute(ctx, L, s)) return rc;
     L.slice = slice_idx;
     return DSA_OK;
@@ -669,7 +514,9 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
         HIPC(hipStreamSynchronize(L.stream));
         HIPC(hipGetLastError());
         const Counters c = L.host->ctr;
-        if (c.n_kept <= L.d_kept.cap && c.n_tasks <= L.d_tasks.cap && c.n_masks <= L.d_masks.cap / 2 && c.n_gtasks <= L.d_gtasks.cap) break;
+        const bool tiers_ok = (c.need_tiers & ~L.tiers_launched) == 0;
+        L.tier_hint = tiers_ok ? c.need_tiers : 0xFu;          // what the next slice of this lane launches
+        if (tiers_ok && c.n_kept <= L.d_kept.cap && c.n_tasks <= L.d_tasks.cap && c.n_masks <= L.d_masks.cap / 2 && c.n_gtasks <= L.d_gtasks.cap) break;
         if (attempt >= 3) return fail(ctx, DSA_E_DEVICE, "finish stage did not converge");
         HIPC(L.d_kept.reserve(c.n_kept + 1024));
         HIPC(L.d_tasks.reserve(c.n_tasks + 1024));
@@ -728,8 +575,8 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
     }
 #endif
     L.last_gtasks = L.host->ctr.n_gtasks;
+    ctx->timing.cells += (int64_t)L.host->plan.cells;
     const int64_t n_rec = L.host->n_rec;
-    if (L.copied_descriptors) ctx->timing.pack_ms += elapsed(L.ev[0], L.ev[4]);
     if (!(L.emit_early && (uint64_t)n_rec <= L.emit_cap)) {
         if (L.emit_early) ctx->timing.finish_ms += elapsed(L.ev[L.emit_from], L.ev[6]);     // the short attempt was work too
         if (int rc = grow_records(ctx, (size_t)(ctx->n_records + n_rec))) return rc;
@@ -822,6 +669,7 @@ int dsa_create(dsa_ctx** out, int device)
         ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
     }
     for (auto& e : ctx->ev_pack) ok = ok && hipEventCreate(&e) == hipSuccess;
+    for (auto& e : ctx->ev_plan) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) {
         dsa_destroy(ctx);
         return DSA_E_DEVICE;
@@ -840,10 +688,14 @@ void dsa_destroy(dsa_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_sweep.release();
+    ctx->d_ref.release(); ctx->d_reads.release(); ctx->d_fusions.release(); ctx->d_pairs.release(); ctx->d_orig.release(); ctx->d_pairs_in.release();
     ctx->d_min_score.release(); ctx->d_records.release(); ctx->d_refcodes.release();
-    ctx->plan_stat.release(); ctx->plan_votes.release(); ctx->plan_start.release(); ctx->plan_rank.release(); ctx->plan_tiles.release();
+    ctx->plan_runs.release(); ctx->plan_key.release(); ctx->plan_key_sorted.release(); ctx->plan_fidx.release(); ctx->plan_order.release();
+    ctx->plan_bsum.release(); ctx->plan_start.release(); ctx->plan_rank.release(); ctx->plan_bound.release(); ctx->plan_flip.release();
+    ctx->plan_sort_tmp.release(); ctx->plan_glob.release();
     for (auto& e : ctx->ev_pack)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_plan)
         if (e) (void)hipEventDestroy(e);
     ctx->lanes.reset();          // the last context of a shared set frees the lanes (streams, events, scratch planes)
     delete ctx;
@@ -908,8 +760,11 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
         if (fu.ref0_len > lim.max_ref_len || fu.ref1_len > lim.max_ref_len)
             return fail(ctx, DSA_E_LIMIT, "fusion %d: reference window longer than %d", f, lim.max_ref_len);
     }
-    int nch_all = 1;
-    for (int32_t f = 0; f < n_fusions; ++f) nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
+    int nch_all = 1, maxwin = 0;
+    for (int32_t f = 0; f < n_fusions; ++f) {
+        nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
+        maxwin = std::max(maxwin, std::max(fusions[f].ref0_len, fusions[f].ref1_len));
+    }
     int lqmax = 0;
     for (int64_t p = 0; p < n_pairs; ++p) {
         const dsa_pair& pr = pairs[p];
@@ -928,28 +783,46 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     ctx->ref_bytes_len = ref_bytes_len;
     ctx->read_bytes_len = read_bytes_len;
     HIPC(ctx->d_ref.reserve((size_t)ref_bytes_len + 1));
-    HIPC(ctx->d_reads.reserve((size_t)read_bytes_len + 1));
+    HIPC(ctx->d_reads.reserve((size_t)read_bytes_len + 64));      // the planning kernels read whole dwords up to 36 bytes past a read's end
     HIPC(ctx->d_fusions.reserve((size_t)n_fusions + 1));
-    HIPC(ctx->d_pairs.reserve((size_t)n_pairs + 1));
+    HIPC(ctx->d_pairs_in.reserve((size_t)n_pairs + 1));
     ctx->nch_all = nch_all;
     HIPC(ctx->d_refcodes.reserve((size_t)n_fusions * nch_all * W + 1));
     hipStream_t st = ctx->stream;
     if (ref_bytes_len) HIPC(hipMemcpyAsync(ctx->d_ref.p, ref_bytes, ref_bytes_len, hipMemcpyHostToDevice, st));
     if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
     if (n_fusions) HIPC(hipMemcpyAsync(ctx->d_fusions.p, fusions, n_fusions * sizeof(dsa_fusion), hipMemcpyHostToDevice, st));
-    if (n_pairs) {
-        HIPC(hipMemcpyAsync(ctx->d_pairs.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_clear_pad, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st, ctx->d_pairs.p, n_pairs);
-    }
+    if (n_pairs) HIPC(hipMemcpyAsync(ctx->d_pairs_in.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
     std::vector<int32_t> tab(lqmax + 1);
     for (int l = 0; l <= lqmax; ++l) tab[l] = min_score_for(l);
     HIPC(ctx->d_min_score.reserve(tab.size()));
     HIPC(hipMemcpyAsync(ctx->d_min_score.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPC(hipStreamSynchronize(st));
-    const int planned = plan_sweep(ctx, fusions, n_pairs, lqmax);
-    if (planned < 0) return planned;
-    if (planned == 1) return DSA_OK;
-    return build_slices(ctx, fusions, pairs, n_pairs);
+    // geometry of the planning kernels: hash slots and packed words for the longest window that is planned at all
+    {
+        const int mw = std::min(maxwin, PLAN_MAXWIN - 1);
+        int slots = 256;
+        while (slots < 2 * mw) slots <<= 1;
+        ctx->plan_prm = PlanParams{};
+        ctx->plan_prm.n_fusions = n_fusions;
+        ctx->plan_prm.slots = slots;
+        ctx->plan_prm.wc = (mw + 2 * PLAN_PAD + 47) / 16 + 1;
+        ctx->plan_prm.tile_cols = W;
+    }
+    make_slices(ctx, n_pairs, lqmax);
+    if (int rc = enqueue_plan(ctx)) return rc;
+    HIPC(hipStreamSynchronize(st));             // the caller's buffers are free again when dsa_upload returns
+    HIPC(hipGetLastError());
+    return DSA_OK;
+}
+
+// The sweep planning of the resident upload once more (everything dsa_upload does after its copies), queued on the
+// context's stream; dsa_run follows it in stream order.
+int dsa_plan(dsa_ctx* ctx)
+{
+    if (!ctx) return DSA_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    ctx->have_results = false;
+    return enqueue_plan(ctx);
 }
 
 int dsa_run(dsa_ctx* ctx, int64_t* out_n)
@@ -958,7 +831,6 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
     HIPC(hipSetDevice(ctx->device));
     ctx->n_records = 0;
     ctx->timing = dsa_timing{};
-    ctx->timing.cells = ctx->total_cells;
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
     const auto t0 = std::chrono::steady_clock::now();
@@ -993,6 +865,11 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
         HIPC(hipStreamSynchronize(L.stream));
     }
     if (ns > 0 && ctx->n_fusions > 0) ctx->timing.pack_ms += elapsed(ctx->ev_pack[0], ns > 1 ? ctx->ev_pack[1] : ctx->lanes->lane[0].ev[1]);
+    if (ctx->plan_timed) {                    // the planning that preceded this run, on the same stream
+        ctx->last_plan_ms = elapsed(ctx->ev_plan[0], ctx->ev_plan[1]);
+        ctx->plan_timed = false;
+    }
+    ctx->timing.plan_ms = ctx->last_plan_ms;
     // stage times are per-stream sums and overlap between the lanes; total_ms is the elapsed time
     ctx->timing.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     ctx->timing.n_records = ctx->n_records;

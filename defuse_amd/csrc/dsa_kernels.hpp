@@ -124,29 +124,25 @@ struct WaveInfo {
     int32_t nch_max;       // most tiles among the wave's pairs (either matrix)
 };
 
-// Per workgroup (WG_WAVES waves = WG_LANES pairs): the distinct fusions of its pairs, for the fast path.
-struct WgInfo {
-    int32_t n_groups;              // 0 => generic kernel (more than GSPLIT fusions); > GMAX => split tables
-    int32_t group_f[GSPLIT2];      // fusion_idx
-};
+// Which kernel sweeps a workgroup (wg_tier[], written by k_fill_fast<0>, which is always launched first): the table tiers 0..2
+// of k_fill_fast or TIER_GENERIC; the bits of Counters::need_tiers say which kernels a slice needs at all.
+constexpr uint8_t TIER_GENERIC = 3;
 
-// What a kernel keeps of its workgroup's descriptor: the first GMAX fusions in registers (all there are for
-// the 25-row-table tier) and a pointer to the full list for the split-table tiers.  Copying the whole
-// WgInfo into a kernel costs scratch and 1-2 % of the common case.
+// Per workgroup (WG_WAVES waves = WG_LANES pairs): the fusions of its pairs, for the fast path.  A "group" is a run of
+// consecutive pairs of one fusion (in a planned sweep every fusion is one run, so groups are the distinct fusions; a fusion
+// that comes back later in an unplanned order simply gets a second table).  The fill kernels find the runs themselves, in
+// their prologue (wg_groups): every lane knows its group, the list of the groups' fusions lives in LDS.
+struct WgGroupsLds {
+    int32_t wave_starts[WG_WAVES];     // runs that begin in each wave
+    int32_t group_f[GSPLIT2];          // fusion_idx of group k
+};
+// What a kernel keeps of its workgroup's groups: the first GMAX fusions in registers (all there are for the 25-row-table
+// tier) and a pointer to the full list for the split-table tiers.
 struct WgView {
-    int32_t n_groups;
+    int32_t n_groups;      // 0: more than GSPLIT2 runs (generic kernel)
     int32_t f4[GMAX];
     const int32_t* list;
 };
-__device__ __forceinline__ WgView view_of(const WgInfo* w)
-{
-    WgView v;
-    v.n_groups = w->n_groups;
-#pragma unroll
-    for (int k = 0; k < GMAX; ++k) v.f4[k] = w->group_f[k];
-    v.list = w->group_f;
-    return v;
-}
 __device__ __forceinline__ int group_fusion(const WgView& v, int k)      // fusion_idx of group k < n_groups
 {
     if (v.n_groups > GMAX) return v.list[k];                          // uniform
@@ -156,18 +152,34 @@ __device__ __forceinline__ int group_fusion(const WgView& v, int k)      // fusi
         if (k == j) f = v.f4[j];
     return f;
 }
-__device__ __forceinline__ int group_of(const WgView& v, int fusion_idx)  // group of a fusion of the workgroup, -1 if none
+// Prologue of the fill kernels, called by all threads of the workgroup (barrier inside): f = fusion of the lane's pair (lanes
+// past the end shadow the last pair), f_before = fusion of the pair before the workgroup's first (any value for workgroup 0's
+// first lane: it starts a run anyway).  Returns the view; my_group = the lane's group (meaningful while n_groups > 0).
+__device__ __forceinline__ WgView wg_groups(WgGroupsLds* gl, int f, int f_prev_of_wave_lane0, int& my_group)
 {
-    int gsel = -1;
-    if (v.n_groups > GMAX) {
-        for (int k = 0; k < v.n_groups; ++k)
-            if (v.list[k] == fusion_idx) gsel = k;
-    } else {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int fprev = __shfl_up(f, 1, 64);
+    if (lane == 0) fprev = f_prev_of_wave_lane0;
+    const bool start = tid == 0 || f != fprev;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(start);
+    if (lane == 0) gl->wave_starts[wv] = __builtin_popcountll(m);
+    __syncthreads();
+    int base = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < GMAX; ++k)
-            if (k < v.n_groups && v.f4[k] == fusion_idx) gsel = k;
+    for (int k = 0; k < WG_WAVES; ++k) {
+        const int c = gl->wave_starts[k];
+        if (k < wv) base += c;
+        total += c;
     }
-    return gsel;
+    my_group = base + __builtin_popcountll(m & ((2ull << lane) - 1ull)) - 1;
+    if (start && my_group < GSPLIT2) gl->group_f[my_group] = f;
+    __syncthreads();
+    WgView v;
+    v.n_groups = total <= GSPLIT2 ? total : 0;
+    v.list = gl->group_f;
+#pragma unroll
+    for (int k = 0; k < GMAX; ++k) v.f4[k] = k < total ? gl->group_f[k] : 0;
+    return v;
 }
 
 // Geometry shared by all kernels of one run (one slice).  Pair p <-> wave p>>6, lane p&63.
@@ -180,6 +192,7 @@ struct Geom {
     int32_t n_fusions;
     int64_t n_pairs;
     const int32_t* orig;   // pair order of the sweep -> the caller's pair index (nullptr: the same order)
+    uint32_t tiers_launched;   // fill kernels this slice was given (bit t: k_fill_fast<t>, bit 3: k_fill_generic)
 #ifdef DSA_PRUNE_STATS
     unsigned long long* stats;   // diagnostic builds only
 #endif
@@ -231,6 +244,8 @@ constexpr uint8_t STATE_TILES = 2;     // tiles0 / tiles1 are valid (windows of 
 
 struct Counters {          // device-side allocation cursors (and overflow detection)
     unsigned long long n_kept, n_tasks, n_masks, n_gtasks;
+    unsigned need_tiers;   // bit t: some workgroup of the slice belongs to fill kernel t (1, 2: split-table tiers, 3: generic)
+    unsigned pad_;
 };
 
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
@@ -260,361 +275,6 @@ __global__ void k_pack_refs(const uint8_t* __restrict__ ref_bytes, const dsa_fus
     if (i < f.ref0_len) lo = (uint32_t)ref_bytes[(int64_t)f.ref0_off + i] << 8;
     if (i < f.ref1_len) hi = (uint32_t)ref_bytes[(int64_t)f.ref1_off + (f.ref1_len - 1 - i)] << 8;
     refcodes[t] = lo | (hi << 16);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sweep planning on the device (speed heuristic only: any order gives the same records).
-//   k_fusion_stats: per fusion the number of pairs, the first and last pair index (callers group pairs by
-//                   fusion; a fusion whose pairs are not one run switches planning off), read length max / sum.
-//   k_probe_wave:   one wave per (fusion, voter): the first PROBE_READS reads of a fusion vote for the tile in
-//                   which their M1 / M2 alignment ends.  The first 16 bases of the read are looked up in window 0
-//                   (64 positions per step, one per lane) and extended along the diagonal, the last 16 bases in
-//                   window 1 and extended backwards (X-drop).  k_probe_pick takes the majority per window.
-//   k_permute_pairs: pairs into sweep order.
-// Fusions whose alignments end in the same tiles are swept next to each other, so that a wave that straddles
-// two fusions is alive in the same tiles for both and the exact pruning stops the others early.
-// ---------------------------------------------------------------------------------------------
-constexpr int PROBE_READS = 4, PROBE_SEED = 16, PROBE_TILES = 16;
-struct FusionStat {
-    int32_t count, first, last, max_lq;
-    long long sum_lq;
-};
-__global__ void k_fusion_stats_init(FusionStat* __restrict__ st, int n_fusions)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_fusions) return;
-    FusionStat s;
-    s.count = 0;
-    s.first = 0x7FFFFFFF;
-    s.last = -1;
-    s.max_lq = 0;
-    s.sum_lq = 0;
-    st[f] = s;
-}
-__global__ void k_fusion_stats(const dsa_pair* __restrict__ pairs, int64_t n_pairs, FusionStat* __restrict__ st)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const dsa_pair pr = pairs[p];
-    FusionStat* s = st + pr.fusion_idx;
-    // runs of one fusion: only the ends of a run touch first / last, one lane per run adds the count
-    const bool run_begin = p == 0 || pairs[p - 1].fusion_idx != pr.fusion_idx;
-    const bool run_end = p + 1 == n_pairs || pairs[p + 1].fusion_idx != pr.fusion_idx;
-    if (run_begin) atomicMin(&s->first, (int32_t)p);
-    if (run_end) atomicMax(&s->last, (int32_t)p);
-    atomicAdd(&s->count, 1);
-    atomicMax(&s->max_lq, pr.read_len);
-    atomicAdd((unsigned long long*)&s->sum_lq, (unsigned long long)pr.read_len);
-}
-
-__global__ __launch_bounds__(64) void k_probe_wave(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
-                                                   const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
-                                                   const FusionStat* __restrict__ st, int32_t* __restrict__ votes)
-{
-    const int f = blockIdx.x / PROBE_READS, v = blockIdx.x % PROBE_READS;
-    const int lane = threadIdx.x;
-    const FusionStat s = st[f];
-    if (v >= s.count) return;
-    const dsa_pair pr = pairs[s.first + v];
-    if (pr.fusion_idx != f) return;                                // not one run: no vote
-    const int lq = pr.read_len;
-    if (lq < PROBE_SEED + 8) return;
-    const dsa_fusion fu = fusions[f];
-    const uint8_t* rd = read_bytes + pr.read_off;
-    const uint8_t* r0 = ref_bytes + fu.ref0_off;
-    const uint8_t* r1 = ref_bytes + fu.ref1_off;
-    // M1: first window position at which the read's first PROBE_SEED bases match
-    int x0 = -1;
-    for (int base = 0; base + PROBE_SEED <= fu.ref0_len && x0 < 0; base += WAVE) {
-        const int x = base + lane;
-        bool ok = x + PROBE_SEED <= fu.ref0_len;
-        for (int k = 0; k < PROBE_SEED && ok; ++k) ok = r0[x + k] == rd[k];
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-        if (m) x0 = base + __builtin_ctzll(m);
-    }
-    // M2: first window position at which its last PROBE_SEED bases match
-    int y0 = -1;
-    for (int base = 0; base + PROBE_SEED <= fu.ref1_len && y0 < 0; base += WAVE) {
-        const int y = base + lane;
-        bool ok = y + PROBE_SEED <= fu.ref1_len;
-        for (int k = 0; k < PROBE_SEED && ok; ++k) ok = r1[y + k] == rd[lq - PROBE_SEED + k];
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-        if (m) y0 = base + __builtin_ctzll(m);
-    }
-    if (lane != 0) return;
-    if (x0 >= 0) {                                                 // extend forwards (X-drop)
-        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;
-        for (int k = PROBE_SEED; k < lq && x0 + k < fu.ref0_len && score > best - 6; ++k) {
-            score += r0[x0 + k] == rd[k] ? 1 : -2;
-            if (score > best) { best = score; best_k = k; }
-        }
-        const int tile = (x0 + best_k) / W;                         // matrix column x0 + best_k + 1
-        atomicAdd(&votes[((int64_t)f * 2 + 0) * PROBE_TILES + min(tile, PROBE_TILES - 1)], 1);
-    }
-    if (y0 >= 0) {                                                 // extend backwards; k counts bases from the read's end
-        int score = PROBE_SEED, best = score, best_k = PROBE_SEED - 1;
-        for (int k = PROBE_SEED; k < lq && y0 + PROBE_SEED - 1 - k >= 0 && score > best - 6; ++k) {
-            score += r1[y0 + PROBE_SEED - 1 - k] == rd[lq - 1 - k] ? 1 : -2;
-            if (score > best) { best = score; best_k = k; }
-        }
-        const int s1 = y0 + PROBE_SEED - 1 - best_k;                // first window-1 base of the aligned suffix
-        const int tile = (fu.ref1_len - s1 - 1) / W;                // its column in the reversed window is len1 - s1
-        atomicAdd(&votes[((int64_t)f * 2 + 1) * PROBE_TILES + min(max(tile, 0), PROBE_TILES - 1)], 1);
-    }
-}
-
-// Order of the pairs INSIDE a fusion (speed only, like the order of the fusions).  All reads of a fusion end their window-0
-// alignment in the same column (the junction) and begin it a read-split a* earlier, so the rows of M1 a wave must sweep in
-// the junction's tile are max(a*) of its lanes, and those of M2 in its tile Lq - min(a*).  Reads in caller order give every
-// wave the full range; sorted by a* a wave holds a contiguous part of it and both matrices stop earlier (exact pruning,
-// DESIGN.md 4).  a* is estimated by the diagonal of the read's first 11-mer found in window 0 (hash of the window's
-// 11-mers in LDS; a read without one — its junction is in its first bases, or it does not belong — sorts to the
-// small-a* end).  Fusions alternate the direction (flip) so that a wave straddling two fusions continues in the same range.
-// One workgroup per fusion; rank[p - first] = position of pair p inside the fusion's run.  Fusions with more than
-// RANK_MAX pairs or windows of 1000 bases and more keep the caller's order.
-//
-// The same lookups give every pair a LOWER BOUND of its final score, which tightens the exact pruning: with
-// the read's first 11-mers on a diagonal d1 of window 0 and its last ones on a diagonal d2 of window 1, the ungapped paths
-// along them are valid DP paths (free start in the reference), so m1(a) >= P1(a) = sum_{j<a} c1(j) and m2(Lq-a) >= P2(a) =
-// sum_{j>=a} c2(j) (c = +2 match / -1 mismatch along the diagonal), and the best split scores at least
-// T' = max_a P1(a) + P2(a) over the a where both sides reach the anchor minimum 8.  Only splits of the final maximum
-// s* >= T' are ever emitted, so "cannot reach minScore" becomes "cannot reach max(minScore, T')" with the same proof;
-// for a clean read T' is within a few points of 2 Lq and a tile without a real alignment dies after a handful of rows
-// instead of twenty.  T' travels to the fill kernels in the two padding bytes of the DEVICE copy of dsa_pair (0 = no bound).
-constexpr int RANK_MAX = 2048, RANK_K = 11, RANK_HASH = 2048, RANK_THREADS = 128;
-__device__ __forceinline__ void rank_table_insert(uint32_t* table, uint32_t km, int x)
-{
-    const uint32_t val = (km << 10) | (uint32_t)x;
-    uint32_t h = (km * 2654435761u) >> 21;                     // 11 bits
-    for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
-        const uint32_t old = atomicCAS(&table[h], 0xFFFFFFFFu, val);
-        if (old == 0xFFFFFFFFu) break;
-        if ((old >> 10) == km) { atomicMin(&table[h], val); break; }     // same 11-mer: the smallest position stays
-    }
-}
-__device__ __forceinline__ int rank_table_find(const uint32_t* table, uint32_t km)
-{
-    uint32_t h = (km * 2654435761u) >> 21;
-    for (int probe = 0; probe < RANK_HASH; ++probe, h = (h + 1) & (RANK_HASH - 1)) {
-        const uint32_t e = table[h];
-        if (e == 0xFFFFFFFFu) return -1;
-        if ((e >> 10) == km) return (int)(e & 1023u);
-    }
-    return -1;
-}
-__global__ __launch_bounds__(RANK_THREADS) void k_rank_in_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
-                                                        const uint8_t* __restrict__ read_bytes, dsa_pair* __restrict__ pairs,
-                                                        const FusionStat* __restrict__ st, const uint8_t* __restrict__ flip,
-                                                        int32_t* __restrict__ rank, int tighten)
-{
-    __shared__ uint32_t table[RANK_HASH];          // window 0: (11-mer << 10) | first position, ~0 = empty
-    __shared__ uint32_t table1[RANK_HASH];         // window 1 likewise
-    __shared__ uint32_t keys[RANK_MAX];            // (sort key << 16) | index inside the fusion
-    const int f = blockIdx.x;
-    const FusionStat s = st[f];
-    const int n = s.count;
-    if (n <= 0) return;
-    const int64_t p0 = s.first;
-    const dsa_fusion fu = fusions[f];
-    if (n > RANK_MAX || n < 2 || fu.ref0_len >= 1000 || fu.ref0_len < RANK_K) {
-        for (int k = threadIdx.x; k < n; k += blockDim.x) { rank[p0 + k] = k; pairs[p0 + k].pad_[0] = 0; pairs[p0 + k].pad_[1] = 0; }
-        return;
-    }
-    auto code = [](uint8_t b) -> int { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; };
-    const bool bound = tighten != 0 && fu.ref1_len >= RANK_K && fu.ref1_len < 1000;
-    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) { table[k] = 0xFFFFFFFFu; table1[k] = 0xFFFFFFFFu; }
-    __syncthreads();
-    const uint8_t* r0 = ref_bytes + fu.ref0_off;
-    const uint8_t* r1 = ref_bytes + fu.ref1_off;
-    auto kmer_at = [&](const uint8_t* p, uint32_t& km) {
-        km = 0;
-        bool ok = true;
-        for (int k = 0; k < RANK_K; ++k) {
-            const int c = code(p[k]);
-            ok = ok && c >= 0;
-            km = (km << 2) | (uint32_t)(c & 3);
-        }
-        return ok;
-    };
-    for (int x = threadIdx.x; x + RANK_K <= fu.ref0_len; x += blockDim.x) {
-        uint32_t km;
-        if (kmer_at(r0 + x, km)) rank_table_insert(table, km, x);
-    }
-    if (bound)
-        for (int x = threadIdx.x; x + RANK_K <= fu.ref1_len; x += blockDim.x) {
-            uint32_t km;
-            if (kmer_at(r1 + x, km)) rank_table_insert(table1, km, x);
-        }
-    __syncthreads();
-    // (A) per read: the diagonals of its first 11-mers in window 0 (d1) and of its last ones in window 1 (d2); reads that have
-    // both vote on d2 - d1, which is the same for every read of the fusion that spans its junction (both are "junction minus
-    // read split")
-    __shared__ short s_d1[RANK_MAX], s_d2[RANK_MAX];
-    __shared__ uint8_t s_have[RANK_MAX];
-    int* s_votes = reinterpret_cast<int*>(keys);   // histogram of d2 - d1 + 1024 (the sort keys are written after the vote)
-    __shared__ int s_delta, s_delta_votes;
-    // the windows (< 1000 bytes each) are staged in LDS: the bound's loops walk them along two diagonals per read
-    __shared__ uint8_t s_win[2][1000];
-    if (bound) {
-        for (int k = threadIdx.x; k < fu.ref0_len; k += blockDim.x) s_win[0][k] = r0[k];
-        for (int k = threadIdx.x; k < fu.ref1_len; k += blockDim.x) s_win[1][k] = r1[k];
-    }
-    for (int k = threadIdx.x; k < RANK_HASH; k += blockDim.x) s_votes[k] = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const dsa_pair pr = pairs[p0 + k];
-        const uint8_t* rd = read_bytes + pr.read_off;
-        const int lq = pr.read_len;
-        int d1 = 0, d2 = 0;
-        bool have1 = false, have2 = false;
-        for (int off = 0; off <= 12 && off + RANK_K <= lq && !have1; off += 4) {
-            uint32_t km;
-            if (!kmer_at(rd + off, km)) continue;
-            const int x = rank_table_find(table, km);
-            if (x >= 0) { d1 = x - off; have1 = true; }
-        }
-        if (bound)
-            for (int off = 0; off <= 12 && off + RANK_K <= lq && !have2; off += 4) {     // the read's last 11-mers in window 1
-                uint32_t km;
-                const int at = lq - RANK_K - off;
-                if (!kmer_at(rd + at, km)) continue;
-                const int y = rank_table_find(table1, km);
-                if (y >= 0) { d2 = y - at; have2 = true; }
-            }
-        s_d1[k] = (short)d1;
-        s_d2[k] = (short)d2;
-        s_have[k] = (uint8_t)((have1 ? 1 : 0) | (have2 ? 2 : 0));
-        if (have1 && have2) {
-            const int v = d2 - d1 + 1024;
-            if (v >= 0 && v < RANK_HASH) atomicAdd(&s_votes[v], 1);
-        }
-    }
-    __syncthreads();
-    {   // the mode of the votes; ties to the smaller difference (deterministic): every thread scans its share, then a wave
-        // and a workgroup maximum over (count, -difference)
-        unsigned mine = 0;
-        for (int v = threadIdx.x; v < RANK_HASH; v += blockDim.x) {
-            const unsigned c = (unsigned)s_votes[v];
-            if (c) mine = max(mine, (c << 12) | (unsigned)(4095 - v));
-        }
-        for (int d = 32; d >= 1; d >>= 1) mine = max(mine, (unsigned)__shfl_xor((int)mine, d, 64));
-        __shared__ unsigned s_best[RANK_THREADS / 64];
-        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = mine;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned b = 0;
-            for (int w = 0; w < RANK_THREADS / 64; ++w) b = max(b, s_best[w]);
-            s_delta_votes = (int)(b >> 12);
-            s_delta = b ? (4095 - (int)(b & 4095u)) - 1024 : 0;
-        }
-    }
-    __syncthreads();
-    int npad = 1;
-    while (npad < n) npad <<= 1;
-    for (int k = threadIdx.x; k < npad; k += blockDim.x) {
-        uint32_t key = 0xFFFF0000u | (uint32_t)k;                 // padding sorts behind everything
-        if (k < n) {
-            const dsa_pair pr = pairs[p0 + k];
-            const uint8_t* rd = read_bytes + pr.read_off;
-            const int lq = pr.read_len;
-            int d1 = s_d1[k], d2 = s_d2[k];
-            bool have1 = (s_have[k] & 1) != 0, have2 = (s_have[k] & 2) != 0;
-            // (B) a read with one side only (its junction lies within a few bases of one end) takes the other diagonal from
-            // the fusion's vote; any pair of diagonals gives a VALID bound below, a wrong guess only a weak one
-            if (s_delta_votes > 0) {
-                if (have1 && !have2) { d2 = d1 + s_delta; have2 = true; }
-                else if (have2 && !have1) { d1 = d2 - s_delta; have1 = true; }
-            }
-            const int diag = have1 ? min(1022, max(0, d1 + 16)) : 1023;      // no diagonal at all: sorts to the small-a* end
-            uint16_t tprime = 0;
-            // (C) read base j lies on window 0 position j + d1 (prefix side) and on window 1 position j + d2 (suffix side)
-            if (bound && have1 && have2 && d1 >= 0 && lq - 1 + d2 < fu.ref1_len && lq > 0) {
-                const int a_hi = min(lq, fu.ref0_len - d1);        // the prefix path stays inside window 0
-                const int a_lo = max(0, -d2);                      // the suffix path stays inside window 1
-                const uint8_t* rb = rd;
-                const uint8_t* w0 = s_win[0] + d1;                 // w0[j] = window 0 base under read base j
-                const uint8_t* w1 = s_win[1] + d2;
-                if (a_lo <= a_hi) {
-                    int suf = 0;                                   // P2(a_lo) = sum over j >= a_lo of c2(j)
-                    for (int j = a_lo; j < lq; ++j) suf += rb[j] == w1[j] ? DSA_MATCH : DSA_MISMATCH;
-                    int pre = 0, best = 0;                         // P1(a)
-                    for (int j = 0; j < a_lo; ++j) pre += rb[j] == w0[j] ? DSA_MATCH : DSA_MISMATCH;
-                    for (int a = a_lo; a <= a_hi; ++a) {
-                        if (pre >= DSA_MIN_SPLIT && suf >= DSA_MIN_SPLIT) best = max(best, pre + suf);
-                        if (a < a_hi) {                            // a < lq here: a_hi <= lq
-                            const uint8_t c = rb[a];
-                            pre += c == w0[a] ? DSA_MATCH : DSA_MISMATCH;
-                            suf -= c == w1[a] ? DSA_MATCH : DSA_MISMATCH;
-                        }
-                    }
-                    tprime = (uint16_t)min(best, 65535);
-                }
-            }
-            pairs[p0 + k].pad_[0] = (uint8_t)(tprime & 0xFF);
-            pairs[p0 + k].pad_[1] = (uint8_t)(tprime >> 8);
-            const int kk = flip[f] ? 1023 - diag : diag;
-            key = ((uint32_t)kk << 16) | (uint32_t)k;
-        }
-        keys[k] = key;
-    }
-    __syncthreads();
-    // bitonic sort of keys[0 .. npad) ascending: (key, index) pairs are distinct, so the order is fully determined
-    for (int size = 2; size <= npad; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
-                const int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
-                const bool up = ((lo / size) & 1) == 0;
-                const uint32_t a = keys[lo], b = keys[hi];
-                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-            }
-            __syncthreads();
-        }
-    for (int r = threadIdx.x; r < n; r += blockDim.x) rank[p0 + (keys[r] & 0xFFFFu)] = r;
-}
-
-// the padding bytes of the device copy of the pairs carry the per-pair score bound (k_rank_in_fusion); whatever the caller
-// had in them is cleared at upload
-__global__ void k_clear_pad(dsa_pair* __restrict__ pairs, int64_t n_pairs)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    pairs[p].pad_[0] = 0;
-    pairs[p].pad_[1] = 0;
-}
-
-// the caller's order inside every fusion
-__global__ void k_rank_identity(const dsa_pair* __restrict__ pairs, int64_t n_pairs, const FusionStat* __restrict__ st, int32_t* __restrict__ rank)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    rank[p] = (int32_t)(p - st[pairs[p].fusion_idx].first);
-}
-
-// pair p of fusion f (one run starting at first[f]) goes to sweep position new_start[f] + rank[p] (its place inside the fusion)
-__global__ void k_permute_pairs(const dsa_pair* __restrict__ pairs, int64_t n_pairs, const FusionStat* __restrict__ st,
-                                const int32_t* __restrict__ new_start, const int32_t* __restrict__ rank, dsa_pair* __restrict__ sweep,
-                                int32_t* __restrict__ orig)
-{
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
-    const dsa_pair pr = pairs[p];
-    (void)st;
-    const int64_t q = (int64_t)new_start[pr.fusion_idx] + rank[p];
-    sweep[q] = pr;
-    orig[q] = (int32_t)p;
-}
-
-// tiles[2f + s] = majority tile of window s of fusion f, 255 without votes
-__global__ void k_probe_pick(const int32_t* __restrict__ votes, int n_windows, uint8_t* __restrict__ tiles)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_windows) return;
-    int best = 0, tile = 255;
-    for (int t = 0; t < PROBE_TILES; ++t) {
-        const int n = votes[(int64_t)q * PROBE_TILES + t];
-        if (n > best) { best = n; tile = t; }
-    }
-    tiles[q] = (uint8_t)tile;
 }
 
 __device__ __forceinline__ bool is_fast_base(uint32_t b)
@@ -866,7 +526,7 @@ template <bool HANDOFF>
 __device__ __forceinline__ void combine_wg(
     const dsa_pair* __restrict__ pairs, const dsa_fusion* __restrict__ fusions, const uint32_t* __restrict__ cmax,
     const uint32_t* __restrict__ rmax, const uint32_t* __restrict__ tmask, const int32_t* __restrict__ min_score_tab,
-    const WgView& wgi, bool fast_wg, FinishLds* fl, const FinishBufs& fb, const Geom& g)
+    const WgView& wgi, int my_group, bool fast_wg, FinishLds* fl, const FinishBufs& fb, const Geom& g)
 {
     PairState* __restrict__ state = fb.state;
     KeptRow* __restrict__ kept = fb.kept;
@@ -1016,7 +676,7 @@ __device__ __forceinline__ void combine_wg(
     // gives the same records: what is left goes to the generic replay, and a tie's tile alone is a short task there).
     // Votes are 16-bit counters in the LDS words that later serve the replay's counting sort; windows of more
     // than VOTE_TILES tiles take the first offer of a (lowest M1 tile, lowest M2 tile) instead.
-    const int gsel = group_of(wgi, fidx);
+    const int gsel = my_group;            // the lane's run of pairs of one fusion (wg_groups)
     int f0 = small ? nth_set_bit(tiles0, 0) : (n_t0 > 0 ? 0 : -1), f1 = small ? nth_set_bit(tiles1, 0) : (n_t1 > 0 ? 0 : -1);   // tiles of task 0
     const bool eligible = n_tasks > 0 && small && fast_wg && gsel >= 0 && f0 >= 0 && f1 >= 0;
     const int key = eligible ? ((f0 << 8) | f1) : -1;
@@ -1566,10 +1226,8 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
 }
 
 __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __restrict__ pairs,
-                                                           const WaveInfo* __restrict__ winfo,
-                                                           const WgInfo* __restrict__ wginfo,
                                                            const dsa_fusion* __restrict__ fusions,
-                                                           const uint32_t* __restrict__ wg_generic,
+                                                           const uint8_t* __restrict__ wg_tier,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint8_t* __restrict__ read_bytes,
                                                            uint32_t* __restrict__ rowcodes,
@@ -1579,27 +1237,30 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
                                                            FinishBufs fb, Geom g)
 {
     __shared__ FinishLds fl;
-    if (wg_generic[blockIdx.x] == 0) return;     // the fast kernel owns this workgroup (uniform)
+    if (wg_tier[blockIdx.x] != TIER_GENERIC) return;     // a table kernel owns this workgroup (uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     if (w < g.n_waves) {                         // whole waves past the end only join the combine barriers
         const int lane = threadIdx.x & 63;
         const int64_t p = min((int64_t)w * WAVE + lane, g.n_pairs - 1);   // tail lanes shadow the last pair
-        const WaveInfo wi = winfo[w];
-        (void)pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);   // the fast kernel packs only what it keeps
+        const bool in_batch = (int64_t)w * WAVE + lane < g.n_pairs;
         const int f = pairs[p].fusion_idx;
         const dsa_fusion fu = fusions[f];
-        const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
-        const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
-        int lq_lane = 0, slack = 0;
-        if ((int64_t)w * WAVE + lane < g.n_pairs) {
-            lq_lane = pairs[p].read_len;
-            slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pairs[p]));
-        }
         auto wave_max = [](int v) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
             return v;
         };
+        WaveInfo wi;                             // rows and tiles of the wave, from its own pairs
+        wi.lq_max = wave_max(in_batch ? (int)pairs[p].read_len : 0);
+        wi.nch_max = wave_max(in_batch ? max(cdiv_dev(fu.ref0_len, W), cdiv_dev(fu.ref1_len, W)) : 0);
+        (void)pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);   // the fast kernel packs only what it keeps
+        const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
+        const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+        int lq_lane = 0, slack = 0;
+        if (in_batch) {
+            lq_lane = pairs[p].read_len;
+            slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pairs[p]));
+        }
         int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
         int stop_prev = 0;
         TileStops stops = {};
@@ -1627,8 +1288,9 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
         reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
-    const WgView wgi = view_of(wginfo + blockIdx.x);
-    combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, false, &fl, fb, g);   // every task goes to k_replay
+    WgView wgi = {};                             // no tables, no groups: every task goes to k_replay
+    wgi.list = nullptr;
+    combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, 0, false, &fl, fb, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1649,9 +1311,7 @@ __host__ __device__ constexpr int tier_of(int n_groups) { return n_groups <= GMA
 #endif
 template <int TIER>
 __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill_fast(const dsa_pair* __restrict__ pairs,
-                                                           const WaveInfo* __restrict__ winfo,
-                                                           const WgInfo* __restrict__ wginfo,
-                                                           uint32_t* __restrict__ wg_generic,
+                                                           uint8_t* __restrict__ wg_tier,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint8_t* __restrict__ read_bytes,
                                                            uint32_t* __restrict__ rowcodes,
@@ -1665,34 +1325,48 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     __shared__ __attribute__((aligned(16))) uint32_t T[TIER == 2 ? GSPLIT2 * TGROUP_SPLIT : GMAX * TGROUP];
     __shared__ int s_nch, s_exotic;
     __shared__ FinishLds fl;
-    if (wg_generic[blockIdx.x] != 0) return;     // the generic kernel owns this workgroup (uniform)
-    const WgView wgi = view_of(wginfo + blockIdx.x);
-    if (tier_of(wgi.n_groups) != TIER) return;   // another instantiation owns it (uniform)
+    __shared__ WgGroupsLds gl;
+    // k_fill_fast<0> is launched first and says which kernel owns every workgroup; the others read that (uniform)
+    if (TIER != 0 && wg_tier[blockIdx.x] != TIER) return;
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * WG_WAVES + (threadIdx.x >> 6)));
     const bool live = w < g.n_waves;             // whole waves past the end still join the barriers
     const int lane = threadIdx.x & 63;
-    WaveInfo wi = {0, 0};
-    int f = 0;
+    // The descriptors of the workgroup come from its own pairs: the runs of pairs of one fusion (table groups), the wave's
+    // longest read and widest window.
+    const int64_t p = (int64_t)w * WAVE + lane;
+    const bool in_batch = p < g.n_pairs;
+    const dsa_pair pr = pairs[min(p, g.n_pairs - 1)];      // lanes past the end shadow the last pair
+    const int f = pr.fusion_idx;
+    int my_group;
+    const WgView wgi = wg_groups(&gl, f, (lane == 0 && threadIdx.x != 0) ? pairs[min(p - 1, g.n_pairs - 1)].fusion_idx : -1, my_group);
+    if (TIER == 0) {
+        const int tier = wgi.n_groups == 0 ? (int)TIER_GENERIC : tier_of(wgi.n_groups);
+        if (threadIdx.x == 0) {
+            wg_tier[blockIdx.x] = (uint8_t)tier;
+            if (tier != 0) atomicOr(&fb.ctr->need_tiers, 1u << tier);
+        }
+        if (tier != 0) return;                   // uniform
+    }
     // Exact pruning: a cell with V(i,j) < 4j - slack, slack = 2*Lq - minScore, can never
     // feed a row maximum that takes part in a split of score >= minScore (each further row adds at most
     // 4), and no live cell's value comes from a dead cell.  Once a whole tile row and everything that
     // can still enter from the left are dead, the rest of the tile is dead: the sweep stops there and
     // stores "V = 0" for the remaining rows (a lower bound, which is all dead cells need to be).
-    int lq_lane = 0, slack = 0;
-    if (live) {
-        wi = winfo[w];
-        const int64_t p = (int64_t)w * WAVE + lane;
-        f = pairs[min(p, g.n_pairs - 1)].fusion_idx;
-        if (p < g.n_pairs) {
-            lq_lane = pairs[p].read_len;
-            slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pairs[p]));
-        }
+    int lq_lane = 0, slack = 0, tiles_lane = 0;
+    if (in_batch) {
+        const dsa_fusion fu = fusions[f];
+        lq_lane = pr.read_len;
+        slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pr));
+        tiles_lane = max(cdiv_dev(fu.ref0_len, W), cdiv_dev(fu.ref1_len, W));
     }
     auto wave_max = [](int v) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
         return v;
     };
+    WaveInfo wi;
+    wi.lq_max = wave_max(lq_lane);
+    wi.nch_max = wave_max(tiles_lane);
     // rows up to which the boundary entering the next tile may still be alive (tile 0: column 0, V = 0)
     int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
     // Row codes are packed here, by the wave that uses them.  A read byte outside {A,C,G,T,N} hands the
@@ -1704,13 +1378,15 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     if (__builtin_amdgcn_ballot_w64(exotic) != 0 && lane == 0) atomicOr(&s_exotic, 1);
     __syncthreads();
     if (s_exotic != 0) {                         // uniform
-        if (threadIdx.x == 0) wg_generic[blockIdx.x] = 1u;
+        if (threadIdx.x == 0) {
+            wg_tier[blockIdx.x] = TIER_GENERIC;
+            atomicOr(&fb.ctr->need_tiers, 1u << TIER_GENERIC);
+        }
         return;
     }
     const int nch_wg = s_nch;
 
-    const int gsel = max(group_of(wgi, f), 0);
-    const uint32_t* tb = T + gsel * (SPLIT ? TGROUP_SPLIT : TGROUP);
+    const uint32_t* tb = T + my_group * (SPLIT ? TGROUP_SPLIT : TGROUP);
     const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
     int stop_prev = 0;                   // stored row groups of the tile to the left
     TileStops stops = {};
@@ -1920,7 +1596,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     STAT_T(t_comb);
     // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
     // workgroups' sweeps, instead of in kernels of its own.
-    combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, wgi.n_groups > 0, &fl, fb, g);
+    combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, my_group, true, &fl, fb, g);
     STAT_T(t_rep);
 #ifndef DSA_ABLATE_REPLAY
     replay_fast_wg<SPLIT>(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
@@ -2011,6 +1687,7 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 5) void k_replay(const ReplayTask* __
     static_assert(REPLAY_BLOCK == WG_LANES, "kept_row() strides the cache by WG_LANES");
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;
+    if (ctr->need_tiers & ~g.tiers_launched) return;      // some workgroups were not swept: the host runs the slice again with every fill kernel
     const int q = threadIdx.x & (RQ - 1);             // quarter of the tile
     const int slot = threadIdx.x / RQ;                // task slot of the block
     for (unsigned long long base = (unsigned long long)blockIdx.x * REPLAY_TASKS; base < n_g;
@@ -2160,16 +1837,21 @@ __global__ void k_reset_finish(Counters* ctr, int64_t* rec_count_end)
 {
     if (threadIdx.x == 0) {
         ctr->n_kept = ctr->n_tasks = ctr->n_masks = ctr->n_gtasks = 0;
+        ctr->need_tiers = 0;
         *rec_count_end = 0;
     }
 }
 
 // the cursors and the record total of a slice, stored into pinned host memory at the end of its phase 1
-__global__ void k_publish(const Counters* __restrict__ ctr, const int64_t* __restrict__ n_rec, Counters* host_ctr, int64_t* host_n_rec)
+struct PlanGlobals;
+__global__ void k_publish(const Counters* __restrict__ ctr, const int64_t* __restrict__ n_rec, const unsigned long long* __restrict__ plan,
+                          Counters* host_ctr, int64_t* host_n_rec, unsigned long long* host_plan)
 {
     if (threadIdx.x == 0) {
         *host_ctr = *ctr;
         *host_n_rec = *n_rec;
+        host_plan[0] = plan[0];          // PlanGlobals of the slice: cells, identity flag
+        host_plan[1] = plan[1];
         __threadfence_system();
     }
 }
@@ -2501,6 +2183,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void k_emit_counted(const dsa_pair* __r
 {
     __shared__ EmitLds<EMIT_SLOTS_COUNTED> lds;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || ctr->n_gtasks > gtask_cap) return;   // counts are void: the host reruns the slice
+    if (ctr->need_tiers & ~g.tiers_launched) return;      // pairs of workgroups that were not swept have no state yet
     const int64_t p = (int64_t)blockIdx.x * EMIT_BLOCK + threadIdx.x;
     PairState st = {};
     int64_t o = 0;                                   // records are counted and written in the caller's pair order
@@ -2529,6 +2212,7 @@ __global__ __launch_bounds__(EMIT_BLOCK) void k_emit_listed(const uint2* __restr
     __shared__ EmitLds<EMIT_SLOTS_LISTED> lds;
     const unsigned long long n_g = ctr->n_gtasks;
     if (ctr->n_tasks > task_cap || ctr->n_masks > mask_cap || ctr->n_kept > kept_cap || n_g > gtask_cap) return;   // the host reruns the slice
+    if (ctr->need_tiers & ~g.tiers_launched) return;
     // Consecutive list entries go to different blocks (entry = thread * blocks + block within a round of the grid): the
     // pairs with many kept rows come in runs, and a wave takes its heavy pairs one after the other.
     const unsigned long long stride = (unsigned long long)gridDim.x * EMIT_BLOCK;
@@ -2559,3 +2243,5 @@ __global__ __launch_bounds__(EMIT_BLOCK) void k_emit_listed(const uint2* __restr
 }
 
 }  // namespace dsa
+
+#include "dsa_plan.hpp"

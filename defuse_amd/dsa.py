@@ -20,7 +20,7 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
 EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
-           "dsa_upload", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
+           "dsa_upload", "dsa_plan", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
 
 DSA_E_CAPACITY = -1
 
@@ -32,7 +32,8 @@ class Limits(ctypes.Structure):
 class Timing(ctypes.Structure):
     _fields_ = [("pack_ms", ctypes.c_float), ("fill_ms", ctypes.c_float), ("finish_ms", ctypes.c_float),
                 ("total_ms", ctypes.c_float), ("fill_launches", ctypes.c_int32), ("n_generic_tasks", ctypes.c_int32),
-                ("cells", ctypes.c_int64), ("n_records", ctypes.c_int64), ("n_replay_tasks", ctypes.c_int64)]
+                ("cells", ctypes.c_int64), ("n_records", ctypes.c_int64), ("n_replay_tasks", ctypes.c_int64),
+                ("plan_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
 
 
 class DsaError(RuntimeError):
@@ -62,6 +63,7 @@ def load_library():
         batch = [vp, vp, i64, vp, i32, vp, i64, vp, i64]
         lib.dsa_align_batch.argtypes = batch + [vp, i64, ctypes.POINTER(i64)]
         lib.dsa_upload.argtypes = batch
+        lib.dsa_plan.argtypes = [vp]
         lib.dsa_run.argtypes = [vp, ctypes.POINTER(i64)]
         lib.dsa_download.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
         lib.dsa_copy_records_device.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
@@ -133,6 +135,12 @@ class Context:
         if rc != 0:
             self._err(rc)
 
+    def plan(self):
+        """dsa_plan: the sweep planning of the resident upload once more (bench.py times plan + run per step)."""
+        rc = self.lib.dsa_plan(self.h)
+        if rc != 0:
+            self._err(rc)
+
     def run(self):
         n = ctypes.c_int64(0)
         rc = self.lib.dsa_run(self.h, ctypes.byref(n))
@@ -165,6 +173,17 @@ class Context:
         t = Timing()
         self.lib.dsa_get_timing(self.h, ctypes.byref(t))
         return t
+
+    def align_batch_into(self, ref_bytes, fusions, read_bytes, pairs, out):
+        """dsa_align_batch on the caller's arrays as they are (no copies: pinned buffers stay pinned); the records go to
+        `out` (RECORD_DTYPE).  Returns the record count; raises DsaError(DSA_E_CAPACITY) if `out` is too small."""
+        n = ctypes.c_int64(0)
+        rc = self.lib.dsa_align_batch(self.h, ref_bytes.ctypes.data, ref_bytes.size, fusions.ctypes.data, len(fusions),
+                                      read_bytes.ctypes.data, read_bytes.size, pairs.ctypes.data, len(pairs),
+                                      out.ctypes.data, len(out), ctypes.byref(n))
+        if rc != 0:
+            self._err(rc)
+        return n.value
 
     def align_batch(self, ref_bytes, fusions, read_bytes, pairs):
         """dsa_align_batch: host arrays in, numpy record array out."""

@@ -93,6 +93,8 @@ typedef struct dsa_timing {
     int64_t cells;                /* DP cells filled: sum over pairs of 2*(Lref+1)*(Lread+1)     */
     int64_t n_records;
     int64_t n_replay_tasks;       /* tiles re-run to enumerate tied columns                      */
+    float   plan_ms;              /* the sweep planning that preceded this run (dsa_upload's or dsa_plan's) */
+    float   pad_;
 } dsa_timing;
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -136,6 +138,11 @@ int dsa_upload(dsa_ctx* ctx,
                const dsa_fusion* fusions, int32_t n_fusions,
                const uint8_t* read_bytes, int64_t read_bytes_len,
                const dsa_pair* pairs, int64_t n_pairs);
+/* Plans the sweep of the resident upload once more — everything dsa_upload does per candidate after its copies (sweep
+ * order of the fusions and of the pairs inside a fusion, per-pair score bounds).  A caller that times the path per
+ * batch calls dsa_plan + dsa_run per step, so that all work the reference does per candidate inside the loop of
+ * SplitReadRealigner::DoAlignment (tools/SplitAlignment.cpp:266-303) is inside its clock (bench.py does). */
+int dsa_plan(dsa_ctx* ctx);
 int dsa_run(dsa_ctx* ctx, int64_t* out_n);                       /* all kernels, records stay on device */
 int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n);
 /* Same as dsa_download, but `out_device` is device memory of the ctx's GPU (room for out_cap records): the

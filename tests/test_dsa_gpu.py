@@ -264,6 +264,43 @@ def test_slices_of_heavy_pairs_run_twice(built, ora):
     ctx.close()
 
 
+def test_plan_again_and_kernels_a_lane_did_not_expect(built, ora):
+    """dsa_plan on a resident upload (what bench.py times per step) changes nothing, and a context whose lanes last ran a
+    batch of large fusions only (so the next slice launches k_fill_fast<0> alone) runs a batch that needs the split-table
+    tiers and the generic kernel: the slice reports what it needed and is run again with every kernel."""
+    from defuse_amd import dsa
+    rng = np.random.default_rng(91)
+    big = cases.mixed_batch(51, n_fusions=6, reads_per_fusion=130, lq=60, lr=(200, 330))
+    bb = cases.BatchBuilder()
+    for k in range(70):                       # 20 / 9 / 3 reads per fusion: both split-table tiers and the generic kernel
+        ref0, ref1 = cases.rnd(rng, int(rng.integers(150, 400))), cases.rnd(rng, int(rng.integers(150, 400)))
+        f = bb.add_fusion(ref0, ref1)
+        for r in range(20 if k < 25 else 9 if k < 45 else 3):
+            read = cases.mutate(rng, cases.split_read(rng, ref0, ref1, int(rng.integers(40, 77))), 0.02)
+            bb.add_read(f, read.lower() if (k == 10 and r == 3) else read)
+    small = bb.arrays()
+    ctx = dsa.Context(0)
+    exp_big, exp_small = ora.align_batch(*big), ora.align_batch(*small)
+    ctx.upload(*big)
+    ctx.run()
+    assert ctx.download().tobytes() == exp_big.tobytes()
+    ctx.plan()
+    ctx.plan()
+    ctx.run()
+    assert ctx.download().tobytes() == exp_big.tobytes()
+    assert ctx.timing().plan_ms > 0
+    ctx.upload(*small)
+    ctx.run()
+    assert ctx.download().tobytes() == exp_small.tobytes()
+    ctx.plan()
+    ctx.run()
+    assert ctx.download().tobytes() == exp_small.tobytes()
+    ctx.upload(*big)
+    ctx.run()
+    assert ctx.download().tobytes() == exp_big.tobytes()
+    ctx.close()
+
+
 def test_full_size_properties(gpu_ctx, ora):
     """BASELINE config 2 at full size (10k fusions x 100 reads, 2x76): size-independent properties
     plus an oracle check on a random sample of fusions."""
