@@ -11,7 +11,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -165,6 +168,7 @@ struct dsa_ctx {
     bool plan_timed = false;         // ev_plan was recorded since the last run read it
     std::vector<Slice> slices;
     float last_plan_ms = 0.f;        // device time of the latest planning (upload's or dsa_plan's)
+    std::vector<int32_t> h_min_score;
 
     // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
     // slice overlaps the fill of the next (separate HIP streams)
@@ -279,7 +283,7 @@ int enqueue_plan(dsa_ctx* ctx)
     HIPC(ctx->d_orig.reserve((size_t)n_pairs));
     HIPC(ctx->d_pairs.reserve((size_t)n_pairs + 1));
     size_t sort_tmp = 0;
-    HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, ctx->plan_key.p, ctx->plan_key_sorted.p, ctx->plan_fidx.p, ctx->plan_order.p, nf, 0, 20, st));
+    HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, ctx->plan_key.p, ctx->plan_key_sorted.p, ctx->plan_fidx.p, ctx->plan_order.p, nf, 0, PLAN_KEY_BITS, st));
     HIPC(ctx->plan_sort_tmp.reserve(sort_tmp));
     const PlanParams prm = ctx->plan_prm;
     const size_t lds = plan_lds_bytes(prm.wc, prm.slots);
@@ -302,7 +306,7 @@ int enqueue_plan(dsa_ctx* ctx)
                                ctx->plan_runs.p, ctx->plan_key.p, ctx->plan_fidx.p, ctx->plan_rank.p, ctx->plan_bound.p, glob, pp);
             size_t tmp = ctx->plan_sort_tmp.cap;
             HIPC(hipcub::DeviceRadixSort::SortPairs(ctx->plan_sort_tmp.p, tmp, ctx->plan_key.p, ctx->plan_key_sorted.p, ctx->plan_fidx.p,
-                                                    ctx->plan_order.p, nf, 0, 20, st));
+                                                    ctx->plan_order.p, nf, 0, PLAN_KEY_BITS, st));
             hipLaunchKernelGGL(k_plan_place_a, dim3((unsigned)nb), dim3(PLACE_BLOCK), 0, st, ctx->plan_order.p, ctx->plan_runs.p, nf, ctx->plan_bsum.p);
             hipLaunchKernelGGL(k_plan_place_b, dim3((unsigned)nb), dim3(PLACE_BLOCK), 0, st, ctx->plan_order.p, ctx->plan_runs.p, nf, ctx->plan_bsum.p,
                                ctx->plan_start.p, ctx->plan_flip.p);
@@ -740,7 +744,12 @@ int dsa_synchronize(dsa_ctx* ctx)
     return DSA_OK;
 }
 
-int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions,
+}  // extern "C"
+
+namespace {
+
+// validation, buffers, copies (queued on st) and slice geometry of an upload; the planning is queued by the caller
+int upload_enqueue(dsa_ctx* ctx, hipStream_t st, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions,
                int32_t n_fusions, const uint8_t* read_bytes, int64_t read_bytes_len, const dsa_pair* pairs,
                int64_t n_pairs)
 {
@@ -782,18 +791,18 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
     ctx->n_fusions = n_fusions;
     ctx->ref_bytes_len = ref_bytes_len;
     ctx->read_bytes_len = read_bytes_len;
-    HIPC(ctx->d_ref.reserve((size_t)ref_bytes_len + 1));
+    HIPC(ctx->d_ref.reserve((size_t)ref_bytes_len + 64));        // (whole dwords, as for the reads)
     HIPC(ctx->d_reads.reserve((size_t)read_bytes_len + 64));      // the planning kernels read whole dwords up to 36 bytes past a read's end
     HIPC(ctx->d_fusions.reserve((size_t)n_fusions + 1));
     HIPC(ctx->d_pairs_in.reserve((size_t)n_pairs + 1));
     ctx->nch_all = nch_all;
     HIPC(ctx->d_refcodes.reserve((size_t)n_fusions * nch_all * W + 1));
-    hipStream_t st = ctx->stream;
     if (ref_bytes_len) HIPC(hipMemcpyAsync(ctx->d_ref.p, ref_bytes, ref_bytes_len, hipMemcpyHostToDevice, st));
     if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
     if (n_fusions) HIPC(hipMemcpyAsync(ctx->d_fusions.p, fusions, n_fusions * sizeof(dsa_fusion), hipMemcpyHostToDevice, st));
     if (n_pairs) HIPC(hipMemcpyAsync(ctx->d_pairs_in.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
-    std::vector<int32_t> tab(lqmax + 1);
+    std::vector<int32_t>& tab = ctx->h_min_score;       // lives as long as the copy may be in flight
+    tab.resize(lqmax + 1);
     for (int l = 0; l <= lqmax; ++l) tab[l] = min_score_for(l);
     HIPC(ctx->d_min_score.reserve(tab.size()));
     HIPC(hipMemcpyAsync(ctx->d_min_score.p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -809,8 +818,23 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
         ctx->plan_prm.tile_cols = W;
     }
     make_slices(ctx, n_pairs, lqmax);
+    HIPC(hipGetLastError());
+    return DSA_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions,
+               int32_t n_fusions, const uint8_t* read_bytes, int64_t read_bytes_len, const dsa_pair* pairs,
+               int64_t n_pairs)
+{
+    if (!ctx) return DSA_E_ARG;
+    if (int rc = upload_enqueue(ctx, ctx->stream, ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs)) return rc;
     if (int rc = enqueue_plan(ctx)) return rc;
-    HIPC(hipStreamSynchronize(st));             // the caller's buffers are free again when dsa_upload returns
+    HIPC(hipStreamSynchronize(ctx->stream));    // the caller's buffers are free again when dsa_upload returns
     HIPC(hipGetLastError());
     return DSA_OK;
 }
@@ -825,15 +849,29 @@ int dsa_plan(dsa_ctx* ctx)
     return enqueue_plan(ctx);
 }
 
-int dsa_run(dsa_ctx* ctx, int64_t* out_n)
+}  // extern "C"
+
+namespace {
+
+// Both lanes idle and without a slice: the state every dsa_run starts from and every failure leaves behind.  Lanes may be
+// shared by several contexts (dsa_share_scratch): a run that failed half way must not leave a slice "in flight" that the next
+// run — of this or of another context — would then finish with its own slice table.
+void reset_lanes(dsa_ctx* ctx)
 {
-    if (!ctx) return DSA_E_ARG;
-    HIPC(hipSetDevice(ctx->device));
-    ctx->n_records = 0;
-    ctx->timing = dsa_timing{};
+    for (PipeLane& L : ctx->lanes->lane) {
+        (void)hipStreamSynchronize(L.stream);
+        (void)hipStreamSynchronize(L.aux);
+        L.slice = -1;
+        L.emit_pending = false;
+        L.emit_early = false;
+    }
+    (void)hipGetLastError();
+}
+
+int run_slices(dsa_ctx* ctx)
+{
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
-    const auto t0 = std::chrono::steady_clock::now();
     if (ns > 0 && ctx->n_fusions > 0) {
         // reference bytes -> 16-bit codes for the whole upload, once per run, on lane 0's stream; lane 1 waits for it
         PipeLane& L0 = ctx->lanes->lane[0];
@@ -865,6 +903,37 @@ int dsa_run(dsa_ctx* ctx, int64_t* out_n)
         HIPC(hipStreamSynchronize(L.stream));
     }
     if (ns > 0 && ctx->n_fusions > 0) ctx->timing.pack_ms += elapsed(ctx->ev_pack[0], ns > 1 ? ctx->ev_pack[1] : ctx->lanes->lane[0].ev[1]);
+    return DSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsa_run(dsa_ctx* ctx, int64_t* out_n)
+{
+    if (!ctx) return DSA_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    ctx->n_records = 0;
+    ctx->have_results = false;
+    ctx->timing = dsa_timing{};
+    for (const PipeLane& L : ctx->lanes->lane)
+        if (L.slice >= 0 || L.emit_pending) {       // left behind by a run that did not end (another context's, on shared lanes)
+            reset_lanes(ctx);
+            break;
+        }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (const char* inj = getenv("DEFUSE_DSA_TEST_FAIL_RUN")) {   // tests: the N-th run of the process stops with its LAST slice in flight
+        static int countdown = atoi(inj);                         // and leaves the lanes as they are (no clean-up at all)
+        if (countdown > 0 && --countdown == 0 && !ctx->slices.empty()) {
+            (void)phase1(ctx, ctx->lanes->lane[0], (int)ctx->slices.size() - 1);
+            return fail(ctx, DSA_E_DEVICE, "injected failure (DEFUSE_DSA_TEST_FAIL_RUN)");
+        }
+    }
+    if (int rc = run_slices(ctx)) {
+        reset_lanes(ctx);                           // the error text of the failure stays in ctx->err
+        return rc;
+    }
     if (ctx->plan_timed) {                    // the planning that preceded this run, on the same stream
         ctx->last_plan_ms = elapsed(ctx->ev_plan[0], ctx->ev_plan[1]);
         ctx->plan_timed = false;
@@ -920,6 +989,224 @@ int dsa_align_batch(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_le
     int64_t n = 0;
     if (int rc = dsa_run(ctx, &n)) return rc;
     return dsa_download(ctx, out, out_cap, out_n);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming: batches submitted one after the other, up to `depth` in flight, collected in order.  Every batch lives in a
+// context of its own (input buffers, plan, records), all of which share one set of pipeline lanes; the copies in run on
+// one HIP stream (queued by the submitting thread), plan + run on the lanes (a worker thread, one batch after the other),
+// the copies out on a third stream — so H2D(k+1), plan / run(k) and D2H(k-1) overlap.
+// ---------------------------------------------------------------------------------------------------------------------
+struct dsa_stream {
+    int device = -1, depth = 0;
+    std::vector<dsa_ctx*> slot;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    struct Job {
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        dsa_record* out = nullptr;
+        int64_t out_cap = 0, n = 0;
+        int rc = 0;
+        bool copied = false;
+        std::string err;
+    };
+    std::vector<Job> job;
+    uint64_t n_submitted = 0, n_run = 0, n_collected = 0;
+    bool stop = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread worker;
+    std::string err;
+};
+
+namespace {
+
+void stream_worker(dsa_stream* s)
+{
+    (void)hipSetDevice(s->device);
+    for (;;) {
+        uint64_t k;
+        {
+            std::unique_lock<std::mutex> lk(s->m);
+            s->cv.wait(lk, [&] { return s->stop || s->n_run < s->n_submitted; });
+            if (s->n_run >= s->n_submitted) return;       // stop, nothing left
+            k = s->n_run;
+        }
+        dsa_ctx* ctx = s->slot[k % s->depth];
+        dsa_stream::Job& j = s->job[k % s->depth];
+        int64_t n = 0;
+        int rc = hipStreamWaitEvent(ctx->stream, j.ev_in, 0) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
+        if (rc == DSA_OK) rc = enqueue_plan(ctx);
+        if (rc == DSA_OK) rc = dsa_run(ctx, &n);
+        j.copied = false;
+        if (rc == DSA_OK && n <= j.out_cap) {
+            if (n && hipMemcpyAsync(j.out, ctx->d_records.p, (size_t)n * sizeof(dsa_record), hipMemcpyDeviceToHost, s->s_out) != hipSuccess) rc = DSA_E_DEVICE;
+            if (hipEventRecord(j.ev_out, s->s_out) != hipSuccess) rc = DSA_E_DEVICE;
+            j.copied = rc == DSA_OK;
+        }
+        j.n = n;
+        j.rc = rc;
+        j.err = rc ? ctx->err : std::string();
+        {
+            std::lock_guard<std::mutex> lk(s->m);
+            ++s->n_run;
+        }
+        s->cv.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsa_stream_create(dsa_stream** out, int device, int depth)
+{
+    if (!out || depth < 1 || depth > 8) return DSA_E_ARG;
+    *out = nullptr;
+    dsa_stream* s = new dsa_stream();
+    s->device = device;
+    s->depth = depth;
+    s->job.resize(depth);
+    bool ok = true;
+    for (int k = 0; k < depth && ok; ++k) {
+        dsa_ctx* c = nullptr;
+        ok = dsa_create(&c, device) == DSA_OK;
+        if (ok) {
+            s->slot.push_back(c);
+            if (k > 0) ok = dsa_share_scratch(c, s->slot[0]) == DSA_OK;
+        }
+    }
+    ok = ok && hipStreamCreateWithFlags(&s->s_in, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&s->s_out, hipStreamNonBlocking) == hipSuccess;
+    for (auto& j : s->job) {
+        ok = ok && hipEventCreateWithFlags(&j.ev_in, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&j.ev_out, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        dsa_stream_destroy(s);
+        return DSA_E_DEVICE;
+    }
+    s->worker = std::thread(stream_worker, s);
+    *out = s;
+    return DSA_OK;
+}
+
+void dsa_stream_destroy(dsa_stream* s)
+{
+    if (!s) return;
+    if (s->worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(s->m);
+            s->stop = true;
+        }
+        s->cv.notify_all();
+        s->worker.join();                       // finishes what was submitted
+    }
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    for (auto& j : s->job) {
+        if (j.ev_in) (void)hipEventDestroy(j.ev_in);
+        if (j.ev_out) (void)hipEventDestroy(j.ev_out);
+    }
+    if (s->s_in) (void)hipStreamDestroy(s->s_in);
+    if (s->s_out) (void)hipStreamDestroy(s->s_out);
+    for (size_t k = s->slot.size(); k-- > 0;) dsa_destroy(s->slot[k]);
+    delete s;
+}
+
+const char* dsa_stream_last_error(const dsa_stream* s) { return s ? s->err.c_str() : "no stream"; }
+
+int dsa_stream_submit(dsa_stream* s, const uint8_t* ref_bytes, int64_t ref_bytes_len, const dsa_fusion* fusions, int32_t n_fusions,
+                      const uint8_t* read_bytes, int64_t read_bytes_len, const dsa_pair* pairs, int64_t n_pairs, dsa_record* out,
+                      int64_t out_cap)
+{
+    if (!s || out_cap < 0 || (out_cap && !out)) return DSA_E_ARG;
+    uint64_t k;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->n_submitted - s->n_collected >= (uint64_t)s->depth) {
+            s->err = "dsa_stream_submit: all slots in flight, collect first";
+            return DSA_E_BUSY;
+        }
+        k = s->n_submitted;
+    }
+    dsa_ctx* ctx = s->slot[k % s->depth];
+    dsa_stream::Job& j = s->job[k % s->depth];
+    if (hipSetDevice(s->device) != hipSuccess) return DSA_E_DEVICE;
+    if (int rc = upload_enqueue(ctx, s->s_in, ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs)) {
+        s->err = ctx->err;
+        return rc;
+    }
+    if (hipEventRecord(j.ev_in, s->s_in) != hipSuccess) return DSA_E_DEVICE;
+    j.out = out;
+    j.out_cap = out_cap;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        ++s->n_submitted;
+    }
+    s->cv.notify_all();
+    return DSA_OK;
+}
+
+int dsa_stream_collect(dsa_stream* s, int64_t* out_n)
+{
+    if (!s) return DSA_E_ARG;
+    uint64_t k;
+    {
+        std::unique_lock<std::mutex> lk(s->m);
+        if (s->n_collected >= s->n_submitted) {
+            s->err = "dsa_stream_collect: nothing submitted";
+            return DSA_E_ARG;
+        }
+        k = s->n_collected;
+        s->cv.wait(lk, [&] { return s->n_run > k; });
+    }
+    dsa_stream::Job& j = s->job[k % s->depth];
+    if (out_n) *out_n = j.n;
+    int rc = j.rc;
+    if (rc == DSA_OK && !j.copied) {             // the records did not fit: the batch stays the oldest until dsa_stream_recollect took them
+        s->err = "dsa_stream_collect: out_cap too small";
+        return DSA_E_CAPACITY;
+    }
+    if (rc == DSA_OK && hipEventSynchronize(j.ev_out) != hipSuccess) rc = DSA_E_DEVICE;
+    if (rc != DSA_OK) s->err = j.err.empty() ? "device error" : j.err;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        ++s->n_collected;
+    }
+    return rc;
+}
+
+int dsa_stream_recollect(dsa_stream* s, dsa_record* out, int64_t out_cap, int64_t* out_n)
+{
+    if (!s) return DSA_E_ARG;
+    uint64_t k;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->n_collected >= s->n_submitted || s->n_run <= s->n_collected) return DSA_E_ARG;
+        k = s->n_collected;
+    }
+    dsa_ctx* ctx = s->slot[k % s->depth];
+    const int rc = dsa_download(ctx, out, out_cap, out_n);      // the worker is not touching this slot: its run is over
+    if (rc == DSA_E_CAPACITY) return rc;
+    if (rc != DSA_OK) s->err = ctx->err;
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        ++s->n_collected;
+    }
+    return rc;
+}
+
+void* dsa_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void dsa_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 }  // extern "C"

@@ -40,6 +40,15 @@ constexpr int PLAN_PAD = 160;          // invalid bases on either side of a pack
 constexpr int PLAN_TILES = 16;         // tile votes: tiles 0..14, 15 = that and beyond
 constexpr int PLAN_VOTE_BINS = 2048;   // histogram of d2 - d1 + 1024
 
+// sort key of a fusion, ascending = sweep order: size class, cost rank (expensive first), the tiles in which the alignments of
+// M1 / M2 end (255 = no vote)
+constexpr int PLAN_KEY_BITS = 14;
+constexpr uint32_t PLAN_KEY_NONE = (1u << PLAN_KEY_BITS) - 1u;
+__host__ __device__ constexpr uint32_t plan_fusion_key(int cls, int cost_rank, int t0, int t1)
+{
+    return ((uint32_t)cls << 12) | ((uint32_t)cost_rank << 10) | ((uint32_t)(t0 == 255 ? 31 : t0) << 5) | (uint32_t)(t1 == 255 ? 31 : t1);
+}
+
 struct PlanRun {
     int32_t first, last, nruns, count;   // pairs of the fusion in the slice (slice-relative); count is filled by k_plan_fusion
 };
@@ -171,10 +180,32 @@ __device__ __forceinline__ uint32_t plan_match32(const PlanChunk& ch, const uint
     return ~mm & ch.valid & wv;
 }
 
-// Shared memory of k_plan_fusion (dynamic): [codes 2 x wc][valid 2 x (wc/2 + 2)][tables 2 x slots][keys PLAN_MAX]
+// the 32 bases that begin at base `at` of a read whose chunks c[k] hold bases 32k .. 32k + 31 (at < 32 * PLAN_CHUNKS)
+__device__ __forceinline__ PlanChunk plan_chunk_at(const PlanChunk (&c)[PLAN_CHUNKS], int at)
+{
+    const int k = at >> 5;
+    const uint32_t sh = (uint32_t)(at & 31);
+    PlanChunk a = c[0], b = c[1 < PLAN_CHUNKS ? 1 : 0];
+#pragma unroll
+    for (int q = 1; q < PLAN_CHUNKS; ++q)
+        if (k == q) {
+            a = c[q];
+            b = q + 1 < PLAN_CHUNKS ? c[q + 1] : PlanChunk{0u, 0u, 0u};
+        }
+    if (sh == 0) return a;
+    const uint64_t ca = ((uint64_t)a.hi << 32) | a.lo, cb = ((uint64_t)b.hi << 32) | b.lo;
+    const uint64_t cc = (ca >> (2 * sh)) | (cb << (64 - 2 * sh));
+    PlanChunk r;
+    r.lo = (uint32_t)cc;
+    r.hi = (uint32_t)(cc >> 32);
+    r.valid = (a.valid >> sh) | (b.valid << (32 - sh));
+    return r;
+}
+
+// Shared memory of k_plan_fusion (dynamic): [codes 2 x wc][valid 2 x (wc/2 + 2)][tables 2 x slots][votes slots][keys 2 x PLAN_THREADS]
 __host__ __device__ inline size_t plan_lds_bytes(int wc, int slots)
 {
-    return sizeof(uint32_t) * ((size_t)2 * wc + 2 * (size_t)(wc / 2 + 2) + 2 * (size_t)slots + PLAN_MAX);
+    return sizeof(uint32_t) * ((size_t)2 * wc + 2 * (size_t)(wc / 2 + 2) + 3 * (size_t)slots + 2 * PLAN_THREADS);
 }
 
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
@@ -192,8 +223,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     uint32_t* valid1 = valid0 + vc;
     uint32_t* table0 = valid1 + vc;
     uint32_t* table1 = table0 + slots;
-    uint32_t* keys = table1 + slots;
-    int* s_votes = reinterpret_cast<int*>(keys);       // histogram of d2 - d1 (before the keys are written)
+    int* s_votes = reinterpret_cast<int*>(table1 + slots);     // histogram of d2 - d1 + slots / 2 (slots >= 2 x the longest window)
+    uint32_t* keys_small = table1 + 2 * slots;                  // sort keys of fusions of at most 2 x PLAN_THREADS pairs
+    uint32_t* keys_big = table0;                                // larger fusions: the keys take the tables' place once the lookups are done
     __shared__ int s_tile[2][PLAN_TILES];
     __shared__ unsigned s_best[PLAN_THREADS / 64];
     __shared__ int s_delta, s_delta_votes;
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         if (tid == 0) {
             if (run.nruns > 1) glob->identity = 1;
             runs[f].count = 0;
-            fkey[f] = 0xFFFFFu;                         // sorts behind every fusion with pairs
+            fkey[f] = PLAN_KEY_NONE;                    // sorts behind every fusion with pairs
         }
         return;
     }
@@ -217,7 +249,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     // size class of the fusion (the table tiers of the fill kernels: whole waves, split tables at 4 / 2 workgroups per CU, generic)
     const int cls = n >= WAVE ? 0 : n >= WG_LANES / GSPLIT ? 1 : n >= (WG_LANES + GSPLIT2 - 1) / GSPLIT2 ? 2 : 3;
     const bool windows_ok = len0 >= PLAN_K && len0 < PLAN_MAXWIN && len1 >= PLAN_K && len1 < PLAN_MAXWIN;
-    const bool full = n >= 2 && n <= PLAN_MAX && windows_ok && (prm.use_rank || prm.use_bound);
+    const bool full = n >= 2 && n <= PLAN_MAX && n <= 2 * slots && windows_ok && (prm.use_rank || prm.use_bound);
 
     if (tid == 0) s_cells = 0;
     if (tid < 2 * PLAN_TILES) (&s_tile[0][0])[tid] = 0;
@@ -234,14 +266,50 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         __syncthreads();
         if (tid == 0) {
             runs[f].count = n;
-            fkey[f] = ((uint32_t)cls << 18) | (0u << 16) | (255u << 8) | 255u;
+            fkey[f] = plan_fusion_key(cls, 0, 255, 255);
             atomicAdd(&glob->cells, s_cells * (unsigned long long)(len0 + 1 + len1 + 1));
         }
         return;
     }
 
+    // The bases of a read: chunks of 32 bases, 2-bit packed (reads of at most PLAN_LQ bases: all of them, in registers; longer
+    // reads get no bound and only their first and last 32 bases are looked at).
+    struct ReadBits {
+        PlanChunk c[PLAN_CHUNKS];
+        PlanChunk tail;
+        int lq, tail_base;
+    };
+    auto load_read = [&](const dsa_pair& pr) -> ReadBits {
+        ReadBits rb;
+        rb.lq = pr.read_len;
+        rb.tail_base = rb.lq > 32 ? rb.lq - 32 : 0;
+        const uint8_t* rd = read_bytes + pr.read_off;
+#pragma unroll
+        for (int c = 0; c < PLAN_CHUNKS; ++c) rb.c[c] = PlanChunk{0u, 0u, 0u};
+        rb.tail = PlanChunk{0u, 0u, 0u};
+        if (rb.lq < PLAN_K) return rb;
+        if (rb.lq <= PLAN_LQ) {
+#pragma unroll
+            for (int c = 0; c < PLAN_CHUNKS; ++c)
+                if (32 * c < rb.lq) rb.c[c] = plan_load_chunk(rd, 32 * c, rb.lq);
+            rb.tail = plan_chunk_at(rb.c, rb.tail_base);
+        } else {
+            rb.c[0] = plan_load_chunk(rd, 0, rb.lq);
+            rb.tail = plan_load_chunk(rd, rb.tail_base, rb.lq);
+        }
+        return rb;
+    };
+    // the first read of every thread is fetched while the windows are packed (the barrier below waits for it)
+    dsa_pair pr_first{};
+    ReadBits rb_first{};
+    if (tid < n) {
+        pr_first = pairs[p0 + tid];
+        rb_first = load_read(pr_first);
+    }
+
     // ---- the two windows, 2-bit packed with PLAN_PAD invalid bases on either side, and their 11-mers hashed
     for (int k = tid; k < 2 * slots; k += PLAN_THREADS) table0[k] = 0xFFFFFFFFu;
+    for (int k = tid; k < slots; k += PLAN_THREADS) s_votes[k] = 0;
     {
         unsigned short* v16_0 = reinterpret_cast<unsigned short*>(valid0);
         unsigned short* v16_1 = reinterpret_cast<unsigned short*>(valid1);
@@ -251,8 +319,21 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
             const uint8_t* src = ref_bytes + (h ? fu.ref1_off : fu.ref0_off);
             uint32_t code = 0, val = 0;
             const int x0 = 16 * wd - PLAN_PAD;
-            if (x0 + 16 > 0 && x0 < len) {
+            if (x0 >= 0 && x0 + 16 <= len) {                    // whole words: aligned dword loads
+                const uintptr_t a = reinterpret_cast<uintptr_t>(src + x0);
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(a & 3u);
+                uint32_t raw[5];
 #pragma unroll
+                for (int k = 0; k < 5; ++k) raw[k] = w[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t c8, v4;
+                    plan_pack4(__builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh), c8, v4);
+                    code |= c8 << (8 * k);
+                    val |= v4 << (4 * k);
+                }
+            } else if (x0 + 16 > 0 && x0 < len) {
                 for (int b = 0; b < 16; ++b) {
                     const int x = x0 + b;
                     if (x >= 0 && x < len) {
@@ -279,27 +360,26 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         ok = ((uint32_t)v & 0x7FFu) == 0x7FFu;
         return (uint32_t)c & 0x3FFFFFu;
     };
-    for (int x = tid; x + PLAN_K <= len0; x += PLAN_THREADS) {
-        bool ok;
-        const uint32_t km = window_kmer(codes0, valid0, x, ok);
-        if (ok) plan_table_insert(table0, slots, km, x);
+    {
+        const int n0 = len0 - PLAN_K + 1, n1 = len1 - PLAN_K + 1;       // 11-mer positions of the two windows, one after the other
+        for (int x = tid; x < n0 + n1; x += PLAN_THREADS) {
+            const bool second = x >= n0;
+            const int xx = second ? x - n0 : x;
+            bool ok;
+            const uint32_t km = window_kmer(second ? codes1 : codes0, second ? valid1 : valid0, xx, ok);
+            if (ok) plan_table_insert(second ? table1 : table0, slots, km, xx);
+        }
     }
-    for (int x = tid; x + PLAN_K <= len1; x += PLAN_THREADS) {
-        bool ok;
-        const uint32_t km = window_kmer(codes1, valid1, x, ok);
-        if (ok) plan_table_insert(table1, slots, km, x);
-    }
-    for (int k = tid; k < PLAN_VOTE_BINS; k += PLAN_THREADS) s_votes[k] = 0;
     __syncthreads();
 
     // ---- per read: the diagonals of its first 11-mers in window 0 (d1) and of its last ones in window 1 (d2)
     struct Diag { int d1, d2; bool have1, have2; };
-    auto diagonals = [&](const uint8_t* rd, int lq, const PlanChunk& head, const PlanChunk& tail, int tail_base) -> Diag {
+    auto diagonals = [&](const ReadBits& rb) -> Diag {
         Diag dg{0, 0, false, false};
-        (void)rd;
+        const int lq = rb.lq;
         for (int off = 0; off <= 12 && off + PLAN_K <= lq && !dg.have1; off += 4) {
             bool ok;
-            const uint32_t km = plan_kmer(head, off, ok);
+            const uint32_t km = plan_kmer(rb.c[0], off, ok);
             if (!ok) continue;
             const int x = plan_table_find(table0, slots, km);
             if (x >= 0) { dg.d1 = x - off; dg.have1 = true; }
@@ -307,7 +387,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         for (int off = 0; off <= 12 && off + PLAN_K <= lq && !dg.have2; off += 4) {
             const int at = lq - PLAN_K - off;
             bool ok;
-            const uint32_t km = plan_kmer(tail, at - tail_base, ok);
+            const uint32_t km = plan_kmer(rb.tail, at - rb.tail_base, ok);
             if (!ok) continue;
             const int y = plan_table_find(table1, slots, km);
             if (y >= 0) { dg.d2 = y - at; dg.have2 = true; }
@@ -315,25 +395,18 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         return dg;
     };
     // the reads that vote on d2 - d1 (the same for every read that spans the junction): the first PLAN_THREADS of the fusion
-    Diag mine{0, 0, false, false};
+    Diag dg_first{0, 0, false, false};
     if (tid < n) {
-        const dsa_pair pr = pairs[p0 + tid];
-        const int lq = pr.read_len;
-        if (lq >= PLAN_K) {
-            const uint8_t* rd = read_bytes + pr.read_off;
-            const int tb = lq > 32 ? lq - 32 : 0;
-            const PlanChunk head = plan_load_chunk(rd, 0, lq), tail = plan_load_chunk(rd, tb, lq);
-            mine = diagonals(rd, lq, head, tail, tb);
-            if (mine.have1 && mine.have2) {
-                const int v = mine.d2 - mine.d1 + 1024;
-                if (v >= 0 && v < PLAN_VOTE_BINS) atomicAdd(&s_votes[v], 1);
-            }
+        dg_first = diagonals(rb_first);
+        if (dg_first.have1 && dg_first.have2) {
+            const int v = dg_first.d2 - dg_first.d1 + slots / 2;
+            if (v >= 0 && v < slots) atomicAdd(&s_votes[v], 1);
         }
     }
     __syncthreads();
     {   // the mode of the votes; ties to the smaller difference (deterministic)
         unsigned best = 0;
-        for (int v = tid; v < PLAN_VOTE_BINS; v += PLAN_THREADS) {
+        for (int v = tid; v < slots; v += PLAN_THREADS) {
             const unsigned c = (unsigned)s_votes[v];
             if (c) best = max(best, (c << 12) | (unsigned)(4095 - v));
         }
@@ -344,7 +417,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
             unsigned b = 0;
             for (int w = 0; w < PLAN_THREADS / 64; ++w) b = max(b, s_best[w]);
             s_delta_votes = (int)(b >> 12);
-            s_delta = b ? (4095 - (int)(b & 4095u)) - 1024 : 0;
+            s_delta = b ? (4095 - (int)(b & 4095u)) - slots / 2 : 0;
         }
         __syncthreads();
     }
@@ -353,19 +426,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     // ---- per read: bound T', tile votes, sort key
     unsigned long long cells = 0;
     for (int k = tid; k < n; k += PLAN_THREADS) {
-        const dsa_pair pr = pairs[p0 + k];
+        const bool first = k == tid;
+        const dsa_pair pr = first ? pr_first : pairs[p0 + k];
+        const ReadBits rb = first ? rb_first : load_read(pr);
+        Diag dg = first ? dg_first : diagonals(rb);
         const int lq = pr.read_len;
         cells += (unsigned long long)(lq + 1);
-        const uint8_t* rd = read_bytes + pr.read_off;
-        Diag dg = mine;
-        if (k != tid) {
-            dg = Diag{0, 0, false, false};
-            if (lq >= PLAN_K) {
-                const int tb = lq > 32 ? lq - 32 : 0;
-                const PlanChunk head = plan_load_chunk(rd, 0, lq), tail = plan_load_chunk(rd, tb, lq);
-                dg = diagonals(rd, lq, head, tail, tb);
-            }
-        }
         // a read with one side only (its junction lies within a few bases of one end) takes the other diagonal from the
         // fusion's vote; any pair of diagonals gives a VALID bound below, a wrong guess only a weak one
         if (delta_votes > 0) {
@@ -377,7 +443,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         // read base j lies on window 0 position j + d1 (prefix side) and on window 1 position j + d2 (suffix side); the
         // ungapped paths along the two diagonals are valid DP paths (free start in the reference), so the best split scores
         // at least max_a P1(a) + P2(a) over the a where both sides reach the anchor minimum
-        if (prm.use_bound && dg.have1 && dg.have2 && dg.d1 >= 0 && lq - 1 + dg.d2 < len1 && lq > 0 && lq <= PLAN_LQ && dg.d2 > -PLAN_PAD) {
+        if (prm.use_bound && dg.have1 && dg.have2 && dg.d1 >= 0 && lq - 1 + dg.d2 < len1 && lq >= PLAN_K && lq <= PLAN_LQ && dg.d2 > -PLAN_PAD) {
             const int a_hi = min(lq, len0 - dg.d1);        // the prefix path stays inside window 0
             const int a_lo = max(0, -dg.d2);               // the suffix path stays inside window 1
             if (a_lo <= a_hi) {
@@ -387,33 +453,37 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
                 for (int c = 0; c < PLAN_CHUNKS; ++c) {
                     m1[c] = m2[c] = 0;
                     if (32 * c < lq) {
-                        const PlanChunk ch = plan_load_chunk(rd, 32 * c, lq);
-                        m1[c] = plan_match32(ch, codes0, valid0, 32 * c, dg.d1);
-                        m2[c] = plan_match32(ch, codes1, valid1, 32 * c, dg.d2);
+                        m1[c] = plan_match32(rb.c[c], codes0, valid0, 32 * c, dg.d1);
+                        m2[c] = plan_match32(rb.c[c], codes1, valid1, 32 * c, dg.d2);
                         // matches of the suffix side at read bases >= a_lo
                         const int lo = a_lo - 32 * c;
                         const uint32_t from = lo <= 0 ? 0xFFFFFFFFu : lo >= 32 ? 0u : ~((1u << lo) - 1u);
                         suf_matches += __builtin_popcount(m2[c] & from);
                     }
                 }
-                // P1(a) = 3 * (matches among read bases < a) - a,   P2(a) = 3 * (matches among bases >= a) - (lq - a)
-                int pre_matches = 0, best = 0, best_a = -1;
+                // P1(a) = 3 * (matches among read bases < a) - a,   P2(a) = 3 * (matches among bases >= a) - (lq - a); the best
+                // (score, smallest a) travels as one word: score << 8 | 255 - a
+                int pre = 0, suf = 3 * suf_matches - (lq - a_lo);
+                uint32_t best = 0;
 #pragma unroll
                 for (int c = 0; c < PLAN_CHUNKS; ++c) {
                     if (32 * c <= a_hi) {
                         const int b_end = min(32, a_hi - 32 * c + 1);
+                        uint32_t w1 = m1[c], w2 = m2[c];
                         for (int b = 0; b < b_end; ++b) {
                             const int a = 32 * c + b;
                             if (a >= a_lo) {
-                                const int pre = 3 * pre_matches - a, suf = 3 * suf_matches - (lq - a);
-                                if (pre >= DSA_MIN_SPLIT && suf >= DSA_MIN_SPLIT && pre + suf > best) { best = pre + suf; best_a = a; }
-                                suf_matches -= (int)((m2[c] >> b) & 1u);
+                                if (min(pre, suf) >= DSA_MIN_SPLIT) best = max(best, ((uint32_t)(pre + suf) << 8) | (uint32_t)(255 - a));
+                                suf -= 3 * (int)(w2 & 1u) - 1;
                             }
-                            pre_matches += (int)((m1[c] >> b) & 1u);
+                            pre += 3 * (int)(w1 & 1u) - 1;
+                            w1 >>= 1;
+                            w2 >>= 1;
                         }
                     }
                 }
-                tprime = min(best, 65535);
+                tprime = min((int)(best >> 8), 65535);
+                const int best_a = best ? 255 - (int)(best & 255u) : -1;
                 if (best_a > 0) {
                     // the tiles in which the two alignments end: matrix column d1 + a* of M1, and of M2 (reversed window 1)
                     // the column len1 - (a* + d2)
@@ -425,7 +495,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
             }
         }
         bound_out[p0 + k] = (uint16_t)tprime;
-        keys[k] = ((uint32_t)(prm.use_rank ? diag : 0) << 16) | (uint32_t)k;
+        const uint32_t key = ((uint32_t)(prm.use_rank ? diag : 0) << 16) | (uint32_t)k;
+        if (n <= 2 * PLAN_THREADS) keys_small[k] = key;
+        else rank[p0 + k] = (int32_t)key;                  // parked in the output array until the tables are free
     }
     atomicAdd(&s_cells, cells);
     __syncthreads();
@@ -433,27 +505,27 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     // ---- rank of every read inside the fusion: ascending (diagonal key, index) — the keys are distinct
     if (n <= 2 * PLAN_THREADS) {
         for (int k = tid; k < n; k += PLAN_THREADS) {
-            const uint32_t me = keys[k];
+            const uint32_t me = keys_small[k];
             int r = 0;
-            for (int i = 0; i < n; ++i) r += keys[i] < me ? 1 : 0;
+            for (int i = 0; i < n; ++i) r += keys_small[i] < me ? 1 : 0;
             rank[p0 + k] = r;
         }
     } else {
         int npad = 1;
-        while (npad < n) npad <<= 1;
-        for (int k = n + tid; k < npad; k += PLAN_THREADS) keys[k] = 0xFFFF0000u | (uint32_t)k;   // padding sorts behind everything
+        while (npad < n) npad <<= 1;                        // <= 2 * slots: the keys fit where the tables were
+        for (int k = tid; k < npad; k += PLAN_THREADS) keys_big[k] = k < n ? (uint32_t)rank[p0 + k] : (0xFFFF0000u | (uint32_t)k);
         __syncthreads();
         for (int size = 2; size <= npad; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 for (int t = tid; t < npad / 2; t += PLAN_THREADS) {
                     const int lo = (t / stride) * stride * 2 + (t % stride), hi = lo + stride;
                     const bool up = ((lo / size) & 1) == 0;
-                    const uint32_t a = keys[lo], b = keys[hi];
-                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                    const uint32_t a = keys_big[lo], b = keys_big[hi];
+                    if ((a > b) == up) { keys_big[lo] = b; keys_big[hi] = a; }
                 }
                 __syncthreads();
             }
-        for (int r = tid; r < n; r += PLAN_THREADS) rank[p0 + (keys[r] & 0xFFFFu)] = r;
+        for (int r = tid; r < n; r += PLAN_THREADS) rank[p0 + (keys_big[r] & 0xFFFFu)] = r;
     }
 
     if (tid == 0) {
@@ -472,7 +544,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
             alive = d == 0 ? 2 : d == 1 ? 3 : 4;
         }
         runs[f].count = n;
-        fkey[f] = ((uint32_t)cls << 18) | ((uint32_t)(prm.use_lpt ? 4 - alive : 0) << 16) | ((uint32_t)t[0] << 8) | (uint32_t)t[1];
+        fkey[f] = plan_fusion_key(cls, prm.use_lpt ? 4 - alive : 0, t[0], t[1]);
         atomicAdd(&glob->cells, s_cells * (unsigned long long)(len0 + 1 + len1 + 1));
     }
 }

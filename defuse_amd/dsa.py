@@ -20,9 +20,12 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
 EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
-           "dsa_upload", "dsa_plan", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize"]
+           "dsa_upload", "dsa_plan", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize",
+           "dsa_stream_create", "dsa_stream_destroy", "dsa_stream_submit", "dsa_stream_collect", "dsa_stream_recollect", "dsa_stream_last_error",
+           "dsa_host_alloc", "dsa_host_free"]
 
 DSA_E_CAPACITY = -1
+DSA_E_BUSY = -5
 
 
 class Limits(ctypes.Structure):
@@ -73,6 +76,18 @@ def load_library():
         lib.dsa_set_scratch_budget.argtypes = [vp, i64]
         lib.dsa_share_scratch.argtypes = [vp, vp]
         lib.dsa_pick_device_among.argtypes = [ctypes.c_int]
+        lib.dsa_stream_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
+        lib.dsa_stream_destroy.argtypes = [vp]
+        lib.dsa_stream_destroy.restype = None
+        lib.dsa_stream_submit.argtypes = [vp] + batch[1:] + [vp, i64]
+        lib.dsa_stream_collect.argtypes = [vp, ctypes.POINTER(i64)]
+        lib.dsa_stream_recollect.argtypes = [vp, vp, i64, ctypes.POINTER(i64)]
+        lib.dsa_stream_last_error.argtypes = [vp]
+        lib.dsa_stream_last_error.restype = ctypes.c_char_p
+        lib.dsa_host_alloc.argtypes = [ctypes.c_size_t]
+        lib.dsa_host_alloc.restype = vp
+        lib.dsa_host_free.argtypes = [vp]
+        lib.dsa_host_free.restype = None
         _lib = lib
     return _lib
 
@@ -91,6 +106,7 @@ class Context:
     def __init__(self, device=0):
         self.lib = load_library()
         self.h = ctypes.c_void_p()
+        self.device = int(device)
         rc = self.lib.dsa_create(ctypes.byref(self.h), int(device))
         if rc != 0:
             raise DsaError(rc, "dsa_create failed (no HIP device %d?)" % device)
@@ -201,3 +217,90 @@ class Context:
                 cap = int(n.value)
                 continue
             self._err(rc)
+
+
+class PinnedArray:
+    """A numpy array in pinned host memory (dsa_host_alloc): the buffers of a Stream copy asynchronously from / to it."""
+
+    def __init__(self, shape, dtype):
+        self.lib = load_library()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self.ptr = self.lib.dsa_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise MemoryError("dsa_host_alloc(%d) failed" % n)
+        buf = (ctypes.c_uint8 * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint8, count=n).view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.lib.dsa_host_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pinned_copy(a):
+    """A pinned copy of a numpy array (keep the returned PinnedArray alive while its .array is in use)."""
+    a = np.ascontiguousarray(a)
+    p = PinnedArray(a.shape, a.dtype)
+    p.array[...] = a
+    return p
+
+
+class Stream:
+    """dsa_stream: batches submitted one after the other, up to `depth` in flight, collected in order.  The arrays given to
+    submit() (inputs and `out`) are used as they are - no copies - and must stay alive and untouched until collect()."""
+
+    def __init__(self, device=0, depth=3):
+        self.lib = load_library()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.dsa_stream_create(ctypes.byref(self.h), int(device), int(depth))
+        if rc != 0:
+            raise DsaError(rc, "dsa_stream_create failed (no HIP device %d?)" % device)
+        self._inflight = []
+
+    def close(self):
+        if self.h:
+            self.lib.dsa_stream_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self, rc):
+        raise DsaError(rc, self.lib.dsa_stream_last_error(self.h).decode())
+
+    def submit(self, ref_bytes, fusions, read_bytes, pairs, out):
+        for a, dt in ((ref_bytes, np.uint8), (fusions, FUSION_DTYPE), (read_bytes, np.uint8), (pairs, PAIR_DTYPE), (out, RECORD_DTYPE)):
+            if a.dtype != dt or not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("Stream.submit takes contiguous arrays of the C-ABI dtypes (they are not copied)")
+        rc = self.lib.dsa_stream_submit(self.h, ref_bytes.ctypes.data, ref_bytes.size, fusions.ctypes.data, len(fusions),
+                                        read_bytes.ctypes.data, read_bytes.size, pairs.ctypes.data, len(pairs), out.ctypes.data, len(out))
+        if rc != 0:
+            self._err(rc)
+        self._inflight.append((ref_bytes, fusions, read_bytes, pairs, out))
+
+    def collect(self):
+        """Records of the oldest batch: a view of the `out` array of its submit (a fresh array if they did not fit)."""
+        n = ctypes.c_int64(0)
+        rc = self.lib.dsa_stream_collect(self.h, ctypes.byref(n))
+        if rc == DSA_E_CAPACITY:
+            big = np.zeros(n.value, dtype=RECORD_DTYPE)
+            rc = self.lib.dsa_stream_recollect(self.h, big.ctypes.data, len(big), ctypes.byref(n))
+            if rc != 0:
+                self._err(rc)
+            self._inflight.pop(0)
+            return big
+        if rc != 0:
+            self._err(rc)
+        out = self._inflight.pop(0)[4]
+        return out[:n.value]

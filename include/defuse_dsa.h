@@ -35,6 +35,7 @@ extern "C" {
 #define DSA_E_DEVICE    (-2)   /* HIP error (no device, launch failure, out of memory)          */
 #define DSA_E_ARG       (-3)   /* inconsistent arguments (offsets out of range, negative sizes) */
 #define DSA_E_LIMIT     (-4)   /* a length exceeds what the kernels support (see dsa_limits)    */
+#define DSA_E_BUSY      (-5)   /* dsa_stream_submit: every slot is in flight, collect first     */
 
 /* Scoring is fixed by the reference (tools/SplitAlignment.cpp:25-29, :234):
  * match +2, mismatch -1, gap -2, minSplitScore = minAnchor*match = 8, endGaps=false. */
@@ -153,6 +154,32 @@ int dsa_get_timing(const dsa_ctx* ctx, dsa_timing* out);
  * hipStream_t as an opaque pointer, NULL restores the private stream. */
 int dsa_set_stream(dsa_ctx* ctx, void* hip_stream);
 int dsa_synchronize(dsa_ctx* ctx);
+
+/* ---- streaming: what a tool that aligns one batch after the other calls -------------------------------------- */
+/* SplitReadRealigner::DoAlignment (tools/SplitAlignment.cpp:266-303) walks its candidates once; a binding that cuts them
+ * into batches keeps up to `depth` of them in flight: while batch k is planned and aligned, the host buffers of batch k+1
+ * are copied in and the records of batch k-1 are copied out (three HIP streams, one worker thread).  Batches are collected
+ * in the order of their submission.  The host buffers given to dsa_stream_submit (inputs AND `out`) must stay valid and
+ * untouched until the matching dsa_stream_collect returned; buffers from dsa_host_alloc (pinned) make the copies
+ * asynchronous, any other host memory works but is staged by the runtime. */
+typedef struct dsa_stream dsa_stream;
+int  dsa_stream_create(dsa_stream** out, int device, int depth);          /* depth 1..8 batches in flight */
+void dsa_stream_destroy(dsa_stream* s);                                   /* finishes what was submitted  */
+int  dsa_stream_submit(dsa_stream* s,
+                       const uint8_t* ref_bytes, int64_t ref_bytes_len,
+                       const dsa_fusion* fusions, int32_t n_fusions,
+                       const uint8_t* read_bytes, int64_t read_bytes_len,
+                       const dsa_pair* pairs, int64_t n_pairs,
+                       dsa_record* out, int64_t out_cap);                 /* DSA_E_BUSY: depth batches in flight */
+/* Blocks until the oldest batch is done and its records are in the `out` of its submit; *out_n = their number.
+ * DSA_E_CAPACITY: they did not fit (*out_n = the number) — the batch stays the oldest until dsa_stream_recollect copied
+ * them into a larger buffer. */
+int  dsa_stream_collect(dsa_stream* s, int64_t* out_n);
+int  dsa_stream_recollect(dsa_stream* s, dsa_record* out, int64_t out_cap, int64_t* out_n);
+const char* dsa_stream_last_error(const dsa_stream* s);
+/* pinned host memory for the buffers of a stream (NULL when it cannot be had) */
+void* dsa_host_alloc(size_t bytes);
+void  dsa_host_free(void* p);
 
 #ifdef __cplusplus
 }

@@ -301,6 +301,95 @@ def test_plan_again_and_kernels_a_lane_did_not_expect(built, ora):
     ctx.close()
 
 
+def test_run_after_a_failed_run_on_shared_lanes(built, ora):
+    """A run that stops half way leaves a slice in flight on its pipeline lane.  The lanes may be shared with other contexts
+    (dsa_share_scratch): the next run, here of a context with FEWER slices than the stale slice index, starts from clean
+    lanes and gives the right records, and so does a retry of the run that failed.  (Runs in a child process: the failure
+    is injected by an environment switch that counts the runs of the process.)"""
+    import subprocess
+    import sys
+    code = '''
+import os, sys
+sys.path.insert(0, %r)
+from defuse_amd import dsa
+from oracle import dosplitalign_oracle as ora
+from tests import cases
+os.environ["DEFUSE_DSA_SCRATCH_MB"] = "1"
+big = cases.mixed_batch(21, n_fusions=10, reads_per_fusion=150, lq=40, lr=(80, 200))      # several slices at 1 MB
+small = cases.mixed_batch(22, n_fusions=2, reads_per_fusion=20, lq=40, lr=(80, 120))      # one slice
+a, b = dsa.Context(0), dsa.Context(0)
+b.share_scratch(a)
+a.upload(*big)
+b.upload(*small)
+a.run()
+assert a.timing().fill_launches > 2
+try:
+    a.run()                      # the second run of the process: injected failure, last slice left in flight
+    raise SystemExit("the injected failure did not happen")
+except dsa.DsaError as e:
+    assert "injected" in str(e), e
+b.run()
+assert b.download().tobytes() == ora.align_batch(*small).tobytes()
+a.run()
+assert a.download().tobytes() == ora.align_batch(*big).tobytes()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, DEFUSE_DSA_TEST_FAIL_RUN="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr)
+
+
+def test_stream_of_batches_equals_the_oracle(built, ora):
+    """The streaming entry points (what a tool that cuts its candidates into batches calls): seven different batches through
+    a stream of depth 3 - pinned and ordinary host buffers, one batch whose records do not fit its buffer (collected
+    again into a larger one), a submit beyond the depth (refused), an empty batch - every batch equals the oracle."""
+    from defuse_amd import dsa
+    batches = [cases.mixed_batch(60 + k, n_fusions=4 + 3 * k, reads_per_fusion=20 + 25 * (k % 3), lq=40 + 9 * k, lr=(90 + 30 * k, 160 + 40 * k))
+               for k in range(6)]
+    batches.insert(3, cases.repeat_batch(13, n_fusions=3))            # many records per pair
+    exp = [ora.align_batch(*b) for b in batches]
+    st = dsa.Stream(0, depth=3)
+    keep, outs = [], []
+    for k, b in enumerate(batches):
+        if k % 2 == 0:                                                # pinned inputs and output
+            pins = [dsa.pinned_copy(a) for a in b]
+            keep.append(pins)
+            arrs = [p.array for p in pins]
+        else:
+            arrs = list(dsa._check_arrays(*b))
+        cap = 16 if k == 3 else len(exp[k]) + 5                       # batch 3: far too small
+        if k % 2 == 0:
+            po = dsa.PinnedArray((cap,), dsa.RECORD_DTYPE)
+            keep.append(po)
+            out = po.array
+        else:
+            out = np.zeros(cap, dtype=dsa.RECORD_DTYPE)
+        outs.append((arrs, out))
+    got = []
+    submitted = 0
+    for k in range(len(batches)):
+        while submitted < len(batches) and submitted - k < 3:
+            st.submit(*outs[submitted][0], outs[submitted][1])
+            submitted += 1
+        if k == 0:
+            with pytest.raises(dsa.DsaError) as e:                    # depth batches in flight
+                st.submit(*outs[0][0], outs[0][1])
+            assert e.value.code == dsa.DSA_E_BUSY
+        got.append(st.collect().copy())
+    for k in range(len(batches)):
+        assert got[k].tobytes() == exp[k].tobytes(), k
+    assert len(exp[3]) > 16
+    # an empty batch, and the stream is reusable after everything was collected
+    empty = [np.zeros(0, np.uint8), np.zeros(0, dsa.FUSION_DTYPE), np.zeros(0, np.uint8), np.zeros(0, dsa.PAIR_DTYPE)]
+    st.submit(*empty, np.zeros(4, dsa.RECORD_DTYPE))
+    st.submit(*outs[1][0], outs[1][1])
+    assert len(st.collect()) == 0
+    assert st.collect().tobytes() == exp[1].tobytes()
+    with pytest.raises(dsa.DsaError):
+        st.collect()                                                  # nothing submitted
+    st.close()
+
+
 def test_full_size_properties(gpu_ctx, ora):
     """BASELINE config 2 at full size (10k fusions x 100 reads, 2x76): size-independent properties
     plus an oracle check on a random sample of fusions."""
