@@ -223,7 +223,7 @@ class Share:
             ctx.close()
 
 
-def gather_job(share, rank, world, backend, barrier):
+def gather_job(share, rank, world, backend, barrier, dump=None):
     """The final gather of the job's records on rank 0 (defuse_amd/shard.py:gather_records), once, after the timed steps:
     every upload's records are copied device -> device into one tensor per rank (pair numbers made job-wide), then one
     all_gather of the counts and one group of exact-size isend/irecv.  Any failure propagates (non-zero exit)."""
@@ -260,6 +260,9 @@ def gather_job(share, rank, world, backend, barrier):
                 raise RuntimeError("gather: records of rank %d carry pair numbers outside its share" % r)
         lo += c
     nbytes = (total - counts[0]) * shard.RECORD_WORDS * 4
+    if dump:
+        import numpy as np
+        np.save(dump, out.cpu().numpy())
     return {"ms": ms, "records": total, "bytes_moved": nbytes, "GB/s": nbytes / (ms * 1e-3) / 1e9, "verified": True,
             "backend": "rccl" if backend == "nccl" else backend, "included_in_value": False, "times_per_job": 1,
             "pattern": "all_gather of counts + grouped isend/irecv, exact sizes, peers -> rank 0"}
@@ -277,11 +280,22 @@ def spawn_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+    # a rank that fails takes the job down: the others are given a few seconds to notice (a collective that lost its peer
+    # raises) and are then ended, so that a lost rank is a non-zero exit and never a hang
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:
+                rc = p.returncode
+                deadline = time.monotonic() + 20.0
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
     for p in procs:
-        p.wait()
         rc = rc or p.returncode
-    sys.exit(rc)
+    sys.exit(rc if rc else 0)
 
 
 def main():
@@ -295,6 +309,7 @@ def main():
     ap.add_argument("--lq", type=int, default=None)
     ap.add_argument("--lr", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-records", default=None, help="N > 1: rank 0 writes the gathered records of the job (numpy .npy) here")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 passes: exactly --steps timed steps and nothing else (no minimum duration, no resident re-run, "
                          "no one-shot leg, no CPU baseline)")
@@ -401,7 +416,9 @@ def main():
     alone = None
     if world > 1:
         if os.environ.get("DEFUSE_BENCH_GATHER", "1") != "0":
-            gather = gather_job(share, rank, world, backend, barrier)       # raises on failure: the run fails
+            if os.environ.get("DEFUSE_BENCH_TEST_EXIT_RANK") == str(rank):  # tests: a rank that dies before the exchange
+                os._exit(3)
+            gather = gather_job(share, rank, world, backend, barrier, args.dump_records)       # raises on failure: the run fails
         # rank 0 alone on its share, the other ranks idle at the barrier
         if rank == 0:
             k = max(3, steps // 4)

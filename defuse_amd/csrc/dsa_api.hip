@@ -622,19 +622,35 @@ int dsa_device_count(void)
 int dsa_pick_device_among(int n)
 {
     if (n <= 1) return 0;
+    // The claim is one per process: a lock taken with flock belongs to its open file description, so a second call with a
+    // fresh descriptor would find the process's own lock taken, move on to the next device and hold two.  The first
+    // decision for a given n is remembered.
+    static std::mutex pick_mutex;
+    static int picked_n = -1, picked = 0;
+    std::lock_guard<std::mutex> lk(pick_mutex);
+    if (picked_n == n) return picked;
     const int start = (int)((unsigned long)getpid() % (unsigned long)n);
     const char* dir = getenv("DEFUSE_GPU_LOCK_DIR");
     if (!dir) dir = "/tmp";
+    int found = start;
+    static int held_fd = -1;                   // a claim for another n is given up first
+    if (held_fd >= 0) { close(held_fd); held_fd = -1; }
     for (int k = 0; k < n; ++k) {
         const int d = (start + k) % n;
         char path[512];
         snprintf(path, sizeof path, "%s/defuse_gpu.%d.lock", dir, d);
         const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
         if (fd < 0) continue;
-        if (flock(fd, LOCK_EX | LOCK_NB) == 0) return d;        // fd stays open on purpose: it is the claim
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) {        // fd stays open on purpose: it is the claim
+            held_fd = fd;
+            found = d;
+            break;
+        }
         close(fd);
     }
-    return start;
+    picked_n = n;
+    picked = found;
+    return found;
 }
 
 int dsa_pick_device(void)

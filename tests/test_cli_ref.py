@@ -13,6 +13,13 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "tclap_ref")
 
 # (flag, name, description, value type[:label shown in the usage text], required) in the order the reference defines them
 SPECS = {
+    "dosplitalign": ("Fusion sequence prediction by split reads", [                     # tools/dosplitalign.cpp:43-56
+        ("f", "fasta", "Reference Fasta", "string", 1), ("e", "exons", "Exon Regions Filename", "string", 1),
+        ("u", "ufrag", "Fragment Length Mean", "float", 1), ("s", "sfrag", "Fragment Length Standard Deviation", "float", 1),
+        ("n", "minread", "Minimum Read Length", "int:integer", 1), ("x", "maxread", "Maximum Read Length", "int:integer", 1),
+        ("r", "regions", "Fusion Regions Filename", "string", 1), ("i", "improper", "Improper Alignments Sam Filename", "string", 1),
+        ("1", "seq1", "End 1 Sequences", "string", 1), ("2", "seq2", "End 2 Sequences", "string", 1),
+        ("a", "align", "Split Alignments Filename", "string", 1)]),
     "clustermatepairs": ("Mate Pair Clustering Tool", [                                  # tools/clustermatepairs.cpp:400-406
         ("a", "align", "Alignments Filename", "string", 1), ("c", "clusters", "Output Clusters Filename", "string", 1),
         ("u", "fragmentmean", "Fragment Length Mean", "float:integer", 1),
@@ -85,19 +92,17 @@ def test_parser_output_equals_tclap(driver, tool):
         assert (got.returncode, got.stdout, got.stderr) == (ref.returncode, ref.stdout, ref.stderr), (tool, args)
 
 
-def test_dosplitalign_parser_against_tclap_on_its_required_arguments(driver):
-    """dosplitalign carries five optional arguments of its own (the fused mode), so its usage text is longer than the
-    reference's; the error paths are compared on the messages, which name single arguments."""
+def test_dosplitalign_fused_options_exist_only_on_request(driver):
+    """The five options of the fused mode are not part of the command line unless DEFUSE_FUSED=1: without it `--clusters` is an
+    unknown argument exactly as it is for the reference's parser, with it the help text lists them."""
     binary = os.path.join(ROOT, "bin", "dosplitalign")
-    spec = [("f", "fasta"), ("e", "exons"), ("u", "ufrag"), ("s", "sfrag"), ("n", "minread"), ("x", "maxread"), ("r", "regions"),
-            ("i", "improper"), ("1", "seq1"), ("2", "seq2"), ("a", "align")]                  # tools/dosplitalign.cpp:44-56
-    got = subprocess.run([binary, "--help"], capture_output=True, text=True)
-    for flag, name in spec:
-        assert ("-%s <" % flag) in got.stdout and ("--%s <" % name) in got.stdout
-    got = subprocess.run([binary, "-f", "x"], capture_output=True, text=True)
-    assert got.returncode == 1 and got.stderr.startswith("PARSE ERROR:  \n             One or more required arguments missing!\n\nBrief USAGE: \n")
-    got = subprocess.run([binary, "-n", "fifty"], capture_output=True, text=True)
-    assert got.returncode == 1 and "PARSE ERROR: Argument: -n (--minread)\n             Couldn't read argument value from string 'fifty'\n" in got.stderr
+    env = {k: v for k, v in os.environ.items() if k != "DEFUSE_FUSED"}
+    for args in (["--clusters", "x"], ["--sorted"], ["-q", "x"]):
+        ref = reference(driver, "dosplitalign", args)
+        got = subprocess.run([binary] + args, capture_output=True, text=True, env=env)
+        assert (got.returncode, got.stdout, got.stderr) == (ref.returncode, ref.stdout, ref.stderr), args
+    got = subprocess.run([binary, "--help"], capture_output=True, text=True, env=dict(env, DEFUSE_FUSED="1"))
+    assert got.returncode == 0 and "--clusters <string>" in got.stdout and "--sorted" in got.stdout
 
 
 def test_parsed_values_equal_tclap(driver):

@@ -46,6 +46,7 @@ def test_pipeline_recovers_planted_breakpoint(built, tmp_path):
     (tmp_path / "spanning.txt").write_text("".join(lines))
 
     def run(tool, *args, **kw):
+        kw.setdefault("env", dict(os.environ, DEFUSE_FUSED="1"))          # (the fused-mode options of dosplitalign exist only on request)
         r = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, **kw)
         assert r.returncode == 0, (tool, r.stderr)
         return r
@@ -113,6 +114,7 @@ def test_config5_shaped_chain_every_intermediate_file(built, tmp_path):
     d = str(tmp_path) + "/"
 
     def run(tool, *args, **kw):
+        kw.setdefault("env", dict(os.environ, DEFUSE_FUSED="1"))          # (the fused-mode options of dosplitalign exist only on request)
         r = subprocess.run([os.path.join(BIN, tool)] + list(args), capture_output=True, text=True, **kw)
         assert r.returncode == 0, (tool, r.stderr)
         return r

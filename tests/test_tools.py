@@ -240,3 +240,66 @@ def test_device_pick_spreads_concurrent_processes(tools, tmp_path):
     assert int(again.stdout) in (0, 1, 2, 3)
     lib = ctypes.CDLL(dsa.LIB_PATH)
     assert lib.dsa_pick_device_among(1) == 0 and lib.dsa_pick_device_among(0) == 0
+    # a process that asks twice keeps its device (its own lock must not push it on to the next one) and holds ONE lock
+    twice = ("import ctypes, os, sys\n"
+             "lib = ctypes.CDLL(sys.argv[1])\n"
+             "a, b, c = lib.dsa_pick_device_among(4), lib.dsa_pick_device_among(4), lib.dsa_pick_device_among(4)\n"
+             "locks = [os.readlink('/proc/self/fd/' + f) for f in os.listdir('/proc/self/fd') if os.path.exists('/proc/self/fd/' + f)]\n"
+             "print(a, b, c, sum('defuse_gpu.' in l for l in locks))\n")
+    r = subprocess.run([sys.executable, "-c", twice, dsa.LIB_PATH], capture_output=True, text=True, env=env)
+    a, b, c, n_locks = (int(x) for x in r.stdout.split())
+    assert a == b == c and n_locks == 1, r.stdout
+
+
+def test_no_candidates_never_loads_the_library(tools, tmp_path):
+    """A run without a single candidate does not even load the C-ABI library (let alone start a HIP runtime): with
+    DEFUSE_DSA_LIB pointing nowhere it still succeeds; with a candidate the same setting is a clean error exit (status 1,
+    message on stderr) however far the other threads are."""
+    args = smoke_args(tmp_path, str(tmp_path / "out.align"))
+    with open(tmp_path / "far.txt", "w") as f:
+        f.write("7\t0\tchrA\t+\t2500\t2600\n7\t1\tchrA\t-\t200\t300\n")
+    far = list(args)
+    far[far.index("-r") + 1] = str(tmp_path / "far.txt")
+    env = dict(os.environ, DEFUSE_DSA_LIB=str(tmp_path / "no_such_library.so"))
+    r = subprocess.run([TOOL] + far, capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and os.path.getsize(tmp_path / "out.align") == 0, r.stderr
+    for _ in range(5):                                   # timing-dependent before: the helper thread used to be mid-dlopen
+        r = subprocess.run([TOOL] + args, capture_output=True, text=True, env=env)
+        assert r.returncode == 1 and "cannot load the split alignment library" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_read_store_follows_the_number_of_reads_not_the_largest_id(tools, tmp_path):
+    """deFuse's fragment indices are global to the run: a chunk whose ids sit around 10^8 must not make the read table 10^8
+    slots long.  Also: later reads replace earlier ones, lookups of absent ids fail, sparse and far ids still resolve."""
+    src = tmp_path / "rs.cpp"
+    src.write_text('''
+#include "%s/tools_src/defuse_host.hpp"
+#include <cassert>
+using namespace defuse;
+int main() {
+    ReadStore rs;
+    const int base = 123456789;
+    for (int k = 0; k < 50000; ++k) { std::string s = "ACGT" + std::to_string(k); rs.put(base + k, k & 1, s.data(), s.size()); }
+    rs.put(base + 7, 1, "TTTT", 4);                       // replaces
+    rs.put(5, 0, "GG", 2);                                // far below the chunk: hash map
+    rs.put(base + 40000000, 1, "CC", 2);                  // far above: hash map
+    rs.put(base + 40000000, 1, "CCC", 3);                 // replaces there too
+    const char* s; size_t n;
+    assert(rs.get(base + 7, 1, s, n) && std::string(s, n) == "TTTT");
+    assert(rs.get(base + 8, 0, s, n) && std::string(s, n) == "ACGT8");
+    assert(!rs.get(base + 8, 1, s, n));
+    assert(rs.get(5, 0, s, n) && std::string(s, n) == "GG");
+    assert(rs.get(base + 40000000, 1, s, n) && std::string(s, n) == "CCC");
+    assert(!rs.get(base - 5000, 0, s, n) && !rs.get(base + 49999 + 3, 0, s, n));
+    assert(rs.table_slots() <= 8 * 50010 + 4096);
+    // ids spread thinly (every 1000th): the table stays small and everything resolves
+    ReadStore thin;
+    for (int k = 0; k < 2000; ++k) thin.put(1000 * k, 0, "A", 1);
+    for (int k = 0; k < 2000; ++k) assert(thin.get(1000 * k, 0, s, n) && n == 1);
+    assert(!thin.get(1500, 0, s, n) && thin.table_slots() <= 8 * 2001 + 4096);
+    return 0;
+}
+''' % ROOT)
+    exe = tmp_path / "rs"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", str(exe), str(src)])
+    assert subprocess.run([str(exe)]).returncode == 0

@@ -38,9 +38,17 @@ enum Strand { PlusStrand = 0, MinusStrand = 1 };   // tools/Common.h:20-24
 struct Region { int start = 0, end = 0; };
 struct Location { std::string refName; int strand = 0, start = 0, end = 0; };
 
+// A tool with helper threads that may sit inside a library (dlopen, a runtime coming up) installs a hook that ends the
+// process in an orderly way — std::exit from an arbitrary thread would run exit handlers and library finalisers beside them.
+inline std::function<void()>& die_hook()
+{
+    static std::function<void()> hook;
+    return hook;
+}
 [[noreturn]] inline void die(const std::string& msg)
 {
     std::cerr << msg << std::endl;
+    if (die_hook()) die_hook()();
     std::exit(1);
 }
 
@@ -1007,31 +1015,37 @@ private:
 };
 
 // The reads of both FASTQ files by ReadID (fragment index, read end): sequences in one byte pool, found through a table
-// indexed by 2*fragment + end (fragment indices are the running numbers scripts/index_paired_fastq.pl gives the reads;
-// an index beyond 2^28 goes to a hash map instead).  A later read of the same id replaces the earlier one, as
-// `reads[id] = sequence` does in the reference (tools/SplitAlignment.cpp:253-264).
+// indexed by 2 * (fragment - first fragment seen) + end.  Fragment indices are the running numbers
+// scripts/index_paired_fastq.pl gives the reads of the WHOLE run, and a tool process sees one chunk of them: the table is
+// relative to the chunk's first index and only grows while it stays dense (at most eight slots per read stored, so its size
+// follows the number of reads, not the largest id); anything else goes to a hash map.  A later read of the same id replaces
+// the earlier one, as `reads[id] = sequence` does in the reference (tools/SplitAlignment.cpp:253-264).
 class ReadStore {
 public:
     void put(int frag, int end, const char* s, size_t n)
     {
         const uint64_t v = ((uint64_t)pool_.size() << 24) | (uint64_t)n;
         pool_.insert(pool_.end(), s, s + n);
-        if (frag >= 0 && frag < (1 << 28)) {
-            const size_t k = (size_t)frag * 2 + (size_t)end;
-            if (k >= dense_.size()) dense_.resize(std::max(k + 1, dense_.size() * 2), NONE);
-            dense_[k] = v;
-        } else {
-            sparse_[pack_id(frag, end)] = v;
+        if (count_++ == 0) base_ = (int64_t)frag - ((int64_t)frag & 1023);        // some room below the first id
+        const int64_t rel = (int64_t)frag - base_;
+        if (rel >= 0 && rel < ((int64_t)1 << 28)) {
+            const size_t k = (size_t)rel * 2 + (size_t)end;
+            if (k < dense_.size()) { dense_[k] = v; return; }
+            if (k + 1 <= 8 * count_ + 4096) {
+                dense_.resize(std::min<size_t>(std::max(k + 1, dense_.size() * 2), 8 * count_ + 4096), NONE);
+                dense_[k] = v;
+                return;
+            }
         }
+        sparse_[pack_id(frag, end)] = v;
     }
     // false: no such read (it then aligns as the empty string, tools/SplitAlignment.cpp:286)
     bool get(int frag, int end, const char*& s, size_t& n) const
     {
         uint64_t v = NONE;
-        if (frag >= 0 && frag < (1 << 28)) {
-            const size_t k = (size_t)frag * 2 + (size_t)end;
-            if (k < dense_.size()) v = dense_[k];
-        } else {
+        const int64_t rel = (int64_t)frag - base_;
+        if (rel >= 0 && (size_t)rel * 2 + (size_t)end < dense_.size()) v = dense_[(size_t)rel * 2 + (size_t)end];
+        if (v == NONE && !sparse_.empty()) {      // (an id stored before the table reached it; the table has the later one if both exist)
             auto it = sparse_.find(pack_id(frag, end));
             if (it != sparse_.end()) v = it->second;
         }
@@ -1040,11 +1054,14 @@ public:
         n = (size_t)(v & 0xFFFFFF);
         return true;
     }
+    size_t table_slots() const { return dense_.size(); }
 private:
     static constexpr uint64_t NONE = ~(uint64_t)0;
     std::vector<char> pool_;
     std::vector<uint64_t> dense_;
     std::unordered_map<int, uint64_t> sparse_;
+    int64_t base_ = 0;
+    size_t count_ = 0;
 };
 
 struct ReadStorePair {

@@ -74,20 +74,28 @@ int main(int argc, char* argv[])
     cmd.add("1", "seq1", "End 1 Sequences", "string");
     cmd.add("2", "seq2", "End 2 Sequences", "string");
     cmd.add("a", "align", "Split Alignments Filename", "string");
-    // Fused mode (optional, the drop-in call never gives these): one process goes from the set-cover
-    // clusters to the breakpoint predictions and still writes every intermediate file the pipeline's separate steps would
-    // (scripts/defuse_run.pl:506-533: get_align_regions.pl -> dosplitalign -> sort -n -k 1 -> evalsplitalign).
-    cmd.add_optional("c", "clusters", "Fused mode: clusters file (setcover / remove_duplicates output); the regions file named by -r is WRITTEN "
-                     "from it by the rule of get_align_regions.pl", "string", "");
-    cmd.add_switch("", "sorted", "Fused mode: write the alignments in the order of `LC_ALL=C sort -n -k 1`");
-    cmd.add_optional("q", "seq", "Fused mode: Sequence Predictions Filename (evalsplitalign -q)", "string", "");
-    cmd.add_optional("b", "break", "Fused mode: Breakpoint Predictions Filename (evalsplitalign -b)", "string", "");
-    cmd.add_optional("p", "predalign", "Fused mode: Predicted Alignments Filename (evalsplitalign -p)", "string", "");
+    // The command line is the reference's, argument for argument (tools/dosplitalign.cpp:43-56): help, usage and error texts
+    // are compared with TCLAP's byte for byte (tests/test_cli_ref.py).
+    // Fused mode, only with DEFUSE_FUSED=1 in the environment — without it these five options do not
+    // exist: one process goes from the set-cover clusters to the breakpoint predictions and still writes every intermediate
+    // file the pipeline's separate steps would (scripts/defuse_run.pl:506-533: get_align_regions.pl -> dosplitalign ->
+    // sort -n -k 1 -> evalsplitalign).
+    const bool fused_cli = [] { const char* e = std::getenv("DEFUSE_FUSED"); return e && std::atoi(e) != 0; }();
+    if (fused_cli) {
+        cmd.add_optional("c", "clusters", "Fused mode: clusters file (setcover / remove_duplicates output); the regions file named by -r is WRITTEN "
+                         "from it by the rule of get_align_regions.pl", "string", "");
+        cmd.add_switch("", "sorted", "Fused mode: write the alignments in the order of `LC_ALL=C sort -n -k 1`");
+        cmd.add_optional("q", "seq", "Fused mode: Sequence Predictions Filename (evalsplitalign -q)", "string", "");
+        cmd.add_optional("b", "break", "Fused mode: Breakpoint Predictions Filename (evalsplitalign -b)", "string", "");
+        cmd.add_optional("p", "predalign", "Fused mode: Predicted Alignments Filename (evalsplitalign -p)", "string", "");
+    }
     cmd.parse(argc, argv);
-    const bool fused_eval = !cmd.str("seq").empty() || !cmd.str("break").empty() || !cmd.str("predalign").empty();
-    if (fused_eval && (cmd.str("seq").empty() || cmd.str("break").empty() || cmd.str("predalign").empty()))
+    const std::string opt_clusters = fused_cli ? cmd.str("clusters") : std::string(), opt_seq = fused_cli ? cmd.str("seq") : std::string(),
+                      opt_break = fused_cli ? cmd.str("break") : std::string(), opt_predalign = fused_cli ? cmd.str("predalign") : std::string();
+    const bool fused_eval = !opt_seq.empty() || !opt_break.empty() || !opt_predalign.empty();
+    if (fused_eval && (opt_seq.empty() || opt_break.empty() || opt_predalign.empty()))
         die("Error: the fused mode needs all of --seq, --break and --predalign");
-    const bool collect = fused_eval || cmd.is_set("sorted");
+    const bool collect = fused_eval || (fused_cli && cmd.is_set("sorted"));
     const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_main = now();
@@ -98,21 +106,38 @@ int main(int argc, char* argv[])
         t_stage = t;
     };
 
-    // The HIP runtime and the context come up on a helper thread while the text inputs are read (a tenth of a second that
-    // would otherwise sit in front of the first batch).  A run without candidates never needs the result.
+    // The HIP runtime and the context come up on a helper thread (a tenth of a second that would otherwise sit in front of
+    // the first batch) — started when the first SAM record that overlaps a mate region has been seen, i.e. after every cheap
+    // check of the inputs (command line, regions, exons, FASTA index, FASTQ files) and only in a run that will have a
+    // candidate to align: a run without one never loads the library, let alone touches a GPU.
     dsa_ctx* ctx = nullptr;
     int ctx_rc = DSA_OK;
     DsaLib dsa;
-    std::thread ctx_thread([&] { ctx_rc = dsa.load() ? dsa.create(&ctx, dsa.pick_device()) : DSA_E_DEVICE; });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } ctx_joiner{ctx_thread};
+    std::thread ctx_thread;
+    std::once_flag ctx_once;
+    auto start_ctx = [&] {
+        std::call_once(ctx_once, [&] { ctx_thread = std::thread([&] { ctx_rc = dsa.load() ? dsa.create(&ctx, dsa.pick_device()) : DSA_E_DEVICE; }); });
+    };
+    // An error exit (die(), on whichever thread) first lets the helper finish what it is in the middle of — dlopen, the
+    // runtime's start — and then ends the process the way the success path does, without running exit handlers beside
+    // threads that are still alive.  Only one thread gets that far; any other that fails meanwhile waits behind it.
+    static std::mutex die_mutex;
+    die_hook() = [&] {
+        die_mutex.lock();
+        if (ctx_thread.joinable() && std::this_thread::get_id() != ctx_thread.get_id()) ctx_thread.join();
+        std::cout.flush();
+        std::cerr.flush();
+        fflush(nullptr);
+        _exit(1);
+    };
 
-    if (!cmd.str("clusters").empty()) {
+    if (!opt_clusters.empty()) {
         // scripts/get_align_regions.pl:14-53 (as bin/defuse_glue get_align_regions): per cluster end the reference, the strand
         // and the span of its alignments; clusters ascending, end 0 then 1
         struct EndInfo { std::string ref, strand; int start = 0, end = 0; bool have = false; };
         std::map<int, std::map<int, EndInfo>> clusters;
         MappedText ctext;
-        ctext.load(cmd.str("clusters"), "Error: Unable to open clusters file ");
+        ctext.load(opt_clusters, "Error: Unable to open clusters file ");
         for (size_t pos = 0; pos < ctext.size();) {
             const size_t e = ctext.line_end(pos);
             const size_t len = (e > pos && ctext[e - 1] == '\n') ? e - 1 - pos : e - pos;
@@ -173,7 +198,8 @@ int main(int argc, char* argv[])
         run_threads(2, [&](unsigned t) { ok[t] = AddReads(names[t], reads.file[t]); });
         if (!ok[0] || !ok[1]) {
             std::cout << "Error: unable to read sequences" << std::endl;
-            return 1;
+            std::cout.flush();
+            _exit(1);                             // (no helper thread exists yet; nothing to unwind that the system does not)
         }
     }
 
@@ -226,7 +252,12 @@ int main(int argc, char* argv[])
                 pairs[(size_t)k] = cand[c];
             }
         }
-        if (ctx_thread.joinable()) ctx_thread.join();
+        start_ctx();                              // (already running: a batch has candidates, so a record had overlaps)
+        {
+            static std::mutex join_mutex;
+            std::lock_guard<std::mutex> lk(join_mutex);
+            if (ctx_thread.joinable()) ctx_thread.join();
+        }
         if (!dsa.error.empty()) die("Error: cannot load the split alignment library: " + dsa.error);
         if (ctx_rc != DSA_OK || !ctx) die("Error: no usable MI355X/HIP device (dsa_create failed)");
         std::vector<dsa_record> recs(std::max<size_t>(1024, 2 * pairs.size()));
@@ -353,6 +384,8 @@ int main(int argc, char* argv[])
             }
             if (readEnd >= 0) pc.lastReadEnd = readEnd;
         });
+        for (const SamPiece& pc : pieces)
+            if (!pc.hits.empty()) { start_ctx(); break; }
         stage("  sam records + overlaps of a round");
         for (SamPiece& pc : pieces) {                                    // read end a piece's first records inherit
             pc.carryIn = carryReadEnd;
@@ -521,14 +554,14 @@ int main(int argc, char* argv[])
         });
         out.write_round(sorted_text, nt);
         if (fused_eval) {
-            const char* names[3] = {"seq", "break", "predalign"};
+            const std::string names[3] = {opt_seq, opt_break, opt_predalign};
             for (int f = 0; f < 3; ++f) {
                 OrderedFileWriter w;
-                if (!w.open_file(cmd.str(names[f]))) die("Error: Unable to open " + cmd.str(names[f]));
+                if (!w.open_file(names[f])) die("Error: Unable to open " + names[f]);
                 std::vector<std::string> parts(nt);
                 for (unsigned t = 0; t < nt; ++t) parts[t].swap(f == 0 ? ev[t].seq : f == 1 ? ev[t].brk : ev[t].pred);
                 w.write_round(parts, nt);
-                if (!w.close_file()) die("Error: failed writing " + cmd.str(names[f]));
+                if (!w.close_file()) die("Error: failed writing " + names[f]);
             }
         }
         stage("fused: sort + evaluation + files");
