@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "dsa_kernels.hpp"
+#include "dsa_long.hpp"
 
 using namespace dsa;
 
@@ -169,6 +170,15 @@ struct dsa_ctx {
     std::vector<Slice> slices;
     float last_plan_ms = 0.f;        // device time of the latest planning (upload's or dsa_plan's)
     std::vector<int32_t> h_min_score;
+    // pairs beyond the 16-bit kernels (dsa_long.hpp): reads longer than FAST_MAX_READ or windows longer than FAST_MAX_REF
+    std::vector<LongDesc> h_long;
+    std::vector<int32_t> h_long_fusions;
+    std::vector<LongState> h_long_state;
+    DevBuf<LongDesc> d_long;
+    DevBuf<int32_t> d_long_fusions, d_long_work, d_long_rows;
+    DevBuf<LongState> d_long_state;
+    DevBuf<uint32_t> d_long_bits;
+    int64_t long_cells = 0;
 
     // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
     // slice overlaps the fill of the next (separate HIP streams)
@@ -402,6 +412,10 @@ void launch_emit(dsa_ctx* ctx, PipeLane& L, const Slice& s, size_t cap_left, boo
                        L.d_state.p, L.d_kept.p, L.d_tasks.p, L.d_masks.p, (const int64_t*)L.d_rec_offset.p, out, (uint64_t)cap_left,
                        (int64_t)s.pair_begin, L.d_ctr.p, (uint64_t)L.d_kept.cap, (uint64_t)L.d_tasks.cap, (uint64_t)(L.d_masks.cap / 2),
                        (uint64_t)L.d_gtasks.cap, g);
+    if (!ctx->h_long.empty())
+        hipLaunchKernelGGL(k_long_emit<true>, dim3((unsigned)((ctx->h_long.size() + 63) / 64)), dim3(64), 0, L.stream, ctx->d_long.p, ctx->d_long_state.p,
+                           (int)ctx->h_long.size(), ctx->d_long_work.p, ctx->d_long_bits.p, (int64_t)s.pair_begin, (int64_t)s.pair_end, L.d_rec_count.p,
+                           (const int64_t*)L.d_rec_offset.p, out, (uint64_t)cap_left);
     (void)hipStreamWaitEvent(L.stream, L.ev_join, 0);
     (void)hipEventRecord(L.ev[6], L.stream);
 }
@@ -450,6 +464,10 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
                        pairs, ctx->d_fusions.p, L.d_state.p, L.d_kept.p, L.d_tasks.p, (uint64_t)L.d_tasks.cap, L.d_masks.p,
                        (uint64_t)(L.d_masks.cap / 2), (uint64_t)L.d_kept.cap, L.d_rec_count.p, (const int64_t*)nullptr, (dsa_record*)nullptr,
                        (uint64_t)0, (int64_t)s.pair_begin, g);
+    if (!ctx->h_long.empty())           // the long pairs of this slice: their counts replace the zeros of the blanked copies
+        hipLaunchKernelGGL(k_long_emit<false>, dim3((unsigned)((ctx->h_long.size() + 63) / 64)), dim3(64), 0, st, ctx->d_long.p, ctx->d_long_state.p,
+                           (int)ctx->h_long.size(), ctx->d_long_work.p, ctx->d_long_bits.p, (int64_t)s.pair_begin, (int64_t)s.pair_end, L.d_rec_count.p,
+                           (const int64_t*)nullptr, (dsa_record*)nullptr, (uint64_t)0);
     if (int rc = exclusive_scan(ctx, L, L.d_rec_count.p, L.d_rec_offset.p, np + 1)) return rc;
     // the cursors and the record total go to the lane's pinned result words
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, L.d_ctr.p, L.d_rec_offset.p + np, reinterpret_cast<const unsigned long long*>(ctx->plan_glob.p + (&s - ctx->slices.data())),
@@ -478,7 +496,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     Geom g = s.g;
     hipStream_t st = L.stream;
     const int64_t np = g.n_pairs;
-    if (g.lq1 > ((7600 + 1 + 3) & ~3)) return fail(ctx, DSA_E_LIMIT, "reads longer than 7600 are not supported");   // lq1 is padded to a multiple of 4
+    if (g.lq1 > ((FAST_MAX_READ + 1 + 3) & ~3)) return fail(ctx, DSA_E_LIMIT, "internal: a long read reached the 16-bit kernels");
     const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
     HIPC(L.d_wg_tier.reserve((size_t)g.n_wgs));
     HIPC(L.d_rowcodes.reserve(n_rows));
@@ -713,6 +731,8 @@ void dsa_destroy(dsa_ctx* ctx)
     ctx->plan_runs.release(); ctx->plan_key.release(); ctx->plan_key_sorted.release(); ctx->plan_fidx.release(); ctx->plan_order.release();
     ctx->plan_bsum.release(); ctx->plan_start.release(); ctx->plan_rank.release(); ctx->plan_bound.release(); ctx->plan_flip.release();
     ctx->plan_sort_tmp.release(); ctx->plan_glob.release();
+    ctx->d_long.release(); ctx->d_long_fusions.release(); ctx->d_long_work.release(); ctx->d_long_rows.release(); ctx->d_long_state.release();
+    ctx->d_long_bits.release();
     for (auto& e : ctx->ev_pack)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_plan)
@@ -736,8 +756,10 @@ int dsa_share_scratch(dsa_ctx* ctx, dsa_ctx* donor)
 int dsa_get_limits(const dsa_ctx*, dsa_limits* out)
 {
     if (!out) return DSA_E_ARG;
-    out->max_read_len = 7600;       // V + 1024 = H + 2j + 1024 <= 4*Lq + 1024 must stay a finite fp16 pattern (< 0x7C00)
-    out->max_ref_len = 255 * W;     // chunk index is 8 bits in ReplayTask
+    // the 16-bit tile kernels take reads up to FAST_MAX_READ and windows up to FAST_MAX_REF; anything longer is swept in 32 bits
+    // (dsa_long.hpp), about three orders of magnitude slower per cell
+    out->max_read_len = LONG_MAX_READ;
+    out->max_ref_len = LONG_MAX_REF;
     out->tile_cols = W;
     return DSA_OK;
 }
@@ -775,28 +797,54 @@ int upload_enqueue(dsa_ctx* ctx, hipStream_t st, const uint8_t* ref_bytes, int64
     if (n_pairs >= ((int64_t)1 << 31)) return fail(ctx, DSA_E_LIMIT, "more than 2^31-1 pairs in one batch");
     if ((n_fusions && !fusions) || (n_pairs && !pairs) || (ref_bytes_len && !ref_bytes) || (read_bytes_len && !read_bytes))
         return fail(ctx, DSA_E_ARG, "null pointer with non-zero size");
-    dsa_limits lim;
-    dsa_get_limits(ctx, &lim);
+    // A pair goes to the 16-bit tile kernels unless its read or one of its fusion's windows is too long for them; those few
+    // are swept in 32 bits by kernels of their own (dsa_long.hpp), and the regular path sees them as empty reads / windows.
+    ctx->h_long.clear();
+    ctx->h_long_fusions.clear();
+    ctx->long_cells = 0;
+    int nch_all = 1, maxwin = 0;
     for (int32_t f = 0; f < n_fusions; ++f) {
         const dsa_fusion& fu = fusions[f];
         if (fu.ref0_len < 0 || fu.ref1_len < 0 || fu.ref0_off < 0 || fu.ref1_off < 0 ||
             (int64_t)fu.ref0_off + fu.ref0_len > ref_bytes_len || (int64_t)fu.ref1_off + fu.ref1_len > ref_bytes_len)
             return fail(ctx, DSA_E_ARG, "fusion %d: reference window outside ref_bytes", f);
-        if (fu.ref0_len > lim.max_ref_len || fu.ref1_len > lim.max_ref_len)
-            return fail(ctx, DSA_E_LIMIT, "fusion %d: reference window longer than %d", f, lim.max_ref_len);
+        if (fu.ref0_len > LONG_MAX_REF || fu.ref1_len > LONG_MAX_REF)
+            return fail(ctx, DSA_E_LIMIT, "fusion %d: reference window longer than %d", f, LONG_MAX_REF);
+        if (fu.ref0_len > FAST_MAX_REF || fu.ref1_len > FAST_MAX_REF) {
+            ctx->h_long_fusions.push_back(f);
+            continue;
+        }
+        nch_all = std::max(nch_all, std::max(cdiv(fu.ref0_len, W), cdiv(fu.ref1_len, W)));
+        maxwin = std::max(maxwin, std::max(fu.ref0_len, fu.ref1_len));
     }
-    int nch_all = 1, maxwin = 0;
-    for (int32_t f = 0; f < n_fusions; ++f) {
-        nch_all = std::max(nch_all, std::max(cdiv(fusions[f].ref0_len, W), cdiv(fusions[f].ref1_len, W)));
-        maxwin = std::max(maxwin, std::max(fusions[f].ref0_len, fusions[f].ref1_len));
-    }
+    const bool any_long_fusion = !ctx->h_long_fusions.empty();
     int lqmax = 0;
     for (int64_t p = 0; p < n_pairs; ++p) {
         const dsa_pair& pr = pairs[p];
         if (pr.fusion_idx < 0 || pr.fusion_idx >= n_fusions) return fail(ctx, DSA_E_ARG, "pair %lld: bad fusion_idx", (long long)p);
         if (pr.read_len < 0 || pr.read_off < 0 || (int64_t)pr.read_off + pr.read_len > read_bytes_len)
             return fail(ctx, DSA_E_ARG, "pair %lld: read outside read_bytes", (long long)p);
-        if (pr.read_len > lim.max_read_len) return fail(ctx, DSA_E_LIMIT, "pair %lld: read longer than %d", (long long)p, lim.max_read_len);
+        if (pr.read_len > LONG_MAX_READ) return fail(ctx, DSA_E_LIMIT, "pair %lld: read longer than %d", (long long)p, LONG_MAX_READ);
+        if (pr.read_len > FAST_MAX_READ ||
+            (any_long_fusion && (fusions[pr.fusion_idx].ref0_len > FAST_MAX_REF || fusions[pr.fusion_idx].ref1_len > FAST_MAX_REF))) {
+            const dsa_fusion& fu = fusions[pr.fusion_idx];
+            LongDesc d;
+            d.pair_idx = (int32_t)p;
+            d.read_off = pr.read_off;
+            d.read_len = pr.read_len;
+            d.ref0_off = fu.ref0_off;
+            d.ref0_len = fu.ref0_len;
+            d.ref1_off = fu.ref1_off;
+            d.ref1_len = fu.ref1_len;
+            d.fusion_id = fu.fusion_id;
+            d.frag = pr.frag;
+            d.read_end = pr.read_end;
+            d.revcomp = pr.revcomp;
+            d.min_score = min_score_for(pr.read_len);
+            ctx->h_long.push_back(d);
+            ctx->long_cells += (int64_t)(fu.ref0_len + 1 + fu.ref1_len + 1) * (pr.read_len + 1);
+            continue;
+        }
         lqmax = std::max(lqmax, (int)pr.read_len);
     }
     HIPC(hipSetDevice(ctx->device));
@@ -817,6 +865,16 @@ int upload_enqueue(dsa_ctx* ctx, hipStream_t st, const uint8_t* ref_bytes, int64
     if (read_bytes_len) HIPC(hipMemcpyAsync(ctx->d_reads.p, read_bytes, read_bytes_len, hipMemcpyHostToDevice, st));
     if (n_fusions) HIPC(hipMemcpyAsync(ctx->d_fusions.p, fusions, n_fusions * sizeof(dsa_fusion), hipMemcpyHostToDevice, st));
     if (n_pairs) HIPC(hipMemcpyAsync(ctx->d_pairs_in.p, pairs, n_pairs * sizeof(dsa_pair), hipMemcpyHostToDevice, st));
+    if (!ctx->h_long.empty() || !ctx->h_long_fusions.empty()) {
+        const int nl = (int)ctx->h_long.size(), nlf = (int)ctx->h_long_fusions.size();
+        HIPC(ctx->d_long.reserve((size_t)nl + 1));
+        HIPC(ctx->d_long_fusions.reserve((size_t)nlf + 1));
+        if (nl) HIPC(hipMemcpyAsync(ctx->d_long.p, ctx->h_long.data(), (size_t)nl * sizeof(LongDesc), hipMemcpyHostToDevice, st));
+        if (nlf) HIPC(hipMemcpyAsync(ctx->d_long_fusions.p, ctx->h_long_fusions.data(), (size_t)nlf * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        const int n = std::max(nl, nlf);
+        hipLaunchKernelGGL(k_long_blank, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx->d_pairs_in.p, ctx->d_long.p, nl, ctx->d_fusions.p,
+                           ctx->d_long_fusions.p, nlf);
+    }
     std::vector<int32_t>& tab = ctx->h_min_score;       // lives as long as the copy may be in flight
     tab.resize(lqmax + 1);
     for (int l = 0; l <= lqmax; ++l) tab[l] = min_score_for(l);
@@ -884,8 +942,50 @@ void reset_lanes(dsa_ctx* ctx)
     (void)hipGetLastError();
 }
 
+// The two sweeps of the long pairs of the upload (dsa_long.hpp), on lane 0's stream in front of the slices: row maxima and
+// kept splits, then — the host sizes the bitmaps in between, this path is rare — the columns of the kept rows.
+int run_long(dsa_ctx* ctx)
+{
+    const int nl = (int)ctx->h_long.size();
+    if (nl == 0) return DSA_OK;
+    hipStream_t st = ctx->lanes->lane[0].stream;
+    std::vector<LongState>& hs = ctx->h_long_state;
+    hs.assign((size_t)nl, LongState{});
+    int64_t work = 0, rows_max = 0;
+    for (int k = 0; k < nl; ++k) {
+        const LongDesc& d = ctx->h_long[(size_t)k];
+        hs[(size_t)k].work_off = work;
+        work += long_work_words(d.read_len);
+        rows_max = std::max(rows_max, long_rows_words(d.ref0_len, d.ref1_len));
+    }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(nl, 512), ((int64_t)1 << 28) / std::max<int64_t>(rows_max, 1)));   // at most 1 GiB of row buffers
+    HIPC(ctx->d_long_work.reserve((size_t)work + 1));
+    HIPC(ctx->d_long_rows.reserve((size_t)(rows_max * grid) + 1));
+    HIPC(ctx->d_long_state.reserve((size_t)nl));
+    HIPC(hipMemcpyAsync(ctx->d_long_state.p, hs.data(), (size_t)nl * sizeof(LongState), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_long_rows, dim3((unsigned)grid), dim3(LONG_THREADS), 0, st, ctx->d_long.p, ctx->d_long_state.p, nl, ctx->d_ref.p, ctx->d_reads.p,
+                       ctx->d_long_work.p, ctx->d_long_rows.p, rows_max);
+    HIPC(hipMemcpyAsync(hs.data(), ctx->d_long_state.p, (size_t)nl * sizeof(LongState), hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    HIPC(hipGetLastError());
+    int64_t bits = 0;
+    for (int k = 0; k < nl; ++k) {
+        const LongDesc& d = ctx->h_long[(size_t)k];
+        hs[(size_t)k].bits_off = bits;
+        bits += (int64_t)hs[(size_t)k].n_kept * (long_bitmap_words(d.ref0_len) + long_bitmap_words(d.ref1_len));
+    }
+    HIPC(ctx->d_long_bits.reserve((size_t)bits + 1));
+    HIPC(hipMemcpyAsync(ctx->d_long_state.p, hs.data(), (size_t)nl * sizeof(LongState), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_long_cols, dim3((unsigned)grid), dim3(LONG_THREADS), 0, st, ctx->d_long.p, ctx->d_long_state.p, nl, ctx->d_ref.p, ctx->d_reads.p,
+                       ctx->d_long_work.p, ctx->d_long_rows.p, rows_max, ctx->d_long_bits.p);
+    HIPC(hipGetLastError());
+    ctx->timing.cells += ctx->long_cells;
+    return DSA_OK;
+}
+
 int run_slices(dsa_ctx* ctx)
 {
+    if (int rc = run_long(ctx)) return rc;
     // two slices in flight: phase 1 of slice k+1 is queued before the host waits for slice k
     const int ns = (int)ctx->slices.size();
     if (ns > 0 && ctx->n_fusions > 0) {

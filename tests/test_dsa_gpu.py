@@ -83,6 +83,63 @@ def test_parity_limits(gpu_ctx, ora, lq, lr, n_reads):
     check_batch(gpu_ctx, ora, bb.arrays())
 
 
+def test_parity_beyond_the_16_bit_kernels(built, ora):
+    """Reads longer than 7600 bases and windows longer than 16320 (the reference's matrix grows on demand,
+    tools/Matrix.h:98-107): such pairs are swept in 32 bits by kernels of their own, in the same batch as ordinary pairs, and
+    their records come out in the caller's pair order like everyone else's - also across slices, also when every pair of the
+    batch is a long one, also with tied columns (a window that holds the junction twice)."""
+    import numpy as np
+    from defuse_amd import dsa
+    rng = np.random.default_rng(2024)
+    bb = cases.BatchBuilder()
+    ref0, ref1 = cases.rnd(rng, 12000), cases.rnd(rng, 11000)
+    f_long = bb.add_fusion(ref0, ref1)                              # windows fit, the read does not
+    s0, s1 = cases.rnd(rng, 330), cases.rnd(rng, 350)
+    f_short = bb.add_fusion(s0, s1)
+    w0 = cases.rnd(rng, 9000)
+    seg = w0[4000:4060]
+    w0 = w0[:7000] + seg + w0[7060:]                                # the same 60 bases twice in a window of 20 000: tied columns
+    wide0, wide1 = w0 + cases.rnd(rng, 11000), cases.rnd(rng, 17000)
+    f_wide = bb.add_fusion(wide0, wide1)                            # short reads, over-long windows
+    for k in range(30):
+        bb.add_read(f_short, cases.mutate(rng, cases.split_read(rng, s0, s1, 76), 0.01))
+    bb.add_read(f_long, cases.mutate(rng, cases.split_read(rng, ref0, ref1, 10000), 0.01))
+    for k in range(30):
+        bb.add_read(f_short, cases.mutate(rng, cases.split_read(rng, s0, s1, 76), 0.01))
+    bb.add_read(f_wide, wide0[4030:4060] + wide1[100:150])          # junction after the repeated segment
+    bb.add_read(f_wide, cases.mutate(rng, cases.split_read(rng, wide0, wide1, 120), 0.02))
+    bb.add_read(f_long, cases.mutate(rng, cases.split_read(rng, ref0, ref1, 7601), 0.005))
+    for k in range(300):
+        bb.add_read(f_short, cases.mutate(rng, cases.split_read(rng, s0, s1, 76), 0.01))
+    batch = bb.arrays()
+    exp = ora.align_batch(*batch)
+    ctx = dsa.Context(0)
+    lim = ctx.limits()
+    assert lim.max_read_len >= 1 << 20 and lim.max_ref_len >= 1 << 24
+    got = ctx.align_batch(*batch)
+    assert got.tobytes() == exp.tobytes()
+    long_pairs = [30, 61, 62, 63]
+    assert all(np.any(exp["pair_idx"] == p) for p in long_pairs)          # every long pair really aligns
+    assert np.sum(exp["pair_idx"] == 61) >= 2                             # the repeated segment: tied columns
+    assert ctx.timing().cells > 2 * 10001 * 12001
+    ctx.close()
+    os.environ["DEFUSE_DSA_SLICE_PAIRS"] = "256"                          # two slices, long pairs in the first
+    try:
+        ctx = dsa.Context(0)
+        assert ctx.align_batch(*batch).tobytes() == exp.tobytes()
+        assert ctx.timing().fill_launches == 2
+        # a batch of long pairs only
+        only = cases.BatchBuilder()
+        f = only.add_fusion(wide0, wide1)
+        only.add_read(f, wide0[4030:4060] + wide1[100:150])
+        only.add_read(f, cases.mutate(rng, cases.split_read(rng, wide0, wide1, 90), 0.02))
+        b2 = only.arrays()
+        assert ctx.align_batch(*b2).tobytes() == ora.align_batch(*b2).tobytes()
+        ctx.close()
+    finally:
+        del os.environ["DEFUSE_DSA_SLICE_PAIRS"]
+
+
 def test_parity_pruning_diagonal_entry(gpu_ctx, ora):
     """A borderline alignment (one mismatch + one inserted read base: exactly minScore) that leaves tile 0 through
     its last column at row 27 and enters tile 1 diagonally at row 28, alone in its wave: everything of tile 1 up
