@@ -451,8 +451,15 @@ constexpr int WV = 64;
 // walk (SX[i] = SX[i-1] + RXO[i]) and the first breakpoint with a positive derivative ends it, so neither the
 // prefix arrays nor the breakpoint list are stored.  nk receives the component's sum of responsibilities
 // (UpdateMixWeights :183-190 takes the same sum in the same order).  Return codes as max_likelihood.
+#ifdef MPE_PHASE_STATS
+__device__ unsigned long long g_mpe_walk[4];      // wave cycles in the M step's serial sums / in its breakpoint walk, walk steps (longest lane), calls
+#endif
 __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int stride, double& a, double& b, double& nk)
 {
+#ifdef MPE_PHASE_STATS
+    const unsigned long long tw0 = __builtin_readcyclecounter();
+    unsigned long long n_steps = 0;
+#endif
     // the component's responsibilities in x order: element r at RXO_base[r * stride] (the fits keep them component-minor,
     // so that the lanes of a fit, which own its components, touch neighbouring words)
     auto RXO = [&](int r) { return RXO_base[(size_t)r * stride]; };
@@ -461,13 +468,22 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
     const int* XfromY = w.XfromY;
     double NK = 0.0, RXYU = 0.0;
     int t = 0;
-    for (; t + MPE_CHAIN <= N; t += MPE_CHAIN) {      // loads in batches so that only the additions are serial
-        int ix[MPE_CHAIN];
+    // Loads in batches so that only the additions are serial, and the batches overlap: a batch's responsibilities are gathered
+    // through indices that were fetched while the batch before it was summed (one round trip to memory per batch, not two).
+    int ixn[MPE_CHAIN];
+    double qn[MPE_CHAIN];
+    if (N >= MPE_CHAIN) {
+#pragma unroll
+        for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[v]; qn[v] = w.XYU[v]; }
+    }
+    for (; t + MPE_CHAIN <= N; t += MPE_CHAIN) {
         double r[MPE_CHAIN], q[MPE_CHAIN];
 #pragma unroll
-        for (int v = 0; v < MPE_CHAIN; ++v) { ix[v] = TX[t + v]; q[v] = w.XYU[t + v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) { r[v] = RXO(ixn[v]); q[v] = qn[v]; }
+        if (t + 2 * MPE_CHAIN <= N) {
 #pragma unroll
-        for (int v = 0; v < MPE_CHAIN; ++v) r[v] = RXO(ix[v]);
+            for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[t + MPE_CHAIN + v]; qn[v] = w.XYU[t + MPE_CHAIN + v]; }
+        }
 #pragma unroll
         for (int v = 0; v < MPE_CHAIN; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
     }
@@ -477,6 +493,9 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
         RXYU += r * w.XYU[t];
     }
     nk = NK;
+#ifdef MPE_PHASE_STATS
+    const unsigned long long tw1 = __builtin_readcyclecounter();
+#endif
     if (NK == 0.0) return 0;
     const double var = w.sd * w.sd;
     double pcx = 0.0, pcy = 0.0, pcs = 0.0, ccx = 0.0, ccy = 0.0, ccs = 0.0;
@@ -503,8 +522,14 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
     double xi = w.XO[0], yj = w.YO[0];
     double xn = 0.0, yn = 0.0, rxn = 0.0, ryn = 0.0;
     if (N > 1) { xn = w.XO[1]; yn = w.YO[1]; rxn = RXO(1); ryn = RXO(XfromY[1]); }
+    // the y side reaches its responsibilities through the rank map (RXO(XfromY[j])): the index of the element after the next is
+    // fetched one advance early, so that an advance waits for one round trip to memory and not for two in a row
+    int jx2 = N > 2 ? XfromY[2] : 0;
     push(xi, yj, 0.0);
     while (!found && i < N && j < N) {
+#ifdef MPE_PHASE_STATS
+        ++n_steps;
+#endif
         const bool hi = i + 1 < N, hj = j + 1 < N;
         bool adv_i, adv_j;
         if (hi && xi == xn) { adv_i = true; adv_j = false; }
@@ -528,9 +553,24 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
             ++j;
             yj = yn;
             if (j < N) sy = sy + ryn;
-            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO(XfromY[j + 1]); }
+            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO(jx2); }
+            if (j + 2 < N) jx2 = XfromY[j + 2];
         }
     }
+#ifdef MPE_PHASE_STATS
+    {
+        const unsigned long long tw2 = __builtin_readcyclecounter();
+        unsigned long long ms = n_steps;
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(ms, off); ms = o > ms ? o : ms; }   // (only the lanes in here take part)
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) {
+            atomicAdd(&g_mpe_walk[0], tw1 - tw0);
+            atomicAdd(&g_mpe_walk[1], tw2 - tw1);
+            atomicAdd(&g_mpe_walk[2], ms);
+            atomicAdd(&g_mpe_walk[3], 1ull);
+        }
+    }
+#endif
     if (!found) return -1;
     const double aplusb = (RXYU + var * LAMBDA * ccs) / NK;
     if (mi == 0) {
@@ -710,6 +750,21 @@ __global__ void k_mpe_final(mpe_params prm, const int64_t* __restrict__ prob_off
 // the chosen K that the reference runs after the model selection is that fit's state, which is still there.
 constexpr int MPE_NCOMP = MPE_KMAX * (MPE_KMAX + 1) / 2;     // 55 component lanes
 
+// -DMPE_PHASE_STATS (diagnostic builds, profiles/microbench/build_variant.sh): wave cycles per phase of k_mpe_problem_wave,
+// summed over the problems and printed by mpe_cluster_batch — set-up, KKZ seeds, k-means start-ups, M steps, E steps,
+// log-likelihood chains + loop control, model selection + memberships
+#ifdef MPE_PHASE_STATS
+__device__ unsigned long long g_mpe_phase[8];
+#define MPE_STAMP(k)                                                   \
+    do {                                                               \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        ph_[k] += now_ - t_;                                           \
+        t_ = now_;                                                     \
+    } while (0)
+#else
+#define MPE_STAMP(k)
+#endif
+
 struct ProblemShared {
     double W[MPE_NCOMP], A[MPE_NCOMP], B[MPE_NCOMP];
     double px[MPE_KMAX], py[MPE_KMAX];
@@ -737,9 +792,13 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     mpe_params prm, const int64_t* __restrict__ prob_off, int p0, const int32_t* __restrict__ order, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
     const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles, int* __restrict__ wints,
-    int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters)
+    int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters,
+    long long* __restrict__ iters_by_k, double* __restrict__ ll_by_k)
 {
     __shared__ ProblemShared s;
+#ifdef MPE_PHASE_STATS
+    unsigned long long ph_[8] = {}, t_ = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x;
     const int q = order[blockIdx.x];
     const int p = p0 + q;
@@ -783,6 +842,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     if (lane < MPE_NCOMP) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
     __syncthreads();
 
+    MPE_STAMP(0);
     // ---- KKZ seeds (:327-386), once for kmax; a fit needs seeds unless K == 1 or K == N
     {
         double best = 0.0;
@@ -814,6 +874,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         }
         __syncthreads();
     }
+    MPE_STAMP(1);
     // ---- start-up of every fit (:388-450): uniform responsibilities, or k-means from the seeds (one fit per lane)
     if (lane >= 1 && lane <= kmax) {
         const int K = lane;
@@ -843,6 +904,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     }
     __syncthreads();
 
+    MPE_STAMP(2);
     // ---- EM of all fits
     long long my_iters = 0;
     for (;;) {
@@ -858,6 +920,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         __syncthreads();
         if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
         __syncthreads();
+        MPE_STAMP(3);
         // E step, fit after fit: exponents, exp, mixture sum, log — and, from the same registers, the responsibilities
         // W_j e_j / sum of UpdateResponsibilities (:139-181).  The reference updates them after the convergence test; nothing
         // reads them between here and the next M step, and a fit that stops in this iteration never reads them again, so
@@ -898,6 +961,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
             if (zero) s.zero[K] = 1;
         }
         __syncthreads();
+        MPE_STAMP(4);
         // log-likelihood chains (:96-137) and the loop control of ExpectationMaximization (:455-492), one fit per lane
         if (lane >= 1 && lane <= kmax && s.active[lane]) {
             const int K = lane;
@@ -934,9 +998,14 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
             s.any_active = any;
         }
         __syncthreads();
+        MPE_STAMP(5);
         if (!s.any_active) break;
     }
     const long long fit_iters = my_iters;                  // lane K: iterations of the fit with K components
+    if (iters_by_k && lane >= 1 && lane <= MPE_KMAX) {                                                      // diagnostics (DEFUSE_MPE_DUMP_ITERS)
+        iters_by_k[(int64_t)p * 12 + lane] = fit_iters;
+        ll_by_k[(int64_t)p * 12 + lane] = (lane <= kmax && s.state[lane] == 1) ? s.like[lane] : 0.0;
+    }
     for (int off = 32; off > 0; off >>= 1) my_iters += __shfl_xor(my_iters, off);
 
     // ---- model selection (:599-606); a fit that tripped a DebugCheck ends the reference's run there
@@ -956,7 +1025,12 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     }
     // the refit of k_min (:608-615) repeats that fit exactly: its parameters are still in s.A / s.B (its iterations are
     // counted again, as the refit's would be); a fit without a likelihood leaves no clusters.
-    my_iters += __shfl(fit_iters, k_min);
+    const long long refit_iters = __shfl(fit_iters, k_min);
+    my_iters += refit_iters;
+    if (iters_by_k && lane == 0) {
+        iters_by_k[(int64_t)p * 12] = k_min;
+        iters_by_k[(int64_t)p * 12 + 11] = refit_iters;
+    }
     if (s.state[k_min] == 1) {
         const int l0 = k_min * (k_min - 1) / 2;
         int* flags = wints + wi_off[q * MPE_KMAX + kmax - 1];
@@ -981,6 +1055,11 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         }
         if (lane == 0) n_clusters[p] = emitted;
     }
+    MPE_STAMP(6);
+#ifdef MPE_PHASE_STATS
+    if (lane == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_mpe_phase[k], ph_[k]);
+#endif
     if (lane == 0) atomicAdd(iters, (unsigned long long)my_iters);
 }
 
@@ -1030,6 +1109,17 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         MPE_HIP(hipMemcpy(d_tyo.p, to_yo, n_mp * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     MPE_HIP(hipMemset(d_iters.p, 0, sizeof(unsigned long long)));
+    // DEFUSE_MPE_DUMP_ITERS=<file>: per problem twelve int64 — [0] the chosen K, [K] the EM iterations of the fit with K
+    // components, [11] those of the refit — for the problems a wave fits (tests compare them with the restatement's)
+    const char* dump_iters = getenv("DEFUSE_MPE_DUMP_ITERS");
+    DBuf<long long> d_by_k;
+    DBuf<double> d_ll_by_k;                  // ... followed in the file by twelve doubles per problem: [K] the log-likelihood fit K ended with
+    if (dump_iters) {
+        MPE_HIP(d_by_k.alloc((size_t)n_problems * 12));
+        MPE_HIP(hipMemset(d_by_k.p, 0, (size_t)n_problems * 12 * sizeof(long long)));
+        MPE_HIP(d_ll_by_k.alloc((size_t)n_problems * 12));
+        MPE_HIP(hipMemset(d_ll_by_k.p, 0, (size_t)n_problems * 12 * sizeof(double)));
+    }
     hipraii::Event e0, e1, e2;               // destroyed on every return, the early ones of MPE_HIP included
     MPE_HIP(e0.create());
     MPE_HIP(e1.create());
@@ -1097,7 +1187,7 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         if (n_large)                 // order[0 .. n_large): the problems with a wave of their own, largest first
             hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
                                d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
-                               d_iters.p);
+                               d_iters.p, d_by_k.p, d_ll_by_k.p);
         if (n_small) {
             const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
             hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_large, n_small,
@@ -1124,6 +1214,36 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     MPE_HIP(hipMemcpy(&it, d_iters.p, sizeof it, hipMemcpyDeviceToHost));
 
     t.em_iterations = (int64_t)it;
+#ifdef MPE_PHASE_STATS
+    {
+        unsigned long long ph[8] = {};
+        MPE_HIP(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_mpe_phase), sizeof ph));
+        unsigned long long tot = 0;
+        for (int k = 0; k < 7; ++k) tot += ph[k];
+        const char* names[7] = {"set-up", "KKZ seeds", "k-means start-ups", "M steps", "E steps", "likelihood chains + control", "selection + memberships"};
+        fprintf(stderr, "[mpe phases] wave cycles");
+        for (int k = 0; k < 7; ++k) fprintf(stderr, " | %s %.1f %%", names[k], tot ? 100.0 * ph[k] / tot : 0.0);
+        fprintf(stderr, " | total %.3g cycles, kernel %.1f ms\n", (double)tot, t.kernel_ms);
+        unsigned long long wk[4] = {};
+        MPE_HIP(hipMemcpyFromSymbol(wk, HIP_SYMBOL(g_mpe_walk), sizeof wk));
+        fprintf(stderr, "[mpe M step] serial sums %.3g cycles, breakpoint walk %.3g cycles, walk steps of the longest lane %.4g per M step (%llu M steps), "
+                "%.0f cycles per walk step\n", (double)wk[0], (double)wk[1], wk[3] ? (double)wk[2] / wk[3] : 0.0, wk[3], wk[2] ? (double)wk[1] / wk[2] : 0.0);
+        unsigned long long zero[8] = {};
+        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_phase), zero, sizeof zero));
+        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_walk), zero, sizeof wk));
+    }
+#endif
+    if (dump_iters) {
+        std::vector<long long> h((size_t)n_problems * 12);
+        MPE_HIP(hipMemcpy(h.data(), d_by_k.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        std::vector<double> hl((size_t)n_problems * 12);
+        MPE_HIP(hipMemcpy(hl.data(), d_ll_by_k.p, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dump_iters, "wb")) {
+            fwrite(h.data(), sizeof(long long), h.size(), f);
+            fwrite(hl.data(), sizeof(double), hl.size(), f);
+            fclose(f);
+        }
+    }
     for (int p = 0; p < n_problems; ++p) t.n_failed += status[p] != 0;
     if (timing) *timing = t;
     return 0;

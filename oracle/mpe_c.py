@@ -21,10 +21,11 @@ class Diag(C.Structure):
                 ("min_deriv_margin", C.c_double), ("min_merge_margin", C.c_double),
                 ("nk_zero", C.c_int64), ("nk_zero_first_iter", C.c_int64), ("ll_underflow", C.c_int64), ("kkz_fail", C.c_int64),
                 ("em_iterations", C.c_int64), ("merge_equal", C.c_int64), ("all_k_failed", C.c_int64),
-                ("min_deriv_margin_first", C.c_double), ("min_merge_margin_first", C.c_double), ("deriv_zero", C.c_int64)]
+                ("min_deriv_margin_first", C.c_double), ("min_merge_margin_first", C.c_double), ("deriv_zero", C.c_int64),
+                ("iters_by_k", C.c_int64 * 12), ("ll_by_k", C.c_double * 12)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n in ("iters_by_k", "ll_by_k") else getattr(self, n)) for n, _ in self._fields_}
 
 
 _lib = None

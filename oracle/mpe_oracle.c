@@ -56,6 +56,8 @@ typedef struct ora_mpe_diag {
     double  min_deriv_margin_first;   /* the same two figures over the FIRST M step of every fit and all M steps of K = 1 fits: their responsibilities are 0/1 (k-means) or 1/K, no exp/log has */
     double  min_merge_margin_first;   /* been evaluated yet, so every implementation computes these decisions from bit-identical operands */
     int64_t deriv_zero;           /* breakpoints where the derivative estimate was exactly 0 (identical in any IEEE evaluation of the same operands) */
+    int64_t iters_by_k[12];       /* [K] = EM iterations of the fit with K components (K = 1..10), [11] = of the refit of the chosen K, [0] = the chosen K */
+    double  ll_by_k[12];          /* [K] = log-likelihood the fit with K components ended with (0 when it gave none) — per problem only, not merged */
 } ora_mpe_diag;
 
 /* ------------------------------------------------------------------------------------------------
@@ -342,6 +344,7 @@ typedef struct em_state {
     double *ka; int *ic1;           /* k-means scratch */
     ora_mpe_diag* dg;
     int failed;                     /* a DebugCheck of the reference fired */
+    int in_refit;                   /* the EM run is the refit of the chosen K (diagnostics only) */
 } em_state;
 
 static inline double dmin(double a, double b) { return a < b ? a : b; }
@@ -571,6 +574,7 @@ static int expectation_maximization(em_state* s, double* ll)
         }
         const double likelihood = log_likelihood(s);
         s->dg->em_iterations++;
+        s->dg->iters_by_k[s->in_refit ? 11 : K]++;
 #ifdef MPE_TRACE
         fprintf(stderr, "K %d ll %.17g last %.17g valid %d A0 %.17g B0 %.17g W0 %.17g\n", K, likelihood, last, valid, s->A[0], s->B[0], s->W[0]);
 #endif
@@ -621,6 +625,7 @@ static int do_clustering(em_state* s, uint16_t* member)
             continue;
         }
         const double bic = -2.0 * ll + K * 2.0 * log((double)N);
+        s->dg->ll_by_k[K] = ll;
         bics[K] = bic;
         bic_ok[K] = 1;
         if (!min_valid || bic < min_bic) {
@@ -634,8 +639,12 @@ static int do_clustering(em_state* s, uint16_t* member)
         if (bic_ok[K] && K != kmin && min_bic != 0.0)
             s->dg->min_bic_gap = dmin(s->dg->min_bic_gap, (bics[K] - min_bic) / fabs(min_bic));
     s->K = kmin;
+    s->dg->iters_by_k[0] = kmin;
+    s->in_refit = 1;
     double ll;
-    if (!expectation_maximization(s, &ll)) {
+    const int refit_ok = expectation_maximization(s, &ll);
+    s->in_refit = 0;
+    if (!refit_ok) {
         if (s->failed) return -1;
         return 0;                      /* "Error: No clusters" */
     }
@@ -680,6 +689,7 @@ static void diag_merge(ora_mpe_diag* into, const ora_mpe_diag* d)
     into->merge_equal += d->merge_equal;
     into->all_k_failed += d->all_k_failed;
     into->deriv_zero += d->deriv_zero;
+    for (int k = 0; k < 12; k++) into->iters_by_k[k] += d->iters_by_k[k];
 }
 
 /* Same arrays as mpe_cluster_batch (include/defuse_mpe.h).  diag and prob_diag may be NULL; prob_diag[p] receives

@@ -261,13 +261,50 @@ def test_config3_one_million_fragments_em_against_the_c_oracle(built, tmp_path):
     d = read_em_dump(str(dump))
     assert len(d["prob_off"]) - 1 > 5000 and len(d["x"]) > 500000
     args = (d["mean"], d["sd"], d["min_prob"], d["min_size"], d["prob_off"], d["x"], d["y"], d["u"], d["to_xo"], d["to_yo"])
-    g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
-    o_ncl, o_member, o_status, dg, _ = mpe_c.cluster_batch(*args)
+    its = tmp_path / "iters.bin"
+    os.environ["DEFUSE_MPE_DUMP_ITERS"] = str(its)
+    try:
+        g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
+    finally:
+        del os.environ["DEFUSE_MPE_DUMP_ITERS"]
+    o_ncl, o_member, o_status, dg, pd = mpe_c.cluster_batch(*args, per_problem_diag=True)
     assert not o_status.any() and not g_status.any()
     assert (g_ncl == o_ncl).all()
     assert g_member.tobytes() == o_member.tobytes()
-    print("config-3 1M EM margins:", dg.as_dict(), "kernel %.1f ms, device EM iterations %d (the restatement also counts the"
-          " refit of the chosen K)" % (t.kernel_ms, t.em_iterations))
+    print("config-3 1M EM margins:", {k: v for k, v in dg.as_dict().items() if not k.endswith("_by_k")}, "kernel %.1f ms, device EM iterations %d, "
+          "restatement %d" % (t.kernel_ms, t.em_iterations, dg.em_iterations))
+    # The iteration counts, fit by fit (round-2 verdict: 2 542 480 against 2 542 492 was "not analysed").  Both count every
+    # likelihood evaluation of every fit plus the refit's.  They differ in a handful of fits, every one of them a fit with
+    # MORE components than the K the problem ends up with: there the surplus components share mate pairs with
+    # responsibilities at rounding level, the M step's exact comparisons (the two inner knife edges) fall
+    # the other way under ocml's exp / log than under glibc's, and the fit walks a slightly different way along a flat
+    # likelihood ridge until |dLL| < 0.001 stops it - a few iterations earlier or later, at a log-likelihood that differs in the
+    # fourth digit.  Such a fit loses the BIC comparison by its 2 ln N per surplus component either way: the chosen K, the
+    # iterations of its fit and of its refit, and every membership bit are the same.
+    import numpy as np
+    n = len(d["prob_off"]) - 1
+    raw = np.fromfile(str(its), dtype=np.int64)
+    dev, dev_ll = raw[:n * 12].reshape(n, 12), raw[n * 12:].view(np.float64).reshape(n, 12)
+    ora = np.array([list(pd[p].iters_by_k) for p in range(n)], dtype=np.int64)
+    ora_ll = np.array([list(pd[p].ll_by_k) for p in range(n)], dtype=np.float64)
+    assert int(dev[:, 1:].sum()) == t.em_iterations and int(ora[:, 1:].sum()) == dg.em_iterations
+    assert (dev[:, 0] == ora[:, 0]).all()                                       # the chosen K
+    assert (dev[:, 11] == ora[:, 11]).all()                                     # the refit
+    differ = [(p, k) for p in range(n) for k in range(1, 11) if dev[p, k] != ora[p, k]]
+    assert all(k > dev[p, 0] for p, k in differ), differ                        # only fits with surplus components
+    assert sum(int(dev[p, k] - ora[p, k]) for p, k in differ) == t.em_iterations - dg.em_iterations    # ... explain the whole difference
+    assert len({p for p, _ in differ}) <= n // 200                              # a handful of 9 000 problems
+    same = np.ones((n, 12), dtype=bool)
+    for p, k in differ:
+        same[p, k] = False
+    both = same & (dev_ll != 0) & (ora_ll != 0)
+    both[:, 0] = both[:, 11] = False
+    rel_same = (np.abs(dev_ll - ora_ll)[both] / np.abs(ora_ll[both])).max()
+    rel_diff = max((abs(dev_ll[p, k] - ora_ll[p, k]) / abs(ora_ll[p, k]) for p, k in differ if dev_ll[p, k] and ora_ll[p, k]), default=0.0)
+    print("fits whose iteration counts differ: %d in %d problems (device - restatement = %d iterations); log-likelihood at the end, largest "
+          "relative difference: %.2e over those fits, %.2e over all the others" % (len(differ), len({p for p, _ in differ}),
+                                                                                t.em_iterations - dg.em_iterations, rel_diff, rel_same))
+    assert rel_diff < 1e-2
     # the knife edges: all decisions are far from a last-ulp flip on this workload
     assert dg.nk_zero_first_iter == 0 and dg.all_k_failed == 0
     assert dg.min_prob_margin > 1e-9 and dg.min_tol_margin > 1e-9 and dg.min_bic_gap > 1e-9
