@@ -25,6 +25,7 @@
 
 #include "dsa_kernels.hpp"
 #include "dsa_long.hpp"
+#include "dsa_diag_host.hpp"
 
 using namespace dsa;
 
@@ -547,54 +548,7 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
         if (int rc = launch_compute(ctx, L, s)) return rc;
     }
 #ifdef DSA_PRUNE_STATS
-    {
-        // the generic replay's tasks by last row and sidedness
-        const size_t ng = (size_t)L.host->ctr.n_gtasks, nt = (size_t)L.host->ctr.n_tasks;
-        std::vector<uint2> gt(ng);
-        std::vector<ReplayTask> tk(nt);
-        if (ng) HIPC(hipMemcpy(gt.data(), L.d_gtasks.p, ng * sizeof(uint2), hipMemcpyDeviceToHost));
-        if (nt) HIPC(hipMemcpy(tk.data(), L.d_tasks.p, nt * sizeof(ReplayTask), hipMemcpyDeviceToHost));
-        long hist[3][10] = {};
-        for (size_t i = 0; i < ng; ++i) {
-            const ReplayTask& t = tk[gt[i].x & ~GTASK_OWNER];
-            const int kind = t.chunk0 != NO_CHUNK && t.chunk1 != NO_CHUNK ? 2 : t.chunk0 != NO_CHUNK ? 0 : 1;
-            hist[kind][std::min(9, (t.last_row & TASK_ROW) / 8)]++;
-        }
-        {
-            const size_t np_ = (size_t)s.g.n_pairs, nk = (size_t)L.host->ctr.n_kept, nm = (size_t)L.host->ctr.n_masks;
-            std::vector<PairState> stv(np_);
-            std::vector<KeptRow> kv(nk);
-            std::vector<uint64_t> mv(nm * 2);
-            HIPC(hipMemcpy(stv.data(), L.d_state.p, np_ * sizeof(PairState), hipMemcpyDeviceToHost));
-            if (nk) HIPC(hipMemcpy(kv.data(), L.d_kept.p, nk * sizeof(KeptRow), hipMemcpyDeviceToHost));
-            if (nm) HIPC(hipMemcpy(mv.data(), L.d_masks.p, nm * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            int shown = 0;
-            for (size_t i = 0; i < ng && shown < 8; ++i) {
-                const ReplayTask& t = tk[gt[i].x & ~GTASK_OWNER];
-                const int R = t.last_row & TASK_ROW;
-                if (t.chunk1 != NO_CHUNK || R < 24 || R > 56) continue;
-                const PairState& st = stv[t.pair];
-                fprintf(stderr, "[stats] task pair %u tile0 %d R %d: n_kept %d n_tasks %d tiles0 %x tiles1 %x first %d %d;", t.pair, t.chunk0, R, st.n_kept, st.n_tasks,
-                        st.tiles0, st.tiles1, st.first0, st.first1);
-                for (int k = 0; k < st.n_kept; ++k)
-                    fprintf(stderr, " [a %d m1 %d m2 %d mask0 %llx mask1 %llx]", kv[st.kept_begin + k].a, kv[st.kept_begin + k].m1, kv[st.kept_begin + k].m2,
-                            (unsigned long long)mv[((size_t)t.mask_begin + k) * 2], (unsigned long long)mv[((size_t)t.mask_begin + k) * 2 + 1]);
-                fprintf(stderr, "\n");
-                ++shown;
-            }
-        }
-        for (int k = 0; k < 3; ++k) {
-            fprintf(stderr, "[stats] generic tasks, %s, by last row / 8:", k == 0 ? "M1 side only" : k == 1 ? "M2 side only" : "both sides");
-            for (int b = 0; b < 10; ++b) fprintf(stderr, " %ld", hist[k][b]);
-            fprintf(stderr, "\n");
-        }
-    }
-    {
-        unsigned long long h[16];
-        HIPC(hipMemcpy(h, L.d_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[stats] row groups skipped %llu of %llu; wave cycles: total %llu, at tile barriers %llu, table build %llu, tail %llu (row max %llu, combine %llu, replay %llu); generic replay: %llu waves, setup %llu, sweep %llu cycles, %llu row groups (lane 0); row groups skipped between live parts %llu (dead groups followed at once by a live boundary %llu, of which through the diagonal %llu); slowest lane of the listed count: %llu cycles, %llu kept rows, %llu tasks\n",
-                h[0], h[1], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[12], h[10], h[11], h[13], h[14], h[2] & 0xFFFFFFFFull, h[2] >> 32, h[15] >> 24, (h[15] >> 8) & 0xFFFF, h[15] & 0xFF);
-    }
+    diag_dump_slice(L.d_stats.p, L.d_gtasks.p, (size_t)L.host->ctr.n_gtasks, L.d_tasks.p, (size_t)L.host->ctr.n_tasks);
 #endif
     L.last_gtasks = L.host->ctr.n_gtasks;
     ctx->timing.cells += (int64_t)L.host->plan.cells;

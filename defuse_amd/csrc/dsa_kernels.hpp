@@ -44,6 +44,7 @@
 #include <stdint.h>
 
 #include "../../include/defuse_dsa.h"
+#include "dsa_diag.hpp"
 
 namespace dsa {
 
@@ -1139,9 +1140,7 @@ __device__ __forceinline__ int sweep_tile_generic(const uint32_t (&r)[W], const 
         }
         cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
         bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
-#ifndef DSA_NO_PRUNE
-        if (4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
-#endif
+        if (DIAG_PRUNE && 4 * gq + 3 > l_in && __builtin_amdgcn_ballot_w64(alive) == 0) { ++gq; break; }   // wave-uniform; a live boundary at row l_in also enters row l_in + 1 (diagonal)
     }
     return gq;
 }
@@ -1293,6 +1292,172 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
     combine_wg<false>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, 0, false, &fl, fb, g);
 }
 
+// The sweep of one tile by one wave of the table kernels (TIER 0: 25-row tables, SPLIT: two 5-row tables per fusion): rows in
+// groups of four, per row one ascending pass over the tile's NW columns — four columns per table read, the diagonal term of the
+// next column formed from X[i] before X[i] is overwritten, the chain max3 -> max3 — the tile's row maximum and, unless the tile
+// is the wave's last (LAST: nothing reads it), its boundary column.  NW = 64; a 16-column instantiation for a last tile of which
+// no lane has more than 16 columns (windows of 389 = 6 x 64 + 5 bases) exists behind -DDSA_NARROW only: measured on one box
+// against the same build without it, the fill took 3.100 instead of 3.050 ms — the second copy of the loop costs more
+// (instruction cache, register allocation) than the quarter-width seventh pass saves.  Exact pruning as described at the
+// kernel.  Returns the row groups stored for the tile; last_bnd = last row whose outgoing boundary is alive (this lane).
+template <int NW, bool SPLIT, bool LAST>
+__device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, const uint4* __restrict__ rows4, const uint4* __restrict__ bi4,
+                                               uint4* __restrict__ cm4, uint4* __restrict__ bo4, bool first_tile, int lq_max, int lq_lane,
+                                               int slack, int l_in, int stop_prev, int& last_bnd, const Geom& g)
+{
+    static_assert(NW % 4 == 0 && NW / 4 > FILL_PF, "table reads in flight");
+    (void)g;
+    uint32_t X[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) X[i] = BIAS2 + drift2(i);
+    const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+    uint32_t bprev = BIAS2;
+    const int ngq = (lq_max >> 2) + 1;
+    uint4 rc_n = rows4[0];
+    uint4 b_n = first_tile ? bias4 : bi4[0];                // every tile stores at least its first row group
+    last_bnd = 0;
+    int gq = 0;
+    int n_gap_groups = 0;
+    for (; gq < ngq; ++gq) {
+        const uint4 rc = rc_n, b = b_n;
+        const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
+        rc_n = rows4[(int64_t)gn * WAVE];
+        b_n = gn < stop_prev ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
+        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
+        uint32_t alive_bits = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * gq + sidx;
+            const uint32_t bcur = bv[sidx];
+            if (j >= 1 && j <= lq_max) {                    // wave-uniform
+                if constexpr (SPLIT) {
+                    const uint32_t k1 = (rcv[sidx] >> 16) & 0xFu, k2 = (rcv[sidx] >> 20) & 0xFu;
+                    uint4 v = split_terms(tb, k1, k2, 0);
+                    uint32_t a = bprev + v.x;
+                    uint32_t up = bcur - TWO2;
+#pragma unroll
+                    for (int q = 0; q < NW / 4; ++q) {
+                        uint4 vn = v;                         // one pair of table reads in flight
+                        if (q + 1 < NW / 4) vn = split_terms(tb, k1, k2, q + 1);
+                        uint32_t an;
+                        an = X[4 * q + 0] + v.y;
+                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                        a = an;
+                        an = X[4 * q + 1] + v.z;
+                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                        a = an;
+                        an = X[4 * q + 2] + v.w;
+                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                        a = an;
+                        an = X[4 * q + 3] + vn.x;
+                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                        a = an;
+                        up = X[4 * q + 3];
+                        v = vn;
+                    }
+                } else {
+                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
+                    uint4 vq[FILL_PF + 1];                  // table reads in flight
+#pragma unroll
+                    for (int k = 0; k <= FILL_PF; ++k) vq[k] = trow[k];
+                    uint32_t a = bprev + vq[0].x;
+                    uint32_t up = bcur - TWO2;
+#pragma unroll
+                    for (int q = 0; q < NW / 4; ++q) {
+                        const uint4 v = vq[0];
+#pragma unroll
+                        for (int k = 0; k < FILL_PF; ++k) vq[k] = vq[k + 1];
+                        if (q + 1 + FILL_PF < NW / 4) vq[FILL_PF] = trow[q + 1 + FILL_PF];
+                        const uint4 vn = vq[0];
+                        uint32_t an;
+                        an = X[4 * q + 0] + v.y;
+                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
+                        a = an;
+                        an = X[4 * q + 1] + v.z;
+                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
+                        a = an;
+                        an = X[4 * q + 2] + v.w;
+                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
+                        a = an;
+                        an = X[4 * q + 3] + vn.x;
+                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
+                        a = an;
+                        up = X[4 * q + 3];
+                    }
+                }
+                {   // the tile's row maximum: one max3 per two columns, two interleaved accumulators (padded columns have
+                    // substitution term 0 and never exceed the valid ones: no masking)
+                    uint32_t acc0 = BIAS2, acc1 = BIAS2;
+#pragma unroll
+                    for (int i = 0; i < NW; i += 4) {
+                        acc0 = max3(acc0, X[i] - drift2(i), X[i + 1] - drift2(i + 1));
+                        acc1 = max3(acc1, X[i + 2] - drift2(i + 2), X[i + 3] - drift2(i + 3));
+                    }
+                    cmv[sidx] = max2(acc0, acc1);
+                }
+                // alive: a field >= thr = 4j - slack (biased).  Both fields at once: x >= thr <=> max(x, thr-1) != thr-1;
+                // rows past the lane's read compare against 0xFFFF, which nothing exceeds.
+                const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
+                const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
+                alive_bits |= pk_max_u16(cmv[sidx], tm2) ^ tm2;
+                if (!LAST) {
+                    bov[sidx] = X[NW - 1] - drift2(NW - 1);
+                    if ((pk_max_u16(bov[sidx], tm2) ^ tm2) != 0u) last_bnd = j;
+                }
+            }
+            bprev = bcur;
+        }
+        const bool alive = alive_bits != 0u;
+        cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
+        if (!LAST) bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
+        if (DIAG_PRUNE && __builtin_amdgcn_ballot_w64(alive) == 0) {      // wave-uniform
+            if (4 * gq + 3 > l_in) { ++gq; break; }             // a live boundary at row l_in also enters row l_in + 1 (diagonal)
+            if (DIAG_GAP_SKIP) {
+                // Nothing in these four rows is alive, so rows further down can only come alive through the boundary
+                // column (a live cell's best predecessor is alive: within the tile that chain would cross these rows).
+                // Until a row group has a live incoming boundary value the sweep is skipped: those groups are all dead
+                // and store V = 0, the lower bound every reader substitutes for dead cells anyway.
+                int g2 = gq + 1;
+                bool resume = false;
+                uint4 bb = b_n;                                     // group gq + 1, already on its way
+                uint32_t in_prev = bv[3];                           // the boundary value of the row above the group: it enters by the diagonal
+                for (; g2 < ngq; ++g2) {
+                    if (g2 > gq + 1) bb = g2 < stop_prev ? bi4[(int64_t)g2 * WAVE] : bias4;
+                    const uint32_t bbv[5] = {in_prev, bb.x, bb.y, bb.z, bb.w};
+                    uint32_t in_bits = 0;
+#pragma unroll
+                    for (int sidx = 0; sidx < 5; ++sidx) {
+                        const int j = 4 * g2 + sidx - 1;
+                        const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
+                        const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
+                        in_bits |= pk_max_u16(bbv[sidx], tm2) ^ tm2;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(in_bits != 0u) != 0) { resume = true; break; }
+                    cm4[(int64_t)g2 * WAVE] = bias4;
+                    if (!LAST) bo4[(int64_t)g2 * WAVE] = bias4;
+                    in_prev = bb.w;
+                    if (4 * g2 + 3 > l_in) { ++g2; break; }
+                }
+                n_gap_groups += g2 - (gq + 1);
+                if (!resume) { gq = g2; break; }                    // g2 groups are stored
+#pragma unroll
+                for (int i = 0; i < NW; ++i) X[i] = BIAS2 + drift2(i);
+                bprev = in_prev;
+                b_n = bb;
+                rc_n = rows4[(int64_t)g2 * WAVE];
+                gq = g2 - 1;
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        DSA_STAT_ADD(g, DS_GAP_GROUPS, n_gap_groups);
+        DSA_STAT_ADD(g, DS_GROUPS_SKIPPED, ngq - gq);
+        DSA_STAT_ADD(g, DS_GROUPS, ngq);
+    }
+    return gq;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1f: fast DP fill (reads over {A,C,G,T,N}).  Per workgroup and tile, the substitution terms of
 // every fusion present are tabulated in LDS:
@@ -1352,12 +1517,13 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     // 4), and no live cell's value comes from a dead cell.  Once a whole tile row and everything that
     // can still enter from the left are dead, the rest of the tile is dead: the sweep stops there and
     // stores "V = 0" for the remaining rows (a lower bound, which is all dead cells need to be).
-    int lq_lane = 0, slack = 0, tiles_lane = 0;
+    int lq_lane = 0, slack = 0, tiles_lane = 0, tail_cols_lane = 0;
     if (in_batch) {
         const dsa_fusion fu = fusions[f];
         lq_lane = pr.read_len;
         slack = 2 * lq_lane - max(min_score_tab[lq_lane], pair_bound(pr));
         tiles_lane = max(cdiv_dev(fu.ref0_len, W), cdiv_dev(fu.ref1_len, W));
+        tail_cols_lane = max(fu.ref0_len, fu.ref1_len) - (tiles_lane - 1) * W;       // columns of the longer window in its last tile
     }
     auto wave_max = [](int v) {
 #pragma unroll
@@ -1391,194 +1557,34 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     int stop_prev = 0;                   // stored row groups of the tile to the left
     TileStops stops = {};
 
-#ifdef DSA_PRUNE_STATS
-    const unsigned long long t_begin = __builtin_readcyclecounter();
+    // columns the lane has in the wave's last tile (wave-uniform maximum): 16 or fewer in every lane -> the narrow sweep
+    const int tail_cols = wave_max(in_batch && tiles_lane == wi.nch_max ? tail_cols_lane : 0);
+    DiagClock clk_all, clk;
     unsigned long long t_bar = 0, t_tab = 0;
-#define STAT_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#else
-#define STAT_T(x)
-#endif
     for (int c = 0; c < nch_wg; ++c) {
-        STAT_T(ts0);
+        clk.lap();
         __syncthreads();                          // previous tile's tables no longer in use
-        STAT_T(ts1);
+        t_bar += clk.lap();
         build_tables<SPLIT>(T, wgi.n_groups, [&](int gi, int i, uint32_t& q0, uint32_t& q1) {
             const uint32_t code = refcodes[(int64_t)group_fusion(wgi, gi) * g.lrp + c * W + i];
             q0 = code & 0xFFFFu;
             q1 = code >> 16;
         });
-        STAT_T(ts2);
+        t_tab += clk.lap();
         __syncthreads();
-#ifdef DSA_PRUNE_STATS
-        t_bar += (ts1 - ts0) + (__builtin_readcyclecounter() - ts2);
-        t_tab += ts2 - ts1;
-#endif
+        t_bar += clk.lap();
         if (!live || c >= wi.nch_max) continue;   // wave-uniform
 
         uint4* cm4 = reinterpret_cast<uint4*>(cmax + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
         uint4* bo4 = reinterpret_cast<uint4*>(bnd + ((int64_t)w * g.nch + c) * g.lq1 * WAVE) + lane;
         const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
-        uint32_t X[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-        const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
-        uint32_t bprev = BIAS2;
-        const int ngq = (wi.lq_max >> 2) + 1;
-        uint4 rc_n = rows4[0];
-        uint4 b_n = (c == 0) ? bias4 : bi4[0];              // every tile stores at least its first row group
-        int last_bnd = 0;                                   // last row whose outgoing boundary is alive (this lane)
-        int gq = 0;
-#ifdef DSA_PRUNE_STATS
-        int n_dead_groups = 0, n_immediate = 0, n_immediate_diag = 0;
-#endif
-        for (; gq < ngq; ++gq) {
-            const uint4 rc = rc_n, b = b_n;
-            const int gn = gq + 1 < ngq ? gq + 1 : gq;      // prefetch the next four rows' operands
-            rc_n = rows4[(int64_t)gn * WAVE];
-            b_n = gn < stop_prev ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
-            const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
-            uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
-            uint32_t alive_bits = 0;
-#pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                const int j = 4 * gq + sidx;
-                const uint32_t bcur = bv[sidx];
-                if (j >= 1 && j <= wi.lq_max) {             // wave-uniform
-                    // one ascending pass, four columns per ds_read_b128; the diagonal term of the next
-                    // column is formed from X[i] before X[i] is overwritten; the chain is max3 -> max3
-                    if constexpr (SPLIT) {
-                        const uint32_t k1 = (rcv[sidx] >> 16) & 0xFu, k2 = (rcv[sidx] >> 20) & 0xFu;
-                        uint4 v = split_terms(tb, k1, k2, 0);
-                        uint32_t a = bprev + v.x;
-                        uint32_t up = bcur - TWO2;
-#pragma unroll
-                        for (int q = 0; q < W / 4; ++q) {
-                            uint4 vn = v;                         // one pair of table reads in flight
-                            if (q + 1 < W / 4) vn = split_terms(tb, k1, k2, q + 1);
-                            uint32_t an;
-                            an = X[4 * q + 0] + v.y;
-                            X[4 * q + 0] = max3(a, X[4 * q + 0], up);
-                            a = an;
-                            an = X[4 * q + 1] + v.z;
-                            X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
-                            a = an;
-                            an = X[4 * q + 2] + v.w;
-                            X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
-                            a = an;
-                            an = X[4 * q + 3] + vn.x;
-                            X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
-                            a = an;
-                            up = X[4 * q + 3];
-                            v = vn;
-                        }
-                    } else {
-                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
-                    uint4 vq[FILL_PF + 1];                  // table reads in flight
-#ifdef DSA_ABLATE_LDS
-#define TROW_LD(k) make_uint4(rcv[sidx] + (k), 0x00060006u, 0x00030003u, 0x00060006u)
-#else
-#define TROW_LD(k) trow[k]
-#endif
-#pragma unroll
-                    for (int k = 0; k <= FILL_PF; ++k) vq[k] = TROW_LD(k);
-                    uint32_t a = bprev + vq[0].x;
-                    uint32_t up = bcur - TWO2;
-#pragma unroll
-                    for (int q = 0; q < W / 4; ++q) {
-                        const uint4 v = vq[0];
-#pragma unroll
-                        for (int k = 0; k < FILL_PF; ++k) vq[k] = vq[k + 1];
-                        if (q + 1 + FILL_PF < W / 4) vq[FILL_PF] = TROW_LD(q + 1 + FILL_PF);
-                        const uint4 vn = vq[0];
-                        uint32_t an;
-                        an = X[4 * q + 0] + v.y;
-                        X[4 * q + 0] = max3(a, X[4 * q + 0], up);
-                        a = an;
-                        an = X[4 * q + 1] + v.z;
-                        X[4 * q + 1] = max3(a, X[4 * q + 1], X[4 * q + 0]);
-                        a = an;
-                        an = X[4 * q + 2] + v.w;
-                        X[4 * q + 2] = max3(a, X[4 * q + 2], X[4 * q + 1]);
-                        a = an;
-                        an = X[4 * q + 3] + vn.x;
-                        X[4 * q + 3] = max3(a, X[4 * q + 3], X[4 * q + 2]);
-                        a = an;
-                        up = X[4 * q + 3];
-                    }
-                    }
-                    cmv[sidx] = tile_row_max<false>(X, W, W);
-                    bov[sidx] = X[W - 1] - drift2(W - 1);
-                    // alive: a field >= thr = 4j - slack (biased).  Both fields at once: x >= thr <=> max(x, thr-1) != thr-1;
-                    // rows past the lane's read compare against 0xFFFF, which nothing exceeds.
-                    const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
-                    const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
-                    alive_bits |= pk_max_u16(cmv[sidx], tm2) ^ tm2;
-                    if ((pk_max_u16(bov[sidx], tm2) ^ tm2) != 0u) last_bnd = j;
-                }
-                bprev = bcur;
-            }
-            const bool alive = alive_bits != 0u;
-#ifdef DSA_ABLATE_STORES
-            if (gq == ngq - 1) {
-#endif
-            cm4[(int64_t)gq * WAVE] = make_uint4(cmv[0], cmv[1], cmv[2], cmv[3]);
-            bo4[(int64_t)gq * WAVE] = make_uint4(bov[0], bov[1], bov[2], bov[3]);
-#ifdef DSA_ABLATE_STORES
-            }
-#endif
-#ifndef DSA_NO_PRUNE
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) {          // wave-uniform
-                if (4 * gq + 3 > l_in) { ++gq; break; }             // a live boundary at row l_in also enters row l_in + 1 (diagonal)
-#ifndef DSA_NO_GAP_SKIP
-                // Nothing in these four rows is alive, so rows further down can only come alive through the boundary
-                // column (a live cell's best predecessor is alive: within the tile that chain would cross these rows).
-                // Until a row group has a live incoming boundary value the sweep is skipped: those groups are all dead
-                // and store V = 0, the lower bound every reader substitutes for dead cells anyway.
-                int g2 = gq + 1;
-                bool resume = false;
-                uint4 bb = b_n;                                     // group gq + 1, already on its way
-                uint32_t in_prev = bv[3];                           // the boundary value of the row above the group: it enters by the diagonal
-                for (; g2 < ngq; ++g2) {
-                    if (g2 > gq + 1) bb = g2 < stop_prev ? bi4[(int64_t)g2 * WAVE] : bias4;
-                    const uint32_t bbv[5] = {in_prev, bb.x, bb.y, bb.z, bb.w};
-                    uint32_t in_bits = 0;
-#pragma unroll
-                    for (int sidx = 0; sidx < 5; ++sidx) {
-                        const int j = 4 * g2 + sidx - 1;
-                        const int t1 = max(4 * j - slack + (int)BIAS16 - 1, 0);
-                        const uint32_t tm2 = j <= lq_lane ? (uint32_t)t1 * 0x00010001u : 0xFFFFFFFFu;
-                        in_bits |= pk_max_u16(bbv[sidx], tm2) ^ tm2;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(in_bits != 0u) != 0) { resume = true; break; }
-                    cm4[(int64_t)g2 * WAVE] = bias4;
-                    bo4[(int64_t)g2 * WAVE] = bias4;
-                    in_prev = bb.w;
-                    if (4 * g2 + 3 > l_in) { ++g2; break; }
-                }
-#ifdef DSA_PRUNE_STATS
-                n_dead_groups += g2 - (gq + 1);
-                if (resume && g2 == gq + 1) ++n_immediate;
-                if (resume && g2 == gq + 1 && __builtin_amdgcn_ballot_w64((pk_max_u16(in_prev, (uint32_t)max(4 * (4 * g2 - 1) - slack + (int)BIAS16 - 1, 0) * 0x00010001u) ^ ((uint32_t)max(4 * (4 * g2 - 1) - slack + (int)BIAS16 - 1, 0) * 0x00010001u)) != 0u) != 0) ++n_immediate_diag;
-#endif
-                if (!resume) { gq = g2; break; }                    // g2 groups are stored
-#pragma unroll
-                for (int i = 0; i < W; ++i) X[i] = BIAS2 + drift2(i);
-                bprev = in_prev;
-                b_n = bb;
-                rc_n = rows4[(int64_t)g2 * WAVE];
-                gq = g2 - 1;
-#endif
-            }
-#endif
-        }
-#ifdef DSA_PRUNE_STATS
-        if (lane == 0) {
-            atomicAdd(&g.stats[14], (unsigned long long)n_dead_groups);
-            atomicAdd(&g.stats[2], (unsigned long long)n_immediate | ((unsigned long long)n_immediate_diag << 32));
-            atomicAdd(&g.stats[0], (unsigned long long)(ngq - gq));
-            atomicAdd(&g.stats[1], (unsigned long long)ngq);
-        }
-#endif
+        int last_bnd = 0, gq;
+        if (c + 1 < wi.nch_max)
+            gq = sweep_tile_fast<W, SPLIT, false>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
+        else if (!DIAG_NARROW || tail_cols > 16)
+            gq = sweep_tile_fast<W, SPLIT, true>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
+        else       // (-DDSA_NARROW builds only, see dsa_diag.hpp)
+            gq = sweep_tile_fast<16, SPLIT, true>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
         // the dead remainder of the tile is not stored: its readers substitute V = 0 past the stop
         if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = gq;
         stop_prev = gq;
@@ -1587,35 +1593,31 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
             if (k == c) stops.v[k] = gq;
         l_in = wave_max(last_bnd);
     }
-    STAT_T(t_tail);
-#ifndef DSA_ABLATE_TAIL
-    if (live) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
+    clk.lap();
+    unsigned long long t_rowmax = 0, t_combine = 0, t_replay = 0;
+    if (DIAG_TAIL) {
+        if (live) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
+            reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
+        }
+        t_rowmax = clk.lap();
+        // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
+        // workgroups' sweeps, instead of in kernels of its own.
+        combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, my_group, true, &fl, fb, g);
+        t_combine = clk.lap();
+        if (DIAG_REPLAY) replay_fast_wg<SPLIT>(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
+        t_replay = clk.lap();
     }
-    STAT_T(t_comb);
-    // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident
-    // workgroups' sweeps, instead of in kernels of its own.
-    combine_wg<true>(pairs, fusions, cmax, rmax, tmask, min_score_tab, wgi, my_group, true, &fl, fb, g);
-    STAT_T(t_rep);
-#ifndef DSA_ABLATE_REPLAY
-    replay_fast_wg<SPLIT>(T, &fl, wgi, fb, refcodes, rowcodes, bnd, g);
-#endif
-#endif
-#ifdef DSA_PRUNE_STATS
     if (lane == 0 && live) {
-        const unsigned long long t_end = __builtin_readcyclecounter();
-        atomicAdd(&g.stats[3], t_end - t_begin);
-        atomicAdd(&g.stats[4], t_bar);
-        atomicAdd(&g.stats[5], t_tab);
-        atomicAdd(&g.stats[6], t_end - t_tail);
-#ifndef DSA_ABLATE_TAIL
-        atomicAdd(&g.stats[7], t_comb - t_tail);
-        atomicAdd(&g.stats[8], t_rep - t_comb);
-        atomicAdd(&g.stats[9], t_end - t_rep);
-#endif
+        DSA_STAT_ADD(g, DS_WAVE_CYCLES, clk_all.lap());
+        DSA_STAT_ADD(g, DS_BARRIER, t_bar);
+        DSA_STAT_ADD(g, DS_TABLES, t_tab);
+        DSA_STAT_ADD(g, DS_TAIL, t_rowmax + t_combine + t_replay);
+        DSA_STAT_ADD(g, DS_ROWMAX, t_rowmax);
+        DSA_STAT_ADD(g, DS_COMBINE, t_combine);
+        DSA_STAT_ADD(g, DS_REPLAY, t_replay);
     }
-#endif
+    (void)t_bar; (void)t_tab; (void)t_rowmax; (void)t_combine; (void)t_replay;
 }
 
 // K3g: replay the tile pairs the table-driven replay left over, from the stored boundaries (generic scoring, any pair
@@ -1721,9 +1723,7 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 5) void k_replay(const ReplayTask* __
         if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
         ReplayTask rt = s_task[valid ? src : s_order[0]];
         if (!valid) { rt.last_row = 0; rt.chunk0 = rt.chunk1 = NO_CHUNK; }
-#ifdef DSA_PRUNE_STATS
-        const unsigned long long tr0 = __builtin_readcyclecounter();
-#endif
+        DiagClock clk;
         const int64_t p = rt.pair;
         const int64_t w = p >> 6;
         const int lane = (int)(p & 63);
@@ -1783,9 +1783,7 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 5) void k_replay(const ReplayTask* __
         uint32_t b_n = q == 0 ? boundary(1) : BIAS2, b_nn = q == 0 ? boundary(2) : BIAS2;
         uint32_t bprev = BIAS2;                            // V(left neighbour column, row 0) = 0
         uint32_t xlast = BIAS2;                            // this lane's last column after its latest row, drift removed (row 0: V = 0)
-#ifdef DSA_PRUNE_STATS
-        const unsigned long long tr1 = __builtin_readcyclecounter();
-#endif
+        const unsigned long long t_setup = clk.lap();
         for (int t = 1; t <= Rw + RQ - 1; ++t) {           // uniform
             const int j = t - q;
             const uint32_t cj = rc_n;
@@ -1820,15 +1818,13 @@ __global__ __launch_bounds__(REPLAY_BLOCK, 5) void k_replay(const ReplayTask* __
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2] = 0;
         if (valid && q == 0 && !has1)
             for (int k = 0; k < st.n_kept; ++k) masks[((uint64_t)rt.mask_begin + k) * 2 + 1] = 0;
-#ifdef DSA_PRUNE_STATS
         if ((threadIdx.x & 63) == 0) {
-            const unsigned long long tr2 = __builtin_readcyclecounter();
-            atomicAdd(&g.stats[10], tr1 - tr0);
-            atomicAdd(&g.stats[11], tr2 - tr1);
-            atomicAdd(&g.stats[12], 1ull);
-            atomicAdd(&g.stats[13], (unsigned long long)(Rw + RQ - 1));
+            DSA_STAT_ADD(g, DS_GREPLAY_SETUP, t_setup);
+            DSA_STAT_ADD(g, DS_GREPLAY_SWEEP, clk.lap());
+            DSA_STAT_ADD(g, DS_GREPLAY_WAVES, 1);
+            DSA_STAT_ADD(g, DS_GREPLAY_STEPS, Rw + RQ - 1);
         }
-#endif
+        (void)t_setup;
     }
 }
 
@@ -2142,9 +2138,6 @@ template <int SLOTS>
 __device__ __forceinline__ bool emit_is_heavy(const PairState& st)
 {
     const int slots = (int)st.n_kept * (int)st.n_tasks;
-#ifdef DSA_NO_HEAVY
-    return false;
-#endif
     if (st.n_tasks == 1 && st.n_kept <= EMIT_REG_ROWS) return false;
     return (st.flags & STATE_TILES) != 0 && slots > SLOTS && slots <= 64 * SLOTS;
 }
@@ -2226,19 +2219,13 @@ __global__ __launch_bounds__(EMIT_BLOCK) void k_emit_listed(const uint2* __restr
         if (mine) st = state[p];
         const int64_t o = mine ? (g.orig ? g.orig[p] : p) : 0;
         const bool heavy = mine && emit_is_heavy<EMIT_SLOTS_LISTED>(st);
-#ifdef DSA_PRUNE_STATS
-        const unsigned long long te0 = __builtin_readcyclecounter();
-#endif
+        DiagClock clk;
         int64_t n = 0;
         if (mine && !heavy) n = emit_pair<WRITE, EMIT_SLOTS_LISTED>(&lds, p, o, st, pairs, fusions, kept, tasks, masks, rec_offset, out, out_cap, pair_base);
         const int64_t nh = emit_heavy_of_wave<WRITE, EMIT_SLOTS_LISTED>(&lds, heavy, p, o, st, pairs, fusions, kept, masks, rec_offset, out, out_cap, pair_base);
         if (!WRITE && mine) rec_count[o] = heavy ? nh : n;
-#ifdef DSA_PRUNE_STATS
-        if (!WRITE && mine) {      // slowest lane: cycles << 24 | n_kept << 8 | n_tasks
-            const unsigned long long dt = __builtin_readcyclecounter() - te0;
-            atomicMax(&g.stats[15], (dt << 24) | ((unsigned long long)st.n_kept << 8) | st.n_tasks);
-        }
-#endif
+        if (!WRITE && mine)        // slowest lane: cycles << 24 | n_kept << 8 | n_tasks
+            DSA_STAT_MAX(g, DS_SLOWEST_LISTED, (clk.lap() << 24) | ((unsigned long long)st.n_kept << 8) | st.n_tasks);
     }
 }
 

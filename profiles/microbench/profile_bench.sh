@@ -1,5 +1,5 @@
 # One call on the GPU box: rocprofv3 kernel stats + HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) + SQ counters
-# (two passes) of `python3 bench.py` (BASELINE configs[1], N = 1), summarised into gpurun_out/profile_bench/:
+# (two passes) of `python3 bench.py` (BASELINE configs[1], N = 1), summarised into gpurun_out/profile_bench/ (copy them to profiles/rNN/):
 #   bench_kernel_stats.csv, pmc_traffic.json, pmc_sq.json        (copy them to profiles/rNN/)
 # Every JSON carries the workload and the SOURCE HASH of the library that ran (dsa_version()); bench.py reports the counters
 # only while that hash equals the loaded library's.
@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profile_bench
 mkdir -p $O
-B="python3 $R/bench.py --no-cpu-baseline --warmup 1"
+B="python3 $R/bench.py --profile-run --warmup 1"
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- $B --steps 20 > $O/kt.log 2>&1 || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- $B --steps 3 > $O/pmc_$c.log 2>&1 || exit 1
