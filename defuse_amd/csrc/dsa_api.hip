@@ -548,6 +548,7 @@ int phase2(dsa_ctx* ctx, PipeLane& L)
         if (int rc = launch_compute(ctx, L, s)) return rc;
     }
 #ifdef DSA_PRUNE_STATS
+    diag_dump_plan();
     diag_dump_slice(L.d_stats.p, L.d_gtasks.p, (size_t)L.host->ctr.n_gtasks, L.d_tasks.p, (size_t)L.host->ctr.n_tasks);
 #endif
     L.last_gtasks = L.host->ctr.n_gtasks;

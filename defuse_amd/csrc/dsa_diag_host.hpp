@@ -40,5 +40,19 @@ inline void diag_dump_slice(const unsigned long long* d_stats, const uint2* d_gt
             (h[DS_SLOWEST_LISTED] >> 8) & 0xFFFF, h[DS_SLOWEST_LISTED] & 0xFF);
 }
 
+inline void diag_dump_plan()
+{
+    unsigned long long h[8] = {}, zero[8] = {};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_plan_phase), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_plan_phase), zero, sizeof zero);
+    double tot = 0;
+    for (int k = 0; k < 6; ++k) tot += (double)h[k];
+    if (tot == 0) return;
+    const char* names[6] = {"prologue + first read", "windows packed", "11-mers hashed", "diagonals + vote", "bounds + keys", "ranks"};
+    fprintf(stderr, "[stats] k_plan_fusion wave cycles %.4g:", tot);
+    for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f %%", names[k], 100.0 * h[k] / tot);
+    fprintf(stderr, "\n");
+}
+
 }  // namespace dsa
 #endif

@@ -208,6 +208,12 @@ __host__ __device__ inline size_t plan_lds_bytes(int wc, int slots)
     return sizeof(uint32_t) * ((size_t)2 * wc + 2 * (size_t)(wc / 2 + 2) + 3 * (size_t)slots + 2 * PLAN_THREADS);
 }
 
+#ifdef DSA_PRUNE_STATS
+__device__ unsigned long long g_plan_phase[8];       // wave cycles of k_plan_fusion by phase (diagnostic builds, dsa_diag.hpp)
+#define PLAN_STAMP(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_plan_phase[k], pclk.lap()); } while (0)
+#else
+#define PLAN_STAMP(k) ((void)0)
+#endif
 __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __restrict__ ref_bytes, const dsa_fusion* __restrict__ fusions,
                                                                const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
                                                                PlanRun* __restrict__ runs, uint32_t* __restrict__ fkey, int32_t* __restrict__ fidx,
@@ -215,6 +221,8 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
                                                                PlanGlobals* __restrict__ glob, PlanParams prm)
 {
     extern __shared__ uint32_t plan_lds[];
+    DiagClock pclk;
+    (void)pclk;
     const int f = blockIdx.x, tid = threadIdx.x;
     const int wc = prm.wc, vc = wc / 2 + 2, slots = prm.slots;
     uint32_t* codes0 = plan_lds;
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         rb_first = load_read(pr_first);
     }
 
+    PLAN_STAMP(0);
     // ---- the two windows, 2-bit packed with PLAN_PAD invalid bases on either side, and their 11-mers hashed
     for (int k = tid; k < 2 * slots; k += PLAN_THREADS) table0[k] = 0xFFFFFFFFu;
     for (int k = tid; k < slots; k += PLAN_THREADS) s_votes[k] = 0;
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         }
     }
     __syncthreads();
+    PLAN_STAMP(1);
     auto window_kmer = [&](const uint32_t* codes, const uint32_t* valid, int x, bool& ok) -> uint32_t {
         const int s = x + PLAN_PAD;
         const uint64_t c = (((uint64_t)codes[(s >> 4) + 1] << 32) | codes[s >> 4]) >> (2 * (s & 15));
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     }
     __syncthreads();
 
+    PLAN_STAMP(2);
     // ---- per read: the diagonals of its first 11-mers in window 0 (d1) and of its last ones in window 1 (d2)
     struct Diag { int d1, d2; bool have1, have2; };
     auto diagonals = [&](const ReadBits& rb) -> Diag {
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         __syncthreads();
     }
     const int delta = s_delta, delta_votes = s_delta_votes;
+    PLAN_STAMP(3);
 
     // ---- per read: bound T', tile votes, sort key
     unsigned long long cells = 0;
@@ -501,6 +513,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     }
     atomicAdd(&s_cells, cells);
     __syncthreads();
+    PLAN_STAMP(4);
 
     // ---- rank of every read inside the fusion: ascending (diagonal key, index) — the keys are distinct
     if (n <= 2 * PLAN_THREADS) {
@@ -528,6 +541,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         for (int r = tid; r < n; r += PLAN_THREADS) rank[p0 + (keys_big[r] & 0xFFFFu)] = r;
     }
 
+    PLAN_STAMP(5);
     if (tid == 0) {
         int t[2];
         for (int h = 0; h < 2; ++h) {
