@@ -1070,17 +1070,20 @@ struct ReadStorePair {
 };
 
 // FASTQ: tools/ReadStream.cpp:18-32 (extension check), :57-104 (record parsing), AddReads SplitAlignment.cpp:253-264
-inline bool AddReads(const std::string& filename, ReadStore& reads)
+// err receives what the reference prints on stderr; a condition on which the reference's process ends (an uncaught
+// bad_lexical_cast, ...) is returned in *fatal instead of ending the process here, so that a caller that reads the FASTQ files
+// beside other work can report things in the reference's order.
+inline bool AddReads(const std::string& filename, ReadStore& reads, std::ostream& err, std::string* fatal)
 {
     const size_t dot = filename.find_last_of('.');
     const std::string ext = filename.substr(dot + 1);
     if (ext != "fastq" && ext != "fq") {
-        std::cerr << "Error: unrecognized extension " << ext << std::endl;
+        err << "Error: unrecognized extension " << ext << std::endl;
         return false;
     }
     FILE* in = fopen(filename.c_str(), "rb");
     if (!in) {
-        std::cerr << "Error: unable to open file " << filename << std::endl;
+        err << "Error: unable to open file " << filename << std::endl;
         return false;
     }
     LineReader reader(in);
@@ -1093,17 +1096,17 @@ inline bool AddReads(const std::string& filename, ReadStore& reads)
         if (!reader.next(l, n)) break;
         sequence.assign(l, n);
         if (!reader.next(l, n) || !reader.next(l, n)) break;
-        if (name.empty() || name[0] != '@') { std::cerr << "Error: Unable to interpret read name " << name << std::endl; break; }
+        if (name.empty() || name[0] != '@') { err << "Error: Unable to interpret read name " << name << std::endl; break; }
         const size_t slash = name.find_first_of('/');
         const char endc = (slash != std::string::npos && slash + 1 < name.size()) ? name[slash + 1] : '\0';
-        if (endc != '1' && endc != '2') { std::cerr << "Error: Unable to interpret read end " << name << std::endl; break; }
+        if (endc != '1' && endc != '2') { err << "Error: Unable to interpret read end " << name << std::endl; break; }
         int frag;
-        if (!field_int(name.data() + 1, slash - 1, frag)) die("Error: bad integer '" + name.substr(1, slash - 1) + "' in read name " + name);
-        if (sequence.size() >= ((size_t)1 << 24)) die("Error: read longer than 16 M bases: " + name);
+        if (!field_int(name.data() + 1, slash - 1, frag)) { *fatal = "Error: bad integer '" + name.substr(1, slash - 1) + "' in read name " + name; break; }
+        if (sequence.size() >= ((size_t)1 << 24)) { *fatal = "Error: read longer than 16 M bases: " + name; break; }
         reads.put(frag, endc == '1' ? 0 : 1, sequence.data(), sequence.size());
     }
     fclose(in);
-    return true;
+    return fatal->empty();
 }
 
 // One SAM line (tools/AlignmentStream.cpp:39-130).  Returns 0 = a record, 1 = nothing to return (header line, rname "*"),

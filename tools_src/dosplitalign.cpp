@@ -173,6 +173,19 @@ int main(int argc, char* argv[])
     }
     const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
     stage("regions");
+    // The two FASTQ files are read on threads of their own while the main thread sets the tasks up (FASTA index — built and
+    // written when it is missing —, exon table, windows): independent inputs.  Whatever the reads' side has to say is held back
+    // until the tasks are done, so that messages and exits come in the reference's order (tasks first, tools/dosplitalign.cpp:
+    // 90-100).  A lookup asks the second file's store first, so a read id that both files hold resolves to the later one as
+    // `reads[id] = sequence` does (tools/SplitAlignment.cpp:253-264).
+    ReadStorePair reads;
+    bool reads_ok[2] = {false, false};
+    std::ostringstream reads_err[2];
+    std::string reads_fatal[2];
+    const std::string read_names[2] = {cmd.str("seq1"), cmd.str("seq2")};
+    std::thread read_threads[2];
+    for (int t = 0; t < 2; ++t)
+        read_threads[t] = std::thread([&, t] { reads_ok[t] = AddReads(read_names[t], reads.file[t], reads_err[t], &reads_fatal[t]); });
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
                                                          cmd.integer("minread"), cmd.integer("maxread"), regions);
 
@@ -187,20 +200,18 @@ int main(int argc, char* argv[])
             for (const Location& loc : kv.second.mMateRegions[ce]) binned.Add(pack_id((int)task_of.size(), ce), loc);
         task_of.push_back(&kv.second);
     }
-
     stage("fasta index + exons + windows");
-    // the two FASTQ files are read side by side into stores of their own; a lookup asks the second file's first, so a read
-    // id that both files hold resolves to the later one as `reads[id] = sequence` does (tools/SplitAlignment.cpp:253-264)
-    ReadStorePair reads;
-    {
-        bool ok[2] = {false, false};
-        const std::string names[2] = {cmd.str("seq1"), cmd.str("seq2")};
-        run_threads(2, [&](unsigned t) { ok[t] = AddReads(names[t], reads.file[t]); });
-        if (!ok[0] || !ok[1]) {
-            std::cout << "Error: unable to read sequences" << std::endl;
-            std::cout.flush();
-            _exit(1);                             // (no helper thread exists yet; nothing to unwind that the system does not)
-        }
+    for (int t = 0; t < 2; ++t) {
+        read_threads[t].join();
+        std::cerr << reads_err[t].str();
+    }
+    for (int t = 0; t < 2; ++t)
+        if (!reads_fatal[t].empty()) die(reads_fatal[t]);
+    if (!reads_ok[0] || !reads_ok[1]) {
+        std::cout << "Error: unable to read sequences" << std::endl;
+        std::cout.flush();
+        std::cerr.flush();
+        _exit(1);                             // (no helper thread exists any more; nothing to unwind that the system does not)
     }
 
     stage("reads");
