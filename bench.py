@@ -466,6 +466,8 @@ def main():
                          "kernel": "k_fill_fast", "kernel_ms": launch_ms, "launches_per_step": n_launch,
                          "algorithmic_bytes_per_align": round(bytes_per_align, 2),
                          "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
+                         "binding_unit": "valu_issue",      # what limits this integer kernel; "bound"/"frac" above answer the metric's HBM question
+                         "binding_frac": (vi or {}).get("frac_flat4"),
                          "valu_issue": vi, "valu_issue_source": vi_src, "library_source_hash": lib_hash,
                          "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)); traffic >> algorithmic "
                                  "bytes because tile checkpoints and tile maxima (needed for exact tie enumeration) stream through HBM, "

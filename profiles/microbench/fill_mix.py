@@ -2,7 +2,7 @@
 defuse_amd/csrc/dsa_api.hip (cross-compiles here, no GPU needed), the three basic blocks with the most v_pk_maximum3_f16,
 VALU opcodes sorted into the two issue classes measured by profiles/microbench/valu_rate*.hip (2 cycles per wave:
 v_add_u32 / v_sub / v_xor / v_mov / v_cndmask / v_cmp / shifts / v_or / v_and; 4 cycles: VOP3P packed ops, v_max3, v_perm).
-Writes profiles/r02/fill_mix.json with the library's source hash; bench.py prices the VALU issue peak with it.
+Writes profiles/r03/fill_mix.json with the library's source hash; bench.py prices the VALU issue peak with it.
 
     python profiles/microbench/fill_mix.py"""
 import collections, json, os, re, subprocess, sys, tempfile
@@ -40,7 +40,7 @@ def main():
            "mix": {"two_cycle": (total - four) / total, "four_cycle": four / total},
            "priced_issue_cycles_per_column_step": (2.0 * (total - four) + 4.0 * four) / 3.0 / 64.0,
            "opcodes": dict(sorted(valu.items(), key=lambda kv: -kv[1]))}
-    path = os.path.join(ROOT, "profiles", "r02", "fill_mix.json")
+    path = os.path.join(ROOT, "profiles", "r03", "fill_mix.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: out[k] for k in ("valu_per_column_step", "mix", "priced_issue_cycles_per_column_step", "source_hash")}))
 
