@@ -59,6 +59,10 @@ struct Work {
     const double* XYU;              // wave version: X + Y + U per mate pair (constant over a fit)
     const int* TX;                  // wave version: ToXO
     int* XfromY;                    // wave version: rank in x order of the mate pair with rank s in y order
+    // wave version: runs of equal XO / YO ("groups": the breakpoint walk of MaxLikelihood compares prefix sums at their ends only)
+    int Gx, Gy;                     // number of groups
+    const int *gx, *gy;             // group of the element with rank r in x order / rank s in y order
+    const double *XG, *YG;          // the groups' coordinates
     int *ic1, *ic2;                 // [N]
     double W[MPE_KMAX], A[MPE_KMAX], B[MPE_KMAX];
     double sd;
@@ -69,9 +73,11 @@ struct Work {
 // workspace of one fit with K components
 __host__ __device__ inline size_t work_doubles(int n, int K) { return (size_t)n * (2 + 4 * K + 2 + 12 + 4) + 16; }
 __host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
-// what the wave kernel uses of a fit's slot: RXO (K*n), SX, SY, kd; behind the largest fit's own arrays the ones all fits
-// of the problem share (XO, YO, X+Y+U, the k-means point array 2n, XfromY)
-__host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return (size_t)n * (K + 3 + (largest ? 6 : 0)) + 16; }
+// what the wave kernel uses of a fit's slot: RXO (K*n), SX, SY, kd, the prefix sums at the group ends in x and in y order
+// (K*n each); behind the largest fit's own arrays the ones all fits of the problem share (XO, YO, X+Y+U, the k-means point
+// array 2n, XfromY, the group maps gx/gy, the group coordinates XG, YG)
+__host__ __device__ inline size_t wave_fit_doubles(int n, int K) { return (size_t)n * (3 * K + 3); }
+__host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return wave_fit_doubles(n, K) + (size_t)n * (largest ? 9 : 0) + 16; }
 
 __device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
 {
@@ -102,11 +108,15 @@ __device__ void transfer(const double* a, int m, double* c, int k, int* nc, doub
 }
 
 // AS 136 with n = 2 (tools/asa136.C:13-336 kmns, :339-566 optra, :569-758 qtran); returns ifault
-__device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2, double* d, int iter)
+// The per-cluster state (counts, the two factors, the live sets) is the caller's: k entries each — private arrays of a lane end
+// up in scratch memory, the wave kernel hands in LDS.
+struct KmState { int nc[MPE_KMAX], ncp[MPE_KMAX], itran[MPE_KMAX], live[MPE_KMAX]; double an1[MPE_KMAX], an2[MPE_KMAX]; };
+
+__device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2, double* d, int iter, KmState& st)
 {
     if (k <= 1 || m <= k) return 3;
-    int nc[MPE_KMAX], ncp[MPE_KMAX], itran[MPE_KMAX], live[MPE_KMAX];
-    double an1[MPE_KMAX], an2[MPE_KMAX];
+    int *nc = st.nc, *ncp = st.ncp, *itran = st.itran, *live = st.live;
+    double *an1 = st.an1, *an2 = st.an2;
     for (int i = 1; i <= m; ++i) {
         ic1[i - 1] = 1;
         ic2[i - 1] = 2;
@@ -391,7 +401,8 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
             c[j] = py[j];
             c[K + j] = px[j];
         }
-        const int ifault = kmns(w.ka, N, c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER);
+        KmState kst;
+        const int ifault = kmns(w.ka, N, c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER, kst);
         if (ifault == 1 || ifault == 3) { w.fail = 1; return false; }     // DebugCheck(ifault != 1 / != 3)
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < K; ++j) {
@@ -447,50 +458,89 @@ constexpr int WV = 64;
 #define MPE_WPE 3       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
 #endif
 
-// MaxLikelihood (:192-325) for one component in one lane, streaming: the two prefix sums advance with the
-// walk (SX[i] = SX[i-1] + RXO[i]) and the first breakpoint with a positive derivative ends it, so neither the
-// prefix arrays nor the breakpoint list are stored.  nk receives the component's sum of responsibilities
-// (UpdateMixWeights :183-190 takes the same sum in the same order).  Return codes as max_likelihood.
+// MaxLikelihood (:192-325) for one component in one lane.  The reference builds the whole list of breakpoints — a merge of
+// the prefix sums of the responsibilities in x order and in y order, compared at the ends of the runs of equal coordinates —
+// and takes the first one with a positive derivative.  Along the list cx + cy never grows (both orders descend) and cs never
+// shrinks (responsibilities are not negative), and every operation of the derivative is monotone in floating point as well:
+// once positive it stays positive.  So the list is never built:
+//   1. one pass of serial sums: NK and RXYU in the caller's order (UpdateMixWeights :183-190 takes the same NK in the same
+//      order), and the two prefix sums, each the reference's chain of additions, kept at the group ends only (GA, GB);
+//   2. a binary search over the x groups for the last state "x has just arrived at group g" whose breakpoint is not positive.
+//      Where y stands at that moment follows from the merge rule: it has passed every group with a smaller sum and, of a run
+//      of sums equal to x's, as many groups as x has passed of its own run of that sum (equal sums advance both sides);
+//   3. the reference's walk from that state, group by group, until the first positive breakpoint.
+// Any state the search accepts is a state the walk goes through with nothing positive before it, so the result is the
+// reference's whatever the search does (a run of ties too long to count is simply not accepted); g_mpe_no_jump switches the
+// search off (DEFUSE_MPE_NO_JUMP, for tests).  nk receives NK.  Returns 0 = no update (NK == 0), 1 = ok, -1 = the reference
+// would read past the end of its list.
 #ifdef MPE_PHASE_STATS
-__device__ unsigned long long g_mpe_walk[4];      // wave cycles in the M step's serial sums / in its breakpoint walk, walk steps (longest lane), calls
+__device__ unsigned long long g_mpe_walk[4];      // wave cycles in the M step's serial sums / in search + walk, walk steps (longest lane), calls
+#define MPE_WALK_ARG , unsigned long long (&wk_)[4]
+#else
+#define MPE_WALK_ARG
 #endif
-__device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int stride, double& a, double& b, double& nk)
+__device__ int g_mpe_no_jump;
+#ifdef MPE_PATH_STATS
+__device__ unsigned long long g_mpe_path[10];      // lanes: no hint, hint accepted, hint positive, windows undecided; waves: with a bisection, all; lanes: hint in front of group 2
+#define MPE_PATH(k) atomicAdd(&g_mpe_path[k], 1ull)
+#else
+#define MPE_PATH(k)
+#endif
+constexpr int MPE_TIE_SCAN = 4;                   // ties counted one by one up to here, by bisection beyond
+
+__device__ int max_likelihood_groups(const Work& w, const double* RXO_base, double* GA_base, double* GB_base, int stride, int& hint_g,
+                                     int& hint_h, double& a, double& b, double& nk MPE_WALK_ARG)
 {
 #ifdef MPE_PHASE_STATS
     const unsigned long long tw0 = __builtin_readcyclecounter();
     unsigned long long n_steps = 0;
 #endif
-    // the component's responsibilities in x order: element r at RXO_base[r * stride] (the fits keep them component-minor,
-    // so that the lanes of a fit, which own its components, touch neighbouring words)
+    // the component's arrays are component-minor: element r at base[r * stride], so that the lanes of a fit, which own its
+    // components, touch neighbouring words
     auto RXO = [&](int r) { return RXO_base[(size_t)r * stride]; };
+    auto GA = [&](int g) { return GA_base[(size_t)g * stride]; };
+    auto GB = [&](int h) { return GB_base[(size_t)h * stride]; };
     const int N = w.N;
     const int* TX = w.TX;
     const int* XfromY = w.XfromY;
-    double NK = 0.0, RXYU = 0.0;
+    double NK = 0.0, RXYU = 0.0, px = 0.0, py = 0.0;
     int t = 0;
     // Loads in batches so that only the additions are serial, and the batches overlap: a batch's responsibilities are gathered
     // through indices that were fetched while the batch before it was summed (one round trip to memory per batch, not two).
-    int ixn[MPE_CHAIN];
-    double qn[MPE_CHAIN];
+    int ixn[MPE_CHAIN], iyn[MPE_CHAIN];
     if (N >= MPE_CHAIN) {
 #pragma unroll
-        for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[v]; qn[v] = w.XYU[v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[v]; iyn[v] = XfromY[v]; }
     }
     for (; t + MPE_CHAIN <= N; t += MPE_CHAIN) {
-        double r[MPE_CHAIN], q[MPE_CHAIN];
+        double r[MPE_CHAIN], q[MPE_CHAIN], rx[MPE_CHAIN], ry[MPE_CHAIN];
+        int gxc[MPE_CHAIN], gyc[MPE_CHAIN];
 #pragma unroll
-        for (int v = 0; v < MPE_CHAIN; ++v) { r[v] = RXO(ixn[v]); q[v] = qn[v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) {
+            r[v] = RXO(ixn[v]); q[v] = w.XYU[t + v];
+            rx[v] = RXO(t + v); ry[v] = RXO(iyn[v]);
+            gxc[v] = w.gx[t + v]; gyc[v] = w.gy[t + v];
+        }
         if (t + 2 * MPE_CHAIN <= N) {
 #pragma unroll
-            for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[t + MPE_CHAIN + v]; qn[v] = w.XYU[t + MPE_CHAIN + v]; }
+            for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[t + MPE_CHAIN + v]; iyn[v] = XfromY[t + MPE_CHAIN + v]; }
         }
 #pragma unroll
-        for (int v = 0; v < MPE_CHAIN; ++v) { NK += r[v]; RXYU += r[v] * q[v]; }
+        for (int v = 0; v < MPE_CHAIN; ++v) {
+            NK += r[v]; RXYU += r[v] * q[v];
+            px += rx[v]; py += ry[v];                        // 0.0 + r == r: the chains start as the reference's do
+            GA_base[(size_t)gxc[v] * stride] = px;           // the last element of a group writes last
+            GB_base[(size_t)gyc[v] * stride] = py;
+        }
     }
     for (; t < N; ++t) {
         const double r = RXO(TX[t]);
         NK += r;
         RXYU += r * w.XYU[t];
+        px += RXO(t);
+        py += RXO(XfromY[t]);
+        GA_base[(size_t)w.gx[t] * stride] = px;
+        GB_base[(size_t)w.gy[t] * stride] = py;
     }
     nk = NK;
 #ifdef MPE_PHASE_STATS
@@ -498,77 +548,170 @@ __device__ int max_likelihood_stream(const Work& w, const double* RXO_base, int 
 #endif
     if (NK == 0.0) return 0;
     const double var = w.sd * w.sd;
-    double pcx = 0.0, pcy = 0.0, pcs = 0.0, ccx = 0.0, ccy = 0.0, ccs = 0.0;
-    int mi = 0;
-    bool found = false;
+    const double inv_var = 1.0 / var;
     // the sign of (RXYU - NK*(cx+cy))/var + LAMBDA*cs without the division wherever it is not in doubt: the product with
     // the rounded reciprocal is within a few ulp of the quotient, so an estimate clear of zero by 1e-9 of its terms has the
     // sign of the exact expression; otherwise the expression itself is evaluated
-    const double inv_var = 1.0 / var;
-    auto push = [&](double cx, double cy, double cs) {
-        if (found) return;
+    auto positive = [&](double cx, double cy, double cs) {
         const double q = RXYU - NK * (cx + cy), lc = LAMBDA * cs;
         const double est = q * inv_var + lc;
-        bool pos;
-        if (fabs(est) > 1e-9 * (fabs(q * inv_var) + fabs(lc)) && fabs(est) > 1e-290 && fabs(est) < 1e290) pos = est > 0;
-        else pos = q / var + lc > 0;
-        if (pos) { found = true; ccx = cx; ccy = cy; ccs = cs; }
+        if (fabs(est) > 1e-9 * (fabs(q * inv_var) + fabs(lc)) && fabs(est) > 1e-290 && fabs(est) < 1e290) return est > 0;
+        return q / var + lc > 0;
+    };
+    const int Gx = w.Gx, Gy = w.Gy;
+    const double* XG = w.XG;
+    const double* YG = w.YG;
+    double pcx = 0.0, pcy = 0.0, pcs = 0.0, ccx = 0.0, ccy = 0.0, ccs = 0.0;
+    int mi = 0;
+    bool found = false;
+    auto push = [&](double cx, double cy, double cs) {
+        if (found) return;
+        if (positive(cx, cy, cs)) { found = true; ccx = cx; ccy = cy; ccs = cs; }
         else { pcx = cx; pcy = cy; pcs = cs; ++mi; }
     };
-    // the walk keeps XO[i], XO[i+1], RXO[i+1] (and the same for j) in registers: one load per advance, off the
-    // critical compare; every kind of step advances through the same code so that the lanes of a wave stay together
-    int i = 0, j = 0;
-    double sx = RXO(0), sy = RXO(XfromY[0]);
-    double xi = w.XO[0], yj = w.YO[0];
-    double xn = 0.0, yn = 0.0, rxn = 0.0, ryn = 0.0;
-    if (N > 1) { xn = w.XO[1]; yn = w.YO[1]; rxn = RXO(1); ryn = RXO(XfromY[1]); }
-    // the y side reaches its responsibilities through the rank map (RXO(XfromY[j])): the index of the element after the next is
-    // fetched one advance early, so that an advance waits for one round trip to memory and not for two in a row
-    int jx2 = N > 2 ? XfromY[2] : 0;
-    push(xi, yj, 0.0);
-    while (!found && i < N && j < N) {
+    int g = 0, h = 0;
+    if (Gx > 2 && !g_mpe_no_jump) {
+        int lo = 0, lo_h = 0, lo_l = 0, hi = Gx;             // lo: accepted arrival (0 = the start), hi: not accepted
+        bool searched = false;
+        // (a) where the last M step of this component ended: responsibilities move little between EM iterations, so the last
+        // arrival but one of its walk is tried first, with everything it needs fetched at once — the four sums in front
+        // of x, a window of eight sums around where y stood then.  Accepted: the walk starts there.  Positive: the
+        // search below looks in front of it.  Anything the windows do not decide: the search below, unrestricted.
+        if (hint_g == 0) searched = true;                    // it ended in front of the second arrival: the walk from the start is short
+        else if (hint_g >= 1) {
+            const int gm = hint_g < Gx ? hint_g : Gx - 1;
+            const int ws = hint_h - 4 > 0 ? (hint_h - 4 < Gy - 8 ? hint_h - 4 : (Gy - 8 > 0 ? Gy - 8 : 0)) : 0;
+            double aw[4], bw[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aw[k] = gm - 1 - k >= 0 ? GA(gm - 1 - k) : -1.0;       // sums are never negative
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bw[k] = ws + k < Gy ? GB(ws + k) : DBL_MAX_;
+            const double xg = XG[gm];
+            const double v = aw[0];
+            int n_lt = 0, n_eq = 0, nx = 1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { n_lt += bw[k] < v ? 1 : 0; n_eq += bw[k] == v ? 1 : 0; }
+#pragma unroll
+            for (int k = 1; k < 4; ++k) nx += (nx == k && aw[k] == v) ? 1 : 0;
+            bool decided = (ws == 0 || bw[0] < v) && (n_lt + n_eq < 8 || ws + 8 >= Gy);    // the window holds the whole story of v
+            if (n_eq > nx && nx == 4 && gm - 5 >= 0) decided = false;                       // x's run of v may be longer than seen
+            if (decided) {
+                const int l = ws + n_lt;
+                const int hm = l + (n_eq < nx ? n_eq : nx);
+                bool ok = hm < Gy;
+                if (ok) ok = !positive(xg, YG[hm], v);
+                if (ok) { lo = gm; lo_h = hm; lo_l = l; searched = true; MPE_PATH(1); }
+                else { hi = gm; MPE_PATH(2); }
+            } else {
+                MPE_PATH(3);
+#ifdef MPE_PATH_STATS
+                if (!(ws == 0 || bw[0] < v)) MPE_PATH(7);                 // the first sum not below v lies in front of the window
+                else if (!(n_lt + n_eq < 8 || ws + 8 >= Gy) && n_eq == 0) atomicAdd(&g_mpe_path[8], 1ull);   // behind it
+#endif
+            }
+        }
+        if (hint_g == 0) MPE_PATH(6);
+        if (hint_g < 0) MPE_PATH(0);
+#ifdef MPE_PATH_STATS
+        {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true), bis = __builtin_amdgcn_ballot_w64(!searched && hi - lo > 1);
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) { MPE_PATH(5); if (bis) MPE_PATH(4); }
+        }
+#endif
+        // (b) bisection over the x groups; per candidate the first y group whose sum is not below v by bisection as well
+        while (!searched && hi - lo > 1) {
+            const int gm = (lo + hi) >> 1;                   // x arrives at group gm >= 1 with cs = the sum at the end of gm - 1
+            const double v = GA(gm - 1);
+            int l = lo_l, r = Gy;                            // (sums never shrink: not in front of the one found for the
+            while (l < r) {                                  // accepted arrival)
+                const int m = (l + r) >> 1;
+                if (GB(m) < v) l = m + 1;
+                else r = m;
+            }
+            int hm = l;
+            if (l < Gy && GB(l) == v) {                      // equal sums advance both sides: y passes as many of them as x has
+                int nx = 1, gg = gm - 2;                     // x groups with this sum up to gm - 1: one by one, then by bisection
+                while (gg >= 0 && nx <= MPE_TIE_SCAN && GA(gg) == v) { ++nx; --gg; }
+                if (nx > MPE_TIE_SCAN) {
+                    int a0 = 0, a1 = gg + 1;                 // first group in [0, gg + 1] with the sum v (gg + 1 has it)
+                    while (a0 < a1) {
+                        const int m = (a0 + a1) >> 1;
+                        if (GA(m) < v) a0 = m + 1;
+                        else a1 = m;
+                    }
+                    nx = gm - a0;
+                }
+                int nb = 1;                                  // y groups with this sum from l on, as far as they matter
+                while (nb < nx && nb <= MPE_TIE_SCAN && l + nb < Gy && GB(l + nb) == v) ++nb;
+                if (nb < nx && nb > MPE_TIE_SCAN) {
+                    int b0 = l + nb, b1 = Gy;                // first group behind l + nb - 1 with a larger sum
+                    while (b0 < b1) {
+                        const int m = (b0 + b1) >> 1;
+                        if (GB(m) > v) b1 = m;
+                        else b0 = m + 1;
+                    }
+                    nb = b0 - l < nx ? b0 - l : nx;
+                }
+                hm = l + nb;
+            }
+            bool ok = hm < Gy;                               // otherwise y ran out before: the walk ends there
+            if (ok) ok = !positive(XG[gm], YG[hm], v);
+            if (ok) { lo = gm; lo_h = hm; lo_l = l; }
+            else hi = gm;
+        }
+        if (lo > 0) {                                        // the last breakpoint before the state, as the walk would have left it
+            g = lo; h = lo_h;
+            pcx = XG[g]; pcy = YG[h]; pcs = GA(g - 1);
+            mi = 1;
+        }
+    }
+    // the walk, group by group, the next two groups of either side on their way; every kind of step advances through the same
+    // code so that the lanes of a wave stay together
+    double sx = GA(g), sy = GB(h);
+    double xi = XG[g], yj = YG[h];
+    double xn = 0.0, yn = 0.0, sxn = 0.0, syn = 0.0, xn2 = 0.0, yn2 = 0.0, sxn2 = 0.0, syn2 = 0.0;
+    if (g + 1 < Gx) { xn = XG[g + 1]; sxn = GA(g + 1); }
+    if (h + 1 < Gy) { yn = YG[h + 1]; syn = GB(h + 1); }
+    if (g + 2 < Gx) { xn2 = XG[g + 2]; sxn2 = GA(g + 2); }
+    if (h + 2 < Gy) { yn2 = YG[h + 2]; syn2 = GB(h + 2); }
+    if (g == 0) push(xi, yj, 0.0);
+    // the next M step of this component tries the last arrival but one this walk has seen (the state it started from counts)
+    int ga0 = -1, ha0 = 0, ga1 = g, ha1 = h;
+    hint_g = found ? 0 : -1;
+    hint_h = 0;
+    while (!found && g < Gx && h < Gy) {
 #ifdef MPE_PHASE_STATS
         ++n_steps;
 #endif
-        const bool hi = i + 1 < N, hj = j + 1 < N;
-        bool adv_i, adv_j;
-        if (hi && xi == xn) { adv_i = true; adv_j = false; }
-        else if (hj && yj == yn) { adv_i = false; adv_j = true; }
-        else {
-            const bool eq = sx == sy, lt = sx < sy;
-            const double cs = (eq || lt) ? sx : sy;
-            push(xi, yj, cs);
-            const bool second = eq ? (hi && hj) : (lt ? hi : hj);
-            if (second) push((eq || lt) ? xn : xi, (eq || !lt) ? yn : yj, cs);
-            adv_i = eq || lt;
-            adv_j = eq || !lt;
+        const bool hi = g + 1 < Gx, hj = h + 1 < Gy;
+        const bool eq = sx == sy, lt = sx < sy;
+        const double cs = (eq || lt) ? sx : sy;
+        push(xi, yj, cs);
+        const bool second = eq ? (hi && hj) : (lt ? hi : hj);
+        if (second) push((eq || lt) ? xn : xi, (eq || !lt) ? yn : yj, cs);
+        if (found) { hint_g = ga0 >= 0 ? ga0 : ga1; hint_h = ga0 >= 0 ? ha0 : ha1; }
+        if (eq || lt) {
+            ga0 = ga1; ha0 = ha1;
+            ga1 = g + 1; ha1 = eq ? h + 1 : h;
+            ++g;
+            xi = xn; sx = sxn; xn = xn2; sxn = sxn2;
+            if (g + 2 < Gx) { xn2 = XG[g + 2]; sxn2 = GA(g + 2); }
         }
-        if (adv_i) {
-            ++i;
-            xi = xn;
-            if (i < N) sx = sx + rxn;
-            if (i + 1 < N) { xn = w.XO[i + 1]; rxn = RXO(i + 1); }
-        }
-        if (adv_j) {
-            ++j;
-            yj = yn;
-            if (j < N) sy = sy + ryn;
-            if (j + 1 < N) { yn = w.YO[j + 1]; ryn = RXO(jx2); }
-            if (j + 2 < N) jx2 = XfromY[j + 2];
+        if (eq || !lt) {
+            ++h;
+            yj = yn; sy = syn; yn = yn2; syn = syn2;
+            if (h + 2 < Gy) { yn2 = YG[h + 2]; syn2 = GB(h + 2); }
         }
     }
 #ifdef MPE_PHASE_STATS
-    {
+    {   // per lane; the lanes of the fit that runs longest have seen every M step of the wave (the kernel takes the largest)
         const unsigned long long tw2 = __builtin_readcyclecounter();
         unsigned long long ms = n_steps;
         for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(ms, off); ms = o > ms ? o : ms; }   // (only the lanes in here take part)
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-        if ((int)(threadIdx.x & 63) == __builtin_ctzll(act)) {
-            atomicAdd(&g_mpe_walk[0], tw1 - tw0);
-            atomicAdd(&g_mpe_walk[1], tw2 - tw1);
-            atomicAdd(&g_mpe_walk[2], ms);
-            atomicAdd(&g_mpe_walk[3], 1ull);
-        }
+        wk_[0] += tw1 - tw0;
+        wk_[1] += tw2 - tw1;
+        wk_[2] += ms;
+        wk_[3] += 1;
     }
 #endif
     if (!found) return -1;
@@ -769,12 +912,13 @@ struct ProblemShared {
     double W[MPE_NCOMP], A[MPE_NCOMP], B[MPE_NCOMP];
     double px[MPE_KMAX], py[MPE_KMAX];
     double c[MPE_KMAX + 1][2 * MPE_KMAX];
+    KmState km[MPE_KMAX + 1];                  // k-means state of the fit with K centres
     double like[MPE_KMAX + 1], last[MPE_KMAX + 1];
     int active[MPE_KMAX + 1], valid[MPE_KMAX + 1], state[MPE_KMAX + 1], zero[MPE_KMAX + 1], ifault[MPE_KMAX + 1];
     int n_seeds, any_active;
 };
 
-struct FitArrays { double *RXO, *SX, *SY, *kd; int *ic1, *ic2; };
+struct FitArrays { double *RXO, *SX, *SY, *kd, *GA, *GB; int *ic1, *ic2; };
 
 __device__ __forceinline__ FitArrays fit_arrays(int N, int K, double* d, int* ip)
 {
@@ -782,7 +926,9 @@ __device__ __forceinline__ FitArrays fit_arrays(int N, int K, double* d, int* ip
     f.RXO = d; d += (size_t)K * N;
     f.SX = d; d += N;
     f.SY = d; d += N;
-    f.kd = d;
+    f.kd = d; d += N;
+    f.GA = d; d += (size_t)K * N;
+    f.GB = d;
     f.ic1 = ip;
     f.ic2 = ip + N;
     return f;
@@ -797,7 +943,10 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
 {
     __shared__ ProblemShared s;
 #ifdef MPE_PHASE_STATS
-    unsigned long long ph_[8] = {}, t_ = __builtin_readcyclecounter();
+    unsigned long long ph_[8] = {}, t_ = __builtin_readcyclecounter(), wk_[4] = {};
+#define MPE_WALK_PASS , wk_
+#else
+#define MPE_WALK_PASS
 #endif
     const int lane = threadIdx.x;
     const int q = order[blockIdx.x];
@@ -817,7 +966,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
 
     // arrays shared by the fits live behind the largest fit's own
     const int slot_max = q * MPE_KMAX + kmax - 1;
-    double* shared_d = wdoubles + wd_off[slot_max] + (size_t)kmax * N + 3 * (size_t)N;
+    double* shared_d = wdoubles + wd_off[slot_max] + wave_fit_doubles(N, kmax);
     Work w;
     w.N = N;
     w.X = x + b; w.Y = y + b; w.U = u + b;
@@ -828,7 +977,11 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     double* xyu = shared_d; shared_d += N;
     w.XYU = xyu;
     w.ka = shared_d; shared_d += 2 * (size_t)N;
-    w.XfromY = (int*)shared_d;
+    w.XfromY = (int*)shared_d; shared_d += N;
+    int* gmap = (int*)shared_d; shared_d += N;             // gx [N], gy [N]
+    double* xg = shared_d; shared_d += N;
+    double* yg = shared_d;
+    w.gx = gmap; w.gy = gmap + N; w.XG = xg; w.YG = yg;
     w.sd = prm.fragment_stddev;
     for (int i = lane; i < N; i += WV) {
         w.XO[w.ToXO[i]] = w.X[i];
@@ -840,6 +993,27 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     }
     if (lane <= MPE_KMAX) { s.active[lane] = 0; s.valid[lane] = 0; s.state[lane] = 0; s.zero[lane] = 0; s.ifault[lane] = 0; s.like[lane] = 0.0; s.last[lane] = 0.0; }
     if (lane < MPE_NCOMP) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
+    __syncthreads();
+    // the runs of equal coordinates in x order and in y order, once per problem: group of every rank, coordinate of every group
+    {
+        auto runs = [&](const double* O, int* grp, double* coord) {
+            int cnt = 0;
+            for (int base = 0; base < N; base += WV) {
+                const int r = base + lane;
+                const bool first = r < N && (r == 0 || O[r] != O[r - 1]);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
+                const int gi = cnt + __popcll(m & ((1ull << lane) - 1ull)) + (first ? 1 : 0) - 1;
+                if (r < N) {
+                    grp[r] = gi;
+                    if (first) coord[gi] = O[r];
+                }
+                cnt += __popcll(m);
+            }
+            return cnt;
+        };
+        w.Gx = runs(w.XO, gmap, xg);
+        w.Gy = runs(w.YO, gmap + N, yg);
+    }
     __syncthreads();
 
     MPE_STAMP(0);
@@ -882,7 +1056,7 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         else if (s.n_seeds >= K) {
             FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
             for (int j = 0; j < K; ++j) { s.c[K][j] = s.py[j]; s.c[K][K + j] = s.px[j]; }
-            const int ifault = kmns(w.ka, N, s.c[K], K, f.ic1, f.ic2, f.kd, KMEANS_ITER);
+            const int ifault = kmns(w.ka, N, s.c[K], K, f.ic1, f.ic2, f.kd, KMEANS_ITER, s.km[K]);
             s.ifault[K] = ifault;
             if (ifault == 1 || ifault == 3) s.state[K] = 2;    // DebugCheck(ifault != 1 / != 3)
             else s.active[K] = 1;
@@ -907,12 +1081,13 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     MPE_STAMP(2);
     // ---- EM of all fits
     long long my_iters = 0;
+    int hint_g = -1, hint_h = 0;               // where this lane's component ended its last M step (the next one starts its search there)
     for (;;) {
         // M step: every component of every running fit
         if (myK && s.active[myK]) {
             double a = 0.0, bb = 0.0, nk = 0.0;
             FitArrays f = fit_arrays(N, myK, wdoubles + wd_off[q * MPE_KMAX + myK - 1], wints + wi_off[q * MPE_KMAX + myK - 1]);
-            const int rc = max_likelihood_stream(w, f.RXO + myJ, myK, a, bb, nk);
+            const int rc = max_likelihood_groups(w, f.RXO + myJ, f.GA + myJ, f.GB + myJ, myK, hint_g, hint_h, a, bb, nk MPE_WALK_PASS);
             if (rc < 0) s.state[myK] = 2;                      // the reference would read past the end: DebugCheck
             if (rc > 0) { s.A[myL] = a; s.B[myL] = bb; }
             s.W[myL] = nk / N;
@@ -1059,6 +1234,11 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
 #ifdef MPE_PHASE_STATS
     if (lane == 0)
         for (int k = 0; k < 7; ++k) atomicAdd(&g_mpe_phase[k], ph_[k]);
+    for (int k = 0; k < 4; ++k) {
+        unsigned long long m = wk_[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(m, off); m = o > m ? o : m; }
+        if (lane == 0) atomicAdd(&g_mpe_walk[k], m);
+    }
 #endif
     if (lane == 0) atomicAdd(iters, (unsigned long long)my_iters);
 }
@@ -1131,9 +1311,14 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     // transcription it is checked against
     int64_t wave_min = 0;
     if (const char* e = getenv("DEFUSE_MPE_WAVE_MIN")) wave_min = atoll(e);
+    {   // DEFUSE_MPE_NO_JUMP=1: the M step walks its breakpoints from the first one (tests compare the two)
+        const char* e = getenv("DEFUSE_MPE_NO_JUMP");
+        const int no_jump = e && *e && *e != '0';
+        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_no_jump), &no_jump, sizeof no_jump));
+    }
 
     // problems are taken in chunks whose fit workspaces (one per problem and K) fit the budget
-    size_t budget = (size_t)32 << 30;       // of 288 GB HBM: one chunk for tens of millions of fragments
+    size_t budget = (size_t)64 << 30;       // of 288 GB HBM: one chunk for tens of millions of fragments
     if (const char* e = getenv("DEFUSE_MPE_SCRATCH_MB")) budget = std::max<size_t>(1, (size_t)atoll(e)) << 20;
     auto slot_doubles = [&](int p, int K) -> size_t {
         const int n = (int)(prob_off[p + 1] - prob_off[p]);
@@ -1226,11 +1411,18 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         fprintf(stderr, " | total %.3g cycles, kernel %.1f ms\n", (double)tot, t.kernel_ms);
         unsigned long long wk[4] = {};
         MPE_HIP(hipMemcpyFromSymbol(wk, HIP_SYMBOL(g_mpe_walk), sizeof wk));
-        fprintf(stderr, "[mpe M step] serial sums %.3g cycles, breakpoint walk %.3g cycles, walk steps of the longest lane %.4g per M step (%llu M steps), "
+        fprintf(stderr, "[mpe M step] serial sums %.3g cycles, breakpoint search + walk %.3g cycles, walk steps of the longest lane %.4g per M step (%llu M steps), "
                 "%.0f cycles per walk step\n", (double)wk[0], (double)wk[1], wk[3] ? (double)wk[2] / wk[3] : 0.0, wk[3], wk[2] ? (double)wk[1] / wk[2] : 0.0);
-        unsigned long long zero[8] = {};
-        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_phase), zero, sizeof zero));
+        unsigned long long zero[10] = {};
+        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_phase), zero, sizeof ph));
         MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_walk), zero, sizeof wk));
+#ifdef MPE_PATH_STATS
+        unsigned long long pa[10] = {};
+        MPE_HIP(hipMemcpyFromSymbol(pa, HIP_SYMBOL(g_mpe_path), sizeof pa));
+        fprintf(stderr, "[mpe M step] lanes: no hint %llu, hint in front of group 2 %llu, hint accepted %llu, hint positive %llu, windows undecided %llu (in front %llu, behind %llu); waves with a bisection %llu of %llu\n",
+                pa[0], pa[6], pa[1], pa[2], pa[3], pa[7], pa[8], pa[4], pa[5]);
+        MPE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mpe_path), zero, sizeof pa));
+#endif
     }
 #endif
     if (dump_iters) {
