@@ -455,7 +455,7 @@ constexpr int WV = 64;
 #define MPE_CHAIN 4     // elements the serial sums of the M step load ahead of their additions
 #endif
 #ifndef MPE_WPE
-#define MPE_WPE 3       // waves per SIMD the wave kernel is compiled for (profiles/microbench/mpe_occ.sh)
+#define MPE_WPE 2       // waves per SIMD the wave kernel is compiled for (profiles/microbench/em_variants.sh: 2 and 3 within 4 %, 4 and 1 slower)
 #endif
 
 // MaxLikelihood (:192-325) for one component in one lane.  The reference builds the whole list of breakpoints — a merge of
@@ -1145,12 +1145,12 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
             if (s.zero[K]) LL = -DBL_MAX_;
             else {
                 int i = 0;
-                for (; i + 4 <= N; i += 4) {
-                    double l1[4], l2[4];
+                for (; i + 8 <= N; i += 8) {
+                    double l1[8], l2[8];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) { l1[v] = f.SX[i + v]; l2[v] = f.SY[i + v]; }
+                    for (int v = 0; v < 8; ++v) { l1[v] = f.SX[i + v]; l2[v] = f.SY[i + v]; }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) LL = LL + l1[v] + l2[v];
+                    for (int v = 0; v < 8; ++v) LL = LL + l1[v] + l2[v];
                 }
                 for (; i < N; ++i) LL = LL + f.SX[i] + f.SY[i];
             }

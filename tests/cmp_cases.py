@@ -177,3 +177,38 @@ def adversarial_em_batch(seed, n_problems=4000, mean=300.0):
     to_xo = np.concatenate([mpe_c.ranks_desc(a) for a in xs])
     to_yo = np.concatenate([mpe_c.ranks_desc(a) for a in ys])
     return np.array(off, dtype=np.int64), x, y, u, to_xo, to_yo
+
+
+def tie_heavy_em_batch(seed, n_problems=120, mean=300.0):
+    """Larger problems (60-500 mate pairs) whose coordinates repeat: the M step's breakpoint search (mpe_api.hip,
+    max_likelihood_groups) works on runs of equal coordinates and on prefix sums that tie between the two orders — with K = 1
+    (every responsibility 1.0) and after the hard k-means start every sum is a whole number — so runs, ties, runs of ties and
+    components without any responsibility over long stretches all occur.  Returns the arrays of adversarial_em_batch."""
+    from oracle import mpe_c
+    rng = np.random.default_rng(seed)
+    xs, ys, off = [], [], [0]
+    for p in range(n_problems):
+        n = int(rng.integers(60, 500))
+        kind = p % 5
+        k = int(rng.integers(1, 7))
+        cx, cy = rng.integers(0, 3000, size=k) * 10, rng.integers(0, 3000, size=k) * 10
+        a = rng.integers(0, k, size=n)
+        if kind == 0:                      # few distinct values per locus
+            x, y = cx[a] + rng.integers(0, 4, size=n) * 7, cy[a] + rng.integers(0, 4, size=n) * 7
+        elif kind == 1:                    # the same multiset in both orders: every prefix sum ties
+            x = cx[a] + rng.integers(0, 25, size=n)
+            y = x.copy()
+        elif kind == 2:                    # one coordinate constant (a single run), the other spread
+            x, y = np.full(n, 500), cy[a] + rng.integers(0, 200, size=n)
+        elif kind == 3:                    # ordinary loci with integer jitter
+            x, y = cx[a] + rng.integers(0, 120, size=n), cy[a] + rng.integers(0, 120, size=n)
+        else:                              # long runs in x, all distinct in y
+            x, y = cx[a] + rng.integers(0, 2, size=n), rng.permutation(n) * 3 + cy[a]
+        xs.append(x.astype(np.float64))
+        ys.append(y.astype(np.float64))
+        off.append(off[-1] + n)
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    u = np.full(len(x), mean - 100.0)
+    to_xo = np.concatenate([mpe_c.ranks_desc(a) for a in xs])
+    to_yo = np.concatenate([mpe_c.ranks_desc(a) for a in ys])
+    return np.array(off, dtype=np.int64), x, y, u, to_xo, to_yo

@@ -365,3 +365,36 @@ def test_em_rare_paths_wave_lane_and_oracle_agree(built, wave_min):
             os.environ.pop("DEFUSE_MPE_WAVE_MIN", None)
         else:
             os.environ["DEFUSE_MPE_WAVE_MIN"] = old
+
+
+@pytest.mark.gpu
+def test_em_breakpoint_search_on_runs_and_ties(built):
+    """The M step finds the first breakpoint with a positive derivative by searching (hinted by the EM iteration before, else
+    by bisection over the runs of equal coordinates) and walks only the last few; with DEFUSE_MPE_NO_JUMP it walks from the
+    first one as the reference does.  On problems full of runs and tied prefix sums: both give the C oracle's memberships,
+    bit for bit, and the same number of EM iterations as each other (any other breakpoint changes a likelihood somewhere)."""
+    from defuse_amd import mpe
+    from oracle import mpe_c
+    mp = mpe_c.lib().ora_min_probability(30.0, 0.95)
+    old = os.environ.get("DEFUSE_MPE_NO_JUMP")
+    try:
+        for seed in (7, 8):
+            args = (300.0, 30.0, mp, 5) + cmp_cases.tie_heavy_em_batch(seed, 300)
+            o_ncl, o_member, o_status, dg, _ = mpe_c.cluster_batch(*args)
+            assert not o_status.any() and o_ncl.sum() > 1000
+            runs = {}
+            for no_jump in (False, True):
+                if no_jump:
+                    os.environ["DEFUSE_MPE_NO_JUMP"] = "1"
+                else:
+                    os.environ.pop("DEFUSE_MPE_NO_JUMP", None)
+                g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
+                assert not g_status.any() and (g_ncl == o_ncl).all()
+                assert g_member.tobytes() == o_member.tobytes(), (seed, no_jump)
+                runs[no_jump] = t.em_iterations
+            assert runs[False] == runs[True] > 10000
+    finally:
+        if old is None:
+            os.environ.pop("DEFUSE_MPE_NO_JUMP", None)
+        else:
+            os.environ["DEFUSE_MPE_NO_JUMP"] = old
