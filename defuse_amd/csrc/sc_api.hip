@@ -211,6 +211,14 @@ struct Buf {
 
 extern "C" const char* sc_last_error(void) { return g_err.c_str(); }
 
+extern "C" int sc_prepare(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return -2;
+    if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) return -2;
+    return 0;
+}
+
 extern "C" int sc_cover(int device, const int64_t* cluster_off, const int32_t* elements, int32_t n_clusters,
                         int32_t max_element, int32_t* owner, sc_timing* timing)
 {

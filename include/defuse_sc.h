@@ -37,6 +37,10 @@ typedef struct sc_timing {
 int sc_cover(int device, const int64_t* cluster_off, const int32_t* elements, int32_t n_clusters,
              int32_t max_element, int32_t* owner, sc_timing* timing);
 const char* sc_last_error(void);
+/* Optional: brings the runtime and the device's context up (a few tenths of a second in a fresh process), so that a caller
+ * can let that happen on a thread of its own while it parses its input.  Thread-safe; 0, or -2 without a usable device
+ * (sc_cover reports that again). */
+int sc_prepare(int device);
 
 #ifdef __cplusplus
 }
