@@ -79,23 +79,25 @@ __host__ __device__ inline size_t work_ints(int n) { return (size_t)n * 2 + 8; }
 __host__ __device__ inline size_t wave_fit_doubles(int n, int K) { return (size_t)n * (3 * K + 3); }
 __host__ __device__ inline size_t wave_work_doubles(int n, int K, bool largest) { return wave_fit_doubles(n, K) + (size_t)n * (largest ? 9 : 0) + 16; }
 
-__device__ double dist2(const double* a, int m, const double* c, int k, int i, int l)   // n = 2
+// squared distance of a point to centre l (n = 2; asa136.C's inner loops over j), the point's coordinates in registers
+__device__ __forceinline__ double dist2p(double ax, double ay, const double* c, int k, int l)
 {
     double s = 0.0;
-    for (int j = 1; j <= 2; ++j) {
-        const double df = a[i - 1 + (j - 1) * m] - c[l - 1 + (j - 1) * k];
-        s = s + df * df;
-    }
+    const double d1 = ax - c[l - 1];
+    s = s + d1 * d1;
+    const double d2 = ay - c[l - 1 + k];
+    s = s + d2 * d2;
     return s;
 }
 
-__device__ void transfer(const double* a, int m, double* c, int k, int* nc, double* an1, double* an2, int* ic1, int* ic2, int i,
+__device__ void transfer(double ax, double ay, double* c, int k, int* nc, double* an1, double* an2, int* ic1, int* ic2, int i,
                          int l1, int l2)
 {
     const double al1 = (double)nc[l1 - 1], alw = al1 - 1.0, al2 = (double)nc[l2 - 1], alt = al2 + 1.0;
     for (int j = 1; j <= 2; ++j) {
-        c[l1 - 1 + (j - 1) * k] = (c[l1 - 1 + (j - 1) * k] * al1 - a[i - 1 + (j - 1) * m]) / alw;
-        c[l2 - 1 + (j - 1) * k] = (c[l2 - 1 + (j - 1) * k] * al2 + a[i - 1 + (j - 1) * m]) / alt;
+        const double aj = j == 1 ? ax : ay;
+        c[l1 - 1 + (j - 1) * k] = (c[l1 - 1 + (j - 1) * k] * al1 - aj) / alw;
+        c[l2 - 1 + (j - 1) * k] = (c[l2 - 1 + (j - 1) * k] * al2 + aj) / alt;
     }
     nc[l1 - 1] -= 1;
     nc[l2 - 1] += 1;
@@ -121,7 +123,8 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
         ic1[i - 1] = 1;
         ic2[i - 1] = 2;
         double dt[2];
-        for (int il = 1; il <= 2; ++il) dt[il - 1] = dist2(a, m, c, k, i, il);
+        const double ax = a[i - 1], ay = a[i - 1 + m];
+        for (int il = 1; il <= 2; ++il) dt[il - 1] = dist2p(ax, ay, c, k, il);
         if (dt[1] < dt[0]) {
             ic1[i - 1] = 2;
             ic2[i - 1] = 1;
@@ -130,7 +133,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             dt[1] = t;
         }
         for (int l = 3; l <= k; ++l) {
-            const double db = dist2(a, m, c, k, i, l);
+            const double db = dist2p(ax, ay, c, k, l);
             if (db < dt[1]) {
                 if (dt[0] <= db) {
                     dt[1] = db;
@@ -170,25 +173,32 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             for (int l = 1; l <= k; ++l)
                 if (itran[l - 1] == 1) live[l - 1] = m + 1;
             bool early = false;
+            // the point's coordinates, clusters and distance are fetched one point ahead: nothing that happens to point i
+            // touches those of point i + 1 (a transfer writes ic1 / ic2 of its own point only), and the point array is constant
+            double axn = a[0], ayn = a[m], dn = d[0];
+            int l1n = ic1[0], l2n = ic2[0];
             for (int i = 1; i <= m; ++i) {
                 indx += 1;
-                const int l1 = ic1[i - 1];
-                int l2 = ic2[i - 1];
+                const double ax = axn, ay = ayn;
+                double di = dn;
+                const int l1 = l1n;
+                int l2 = l2n;
+                if (i < m) { axn = a[i]; ayn = a[i + m]; dn = d[i]; l1n = ic1[i]; l2n = ic2[i]; }
                 const int ll = l2;
                 if (1 < nc[l1 - 1]) {
-                    if (ncp[l1 - 1] != 0) d[i - 1] = dist2(a, m, c, k, i, l1) * an1[l1 - 1];
-                    double r2 = dist2(a, m, c, k, i, l2) * an2[l2 - 1];
+                    if (ncp[l1 - 1] != 0) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[i - 1] = di; }
+                    double r2 = dist2p(ax, ay, c, k, l2) * an2[l2 - 1];
                     for (int l = 1; l <= k; ++l) {
                         if ((i < live[l1 - 1] || i < live[l2 - 1]) && l != l1 && l != ll) {
                             const double rr = r2 / an2[l - 1];
-                            const double dc = dist2(a, m, c, k, i, l);
+                            const double dc = dist2p(ax, ay, c, k, l);
                             if (dc < rr) {
                                 r2 = dc * an2[l - 1];
                                 l2 = l;
                             }
                         }
                     }
-                    if (d[i - 1] <= r2) {
+                    if (di <= r2) {
                         ic2[i - 1] = l2;
                     } else {
                         indx = 0;
@@ -196,7 +206,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                         live[l2 - 1] = m + i;
                         ncp[l1 - 1] = i;
                         ncp[l2 - 1] = i;
-                        transfer(a, m, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                        transfer(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
                     }
                 }
                 if (indx == m) { early = true; break; }
@@ -213,15 +223,20 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             int icoun = 0, istep = 0;
             bool done = false;
             while (!done) {
+                double axn = a[0], ayn = a[m], dn = d[0];          // one point ahead, as in optra
+                int l1n = ic1[0], l2n = ic2[0];
                 for (int i = 1; i <= m; ++i) {
                     icoun += 1;
                     istep += 1;
-                    const int l1 = ic1[i - 1], l2 = ic2[i - 1];
+                    const double ax = axn, ay = ayn;
+                    double di = dn;
+                    const int l1 = l1n, l2 = l2n;
+                    if (i < m) { axn = a[i]; ayn = a[i + m]; dn = d[i]; l1n = ic1[i]; l2n = ic2[i]; }
                     if (1 < nc[l1 - 1]) {
-                        if (istep <= ncp[l1 - 1]) d[i - 1] = dist2(a, m, c, k, i, l1) * an1[l1 - 1];
+                        if (istep <= ncp[l1 - 1]) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[i - 1] = di; }
                         if (istep < ncp[l1 - 1] || istep < ncp[l2 - 1]) {
-                            const double r2 = d[i - 1] / an2[l2 - 1];
-                            const double dd = dist2(a, m, c, k, i, l2);
+                            const double r2 = di / an2[l2 - 1];
+                            const double dd = dist2p(ax, ay, c, k, l2);
                             if (dd < r2) {
                                 icoun = 0;
                                 indx = 0;
@@ -229,7 +244,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                                 itran[l2 - 1] = 1;
                                 ncp[l1 - 1] = istep + m;
                                 ncp[l2 - 1] = istep + m;
-                                transfer(a, m, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                                transfer(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
                             }
                         }
                     }
