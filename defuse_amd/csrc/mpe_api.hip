@@ -1111,44 +1111,48 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
         __syncthreads();
         MPE_STAMP(3);
-        // E step, fit after fit: exponents, exp, mixture sum, log — and, from the same registers, the responsibilities
+        // E step: exponents, exp, mixture sum, log — and, from the same registers, the responsibilities
         // W_j e_j / sum of UpdateResponsibilities (:139-181).  The reference updates them after the convergence test; nothing
         // reads them between here and the next M step, and a fit that stops in this iteration never reads them again, so
         // writing them now is the same — without the K*N array of exponentials and the second pass over it.
-        for (int K = 1; K <= kmax; ++K) {
-            if (!s.active[K]) continue;
-            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
-            const int l0 = K * (K - 1) / 2;
-            bool zero = false;
+        // (mate pairs in the outer loop: X, Y, U and the rank are fetched once for all fits)
+        {
+            unsigned zero_mask = 0;
             for (int i = lane; i < N; i += WV) {
                 const double xi = w.X[i], yi = w.Y[i], ui = w.U[i];
-                double ex[MPE_KMAX];
-#pragma unroll
-                for (int j = 0; j < MPE_KMAX; ++j)
-                    if (j < K) {
-                        const double t = (s.A[l0 + j] + s.B[l0 + j] - xi - yi - ui) / w.sd;
-                        ex[j] = -0.5 * (t * t) - LAMBDA * fmax(0.0, xi - s.A[l0 + j]) - LAMBDA * fmax(0.0, yi - s.B[l0 + j]);
-                    }
-                double maxexp = ex[0];
-#pragma unroll
-                for (int j = 1; j < MPE_KMAX; ++j)
-                    if (j < K) maxexp = fmax(maxexp, ex[j]);
-                double sum = 0.0;
-#pragma unroll
-                for (int j = 0; j < MPE_KMAX; ++j)
-                    if (j < K) {
-                        ex[j] = exp(ex[j] - maxexp);
-                        sum += s.W[l0 + j] * ex[j];
-                    }
-                if (sum == 0.0) zero = true;
-                f.SX[i] = log(sum);
-                f.SY[i] = maxexp;
                 const int ixo = w.TX[i];
+                for (int K = 1; K <= kmax; ++K) {
+                    if (!s.active[K]) continue;
+                    FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+                    const int l0 = K * (K - 1) / 2;
+                    double ex[MPE_KMAX];
 #pragma unroll
-                for (int j = 0; j < MPE_KMAX; ++j)
-                    if (j < K) f.RXO[(size_t)ixo * K + j] = s.W[l0 + j] * ex[j] / sum;
+                    for (int j = 0; j < MPE_KMAX; ++j)
+                        if (j < K) {
+                            const double t = (s.A[l0 + j] + s.B[l0 + j] - xi - yi - ui) / w.sd;
+                            ex[j] = -0.5 * (t * t) - LAMBDA * fmax(0.0, xi - s.A[l0 + j]) - LAMBDA * fmax(0.0, yi - s.B[l0 + j]);
+                        }
+                    double maxexp = ex[0];
+#pragma unroll
+                    for (int j = 1; j < MPE_KMAX; ++j)
+                        if (j < K) maxexp = fmax(maxexp, ex[j]);
+                    double sum = 0.0;
+#pragma unroll
+                    for (int j = 0; j < MPE_KMAX; ++j)
+                        if (j < K) {
+                            ex[j] = exp(ex[j] - maxexp);
+                            sum += s.W[l0 + j] * ex[j];
+                        }
+                    if (sum == 0.0) zero_mask |= 1u << K;
+                    f.SX[i] = log(sum);
+                    f.SY[i] = maxexp;
+#pragma unroll
+                    for (int j = 0; j < MPE_KMAX; ++j)
+                        if (j < K) f.RXO[(size_t)ixo * K + j] = s.W[l0 + j] * ex[j] / sum;
+                }
             }
-            if (zero) s.zero[K] = 1;
+            for (int K = 1; K <= kmax; ++K)
+                if (zero_mask >> K & 1u) s.zero[K] = 1;
         }
         __syncthreads();
         MPE_STAMP(4);
