@@ -139,6 +139,7 @@ void FilterSide(FragmentGroups& g, const FragmentGroups& other, const std::vecto
 
 int main(int argc, char* argv[])
 {
+    keep_freed_memory();
     CmdLine cmd("Mate Pair Clustering Tool");
     cmd.add("a", "align", "Alignments Filename", "string");
     cmd.add("c", "clusters", "Output Clusters Filename", "string");

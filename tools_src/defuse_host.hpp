@@ -6,6 +6,8 @@
 // library through include/defuse_dsa.h.
 #pragma once
 #include <fcntl.h>
+#include <climits>
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -145,6 +147,17 @@ inline bool field_int(const char* p, size_t n, int& out)
     if (v > 2147483647LL || v < -2147483648LL) return false;
     out = (int)v;
     return true;
+}
+
+// A tool that builds and drops gigabytes of small lists on many threads: keep what is freed (no trimming, no mmap per large
+// block) — handing pages back to the system and faulting them in again is where such a run spends its system time.
+// DEFUSE_MALLOC_DEFAULT=1 leaves the allocator alone.
+inline void keep_freed_memory()
+{
+    if (std::getenv("DEFUSE_MALLOC_DEFAULT")) return;
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, INT_MAX);
+    mallopt(M_TOP_PAD, 256 << 20);
 }
 
 // host threads of a tool: DEFUSE_THREADS, else 8 (profiles/microbench/cmp_threads.sh: beyond that the joins cost more than

@@ -20,6 +20,7 @@ struct ClusterLine { int clusterID, clusterEnd, fragmentIndex; };
 
 int main(int argc, char* argv[])
 {
+    keep_freed_memory();
     CmdLine cmd("Set cover for maximum parsimony");
     cmd.add("c", "clusters", "Clusters Filename", "string");
     cmd.add("m", "minclustersize", "Minimum Cluster Size", "integer");
