@@ -177,6 +177,13 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             // touches those of point i + 1 (a transfer writes ic1 / ic2 of its own point only), and the point array is constant
             double axn = a[0], ayn = a[m], dn = d[0];
             int l1n = ic1[0], l2n = ic2[0];
+            double cx[MPE_KMAX], cy[MPE_KMAX], a2[MPE_KMAX];     // centres and the factor an2, in registers for the scan below
+            auto reload = [&]() {
+#pragma unroll
+                for (int l = 0; l < MPE_KMAX; ++l)
+                    if (l < k) { cx[l] = c[l]; cy[l] = c[l + k]; a2[l] = an2[l]; }
+            };
+            reload();
             for (int i = 1; i <= m; ++i) {
                 indx += 1;
                 const double ax = axn, ay = ayn;
@@ -188,13 +195,23 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                 if (1 < nc[l1 - 1]) {
                     if (ncp[l1 - 1] != 0) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[i - 1] = di; }
                     double r2 = dist2p(ax, ay, c, k, l2) * an2[l2 - 1];
-                    for (int l = 1; l <= k; ++l) {
-                        if ((i < live[l1 - 1] || i < live[l2 - 1]) && l != l1 && l != ll) {
-                            const double rr = r2 / an2[l - 1];
-                            const double dc = dist2p(ax, ay, c, k, l);
+                    // the scan over the centres from registers (centres and factors change with a transfer only; the live
+                    // set of l2 when l2 does): the same quotients, distances and comparisons in the same order
+                    const int live1 = live[l1 - 1];
+                    int live2 = live[l2 - 1];
+#pragma unroll
+                    for (int l = 1; l <= MPE_KMAX; ++l) {
+                        if (l <= k && (i < live1 || i < live2) && l != l1 && l != ll) {
+                            const double rr = r2 / a2[l - 1];
+                            double dc = 0.0;
+                            const double d1 = ax - cx[l - 1];
+                            dc = dc + d1 * d1;
+                            const double d2 = ay - cy[l - 1];
+                            dc = dc + d2 * d2;
                             if (dc < rr) {
-                                r2 = dc * an2[l - 1];
+                                r2 = dc * a2[l - 1];
                                 l2 = l;
+                                live2 = live[l - 1];
                             }
                         }
                     }
@@ -207,6 +224,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                         ncp[l1 - 1] = i;
                         ncp[l2 - 1] = i;
                         transfer(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                        reload();
                     }
                 }
                 if (indx == m) { early = true; break; }
