@@ -30,6 +30,11 @@ def _run(cmd):
 
 
 LIB_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared"]
+# The split-read kernels (dsa_api.hip) only: LLVM's iterative ILP scheduler.  The sweep of a tile row is 64 dependent maxima
+# beside independent additions, table reads and row-maximum updates in one straight block; the default scheduler orders it for
+# register pressure, this one interleaves the independent work into the chain's issue gaps: fill kernel 3.05 -> 2.88 ms on one
+# box (profiles/r03/compiler_flags_ab.txt; max-ilp, max-memory-clause, iterative-minreg and -maxocc are slower or equal).
+DSA_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def lib_sources():
@@ -46,17 +51,28 @@ def source_hash(extra_flags=()):
     for p in lib_sources():
         h.update(os.path.basename(p).encode() + b"\0")
         h.update(open(p, "rb").read())
-    h.update(" ".join(LIB_FLAGS + list(extra_flags)).encode())
+    h.update(" ".join(LIB_FLAGS + DSA_FLAGS + list(extra_flags)).encode())
     return h.hexdigest()[:12]
 
 
 def build_lib(force=False):
     srcs = lib_sources()
-    if force or _newer(LIB, srcs):
-        _run([HIPCC] + LIB_FLAGS + ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(),
-              "-o", LIB, os.path.join(CSRC, "dsa_api.hip"), os.path.join(CSRC, "sc_api.hip"), os.path.join(CSRC, "mpe_api.hip"),
-              os.path.join(CSRC, "la_api.hip"), os.path.join(CSRC, "hc_api.hip"), os.path.join(CSRC, "cov_api.hip")])
+    if force or _newer(LIB, srcs + [os.path.abspath(__file__)]):      # the flags live in this file
+        compile_lib(LIB)
     return LIB
+
+
+def compile_lib(out, extra_flags=()):
+    """dsa_api.hip into an object of its own (DSA_FLAGS), then the library from it and the other sources."""
+    extra = list(extra_flags)
+    define = ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(extra)]
+    obj_dir = os.path.join(HERE, "_build")
+    os.makedirs(obj_dir, exist_ok=True)
+    obj = os.path.join(obj_dir, os.path.basename(out) + ".dsa_api.o")
+    _run([HIPCC] + [f for f in LIB_FLAGS if f != "-shared"] + DSA_FLAGS + extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")])
+    _run([HIPCC] + LIB_FLAGS + extra + define + ["-o", out, obj] +
+         [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip")])
+    return out
 
 
 TOOLS = ["dosplitalign", "evalsplitalign", "setcover", "clustermatepairs", "localalign", "defuse_glue", "calccov"]
