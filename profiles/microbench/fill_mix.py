@@ -15,7 +15,7 @@ FOUR = ("v_pk_", "v_max3", "v_min3", "v_perm", "v_mad", "v_mul", "v_med3", "v_ls
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.check_call([build.HIPCC] + build.LIB_FLAGS[:-2] + ["-c", "--save-temps", "-o", os.path.join(tmp, "dsa.o"),
+        subprocess.check_call([build.HIPCC] + build.LIB_FLAGS[:-2] + build.DSA_FLAGS + ["-c", "--save-temps", "-o", os.path.join(tmp, "dsa.o"),
                                os.path.join(build.CSRC, "dsa_api.hip")], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         src = open(os.path.join(tmp, "dsa_api-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     start = next(i for i, l in enumerate(src) if l.startswith("_ZN3dsa11k_fill_fastILi0EE"))
