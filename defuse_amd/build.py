@@ -69,7 +69,15 @@ def compile_lib(out, extra_flags=()):
     obj_dir = os.path.join(HERE, "_build")
     os.makedirs(obj_dir, exist_ok=True)
     obj = os.path.join(obj_dir, os.path.basename(out) + ".dsa_api.o")
-    _run([HIPCC] + [f for f in LIB_FLAGS if f != "-shared"] + DSA_FLAGS + extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")])
+    base = [HIPCC] + [f for f in LIB_FLAGS if f != "-shared"]
+    tail = extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")]
+    try:
+        _run(base + DSA_FLAGS + tail)
+    except subprocess.CalledProcessError:
+        if not DSA_FLAGS:
+            raise
+        print("build: this hipcc rejects %s; compiling dsa_api.hip with the default scheduler (slower fill kernel)" % " ".join(DSA_FLAGS), flush=True)
+        _run(base + tail)
     _run([HIPCC] + LIB_FLAGS + extra + define + ["-o", out, obj] +
          [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip")])
     return out
