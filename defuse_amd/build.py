@@ -42,16 +42,48 @@ def lib_sources():
            [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h", "defuse_cov.h")]
 
 
-def source_hash(extra_flags=()):
-    """12 hex digits over the library's sources and compile flags.  Compiled into the library (dsa_version()) and written
-    into every profile JSON (profiles/microbench/*.sh), so that bench.py can tell whether committed counters were taken on
-    the kernels it is running."""
+_dsa_flags_probe = {}
+
+
+def effective_dsa_flags():
+    """DSA_FLAGS if this hipcc accepts them, else [] (the default scheduler: a slower fill kernel).  Probed once per
+    compiler with an empty translation unit, so that a genuine compile error in the sources is never taken for a
+    rejected flag, and so that the hash and dsa_build_flags() say what was really used."""
+    if HIPCC not in _dsa_flags_probe:
+        ok = True
+        if DSA_FLAGS:
+            r = subprocess.run([HIPCC, "--offload-arch=" + ARCH] + DSA_FLAGS + ["-x", "hip", "-c", os.devnull, "-o", os.devnull],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            ok = r.returncode == 0
+            if not ok:
+                print("build: this hipcc rejects %s; dsa_api.hip is compiled with the default scheduler (slower fill kernel)\n%s" %
+                      (" ".join(DSA_FLAGS), r.stdout[-400:]), flush=True)
+        _dsa_flags_probe[HIPCC] = list(DSA_FLAGS) if ok else []
+    return list(_dsa_flags_probe[HIPCC])
+
+
+def sched_name(flags=None):
+    """"iterative-ilp" | "default": the instruction scheduler dsa_api.hip is built with (bench.py prints it)."""
+    flags = effective_dsa_flags() if flags is None else flags
+    for f in flags:
+        if f.startswith("-amdgpu-sched-strategy="):
+            return f.split("=", 1)[1]
+    return "default"
+
+
+def source_hash(extra_flags=(), dsa_flags=None):
+    """12 hex digits over the library's sources and the compile flags ACTUALLY used (a build that fell back to the default
+    scheduler has another hash than one with DSA_FLAGS).  Compiled into the library (dsa_version()) and written into every
+    profile JSON (profiles/microbench/*.sh), so that bench.py can tell whether committed counters were taken on the kernels
+    it is running."""
     import hashlib
+    if dsa_flags is None:
+        dsa_flags = effective_dsa_flags()
     h = hashlib.sha256()
     for p in lib_sources():
         h.update(os.path.basename(p).encode() + b"\0")
         h.update(open(p, "rb").read())
-    h.update(" ".join(LIB_FLAGS + DSA_FLAGS + list(extra_flags)).encode())
+    h.update(" ".join(LIB_FLAGS + list(dsa_flags) + list(extra_flags)).encode())
     return h.hexdigest()[:12]
 
 
@@ -63,23 +95,27 @@ def build_lib(force=False):
 
 
 def compile_lib(out, extra_flags=()):
-    """dsa_api.hip into an object of its own (DSA_FLAGS), then the library from it and the other sources."""
+    """dsa_api.hip into an object of its own (with the scheduler flag where the compiler has it), then the library from it
+    and the other sources.  Object and library are written under names of this process and renamed into place: several
+    builders (ranks that all call build_lib) never read each other's half-written files."""
     extra = list(extra_flags)
-    define = ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(extra)]
+    dsa_flags = effective_dsa_flags()
+    define = ["-DDSA_BUILD_HASH=\"%s\"" % source_hash(extra, dsa_flags),
+              "-DDSA_BUILD_FLAGS=\"sched=%s %s\"" % (sched_name(dsa_flags), " ".join(f for f in LIB_FLAGS + extra if f not in ("-fPIC", "-shared")))]
     obj_dir = os.path.join(HERE, "_build")
     os.makedirs(obj_dir, exist_ok=True)
-    obj = os.path.join(obj_dir, os.path.basename(out) + ".dsa_api.o")
-    base = [HIPCC] + [f for f in LIB_FLAGS if f != "-shared"]
-    tail = extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")]
+    tag = ".%d.tmp" % os.getpid()
+    obj = os.path.join(obj_dir, os.path.basename(out) + ".dsa_api.o" + tag)
+    tmp_out = out + tag
     try:
-        _run(base + DSA_FLAGS + tail)
-    except subprocess.CalledProcessError:
-        if not DSA_FLAGS:
-            raise
-        print("build: this hipcc rejects %s; compiling dsa_api.hip with the default scheduler (slower fill kernel)" % " ".join(DSA_FLAGS), flush=True)
-        _run(base + tail)
-    _run([HIPCC] + LIB_FLAGS + extra + define + ["-o", out, obj] +
-         [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip")])
+        _run([HIPCC] + [f for f in LIB_FLAGS if f != "-shared"] + dsa_flags + extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")])
+        _run([HIPCC] + LIB_FLAGS + extra + define + ["-o", tmp_out, obj] +
+             [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip")])
+        os.replace(tmp_out, out)
+    finally:
+        for f in (obj, tmp_out):
+            if os.path.exists(f):
+                os.unlink(f)
     return out
 
 

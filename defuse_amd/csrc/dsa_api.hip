@@ -140,7 +140,10 @@ struct Slice {                       // a contiguous range of the caller's pair 
 
 struct dsa_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;    // = lane 0's stream unless dsa_set_stream gave another
+    // The stream a context queues its copies and its planning on is ALWAYS lane 0's (main_stream()), read where it is used:
+    // lanes may be shared (dsa_share_scratch, dsa_stream) and dsa_set_stream on one sharer changes lane 0's stream for all —
+    // a copy of the handle per context would go stale and let dsa_plan and dsa_run queue on two different streams.
+    hipStream_t main_stream() const;
     hipStream_t user_stream = nullptr;
     std::string err;
     size_t scratch_budget = (size_t)16 << 30;
@@ -179,7 +182,8 @@ struct dsa_ctx {
     DevBuf<int32_t> d_long_fusions, d_long_work, d_long_rows;
     DevBuf<LongState> d_long_state;
     DevBuf<uint32_t> d_long_bits;
-    int64_t long_cells = 0;
+    int64_t long_cells = 0;          // DP cells of the long pairs
+    int64_t long_blank_cells = 0;    // what the planning counts for their blanked copies (an empty read on the blanked windows)
 
     // per-slice scratch lives in two pipeline lanes so that the latency-bound finish stage of one
     // slice overlaps the fill of the next (separate HIP streams)
@@ -190,6 +194,8 @@ struct dsa_ctx {
 
     dsa_timing timing{};
 };
+
+hipStream_t dsa_ctx::main_stream() const { return lanes->lane[0].stream; }
 
 namespace {
 
@@ -272,7 +278,7 @@ int enqueue_plan(dsa_ctx* ctx)
     const int nf = ctx->n_fusions;
     const int64_t n_pairs = ctx->n_pairs;
     if (n_pairs == 0 || nf == 0 || ctx->slices.empty()) return DSA_OK;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->main_stream();
     static const bool no_reorder = [] { const char* e = getenv("DEFUSE_DSA_NO_REORDER"); return e && atoi(e) != 0; }();
     static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
     static const bool no_tighten = [] { const char* e = getenv("DEFUSE_DSA_NO_TIGHTEN"); return e && atoi(e) != 0; }();
@@ -322,7 +328,7 @@ int enqueue_plan(dsa_ctx* ctx)
             hipLaunchKernelGGL(k_plan_place_b, dim3((unsigned)nb), dim3(PLACE_BLOCK), 0, st, ctx->plan_order.p, ctx->plan_runs.p, nf, ctx->plan_bsum.p,
                                ctx->plan_start.p, ctx->plan_flip.p);
         }
-        hipLaunchKernelGGL(k_plan_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, ctx->plan_runs.p, ctx->plan_start.p,
+        hipLaunchKernelGGL(k_plan_permute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, ctx->d_fusions.p, ctx->plan_runs.p, ctx->plan_start.p,
                            ctx->plan_flip.p, ctx->plan_rank.p, ctx->plan_bound.p, glob, no_reorder ? 1 : 0, ctx->d_pairs.p + sl.pair_begin,
                            ctx->d_orig.p + sl.pair_begin);
     }
@@ -581,7 +587,13 @@ extern "C" {
 #endif
 // the last word is the hash of the sources and flags this library was built from (defuse_amd/build.py): profiles carry the
 // same hash, so a bench line can tell whether committed counters belong to the kernels that are running
-const char* dsa_version(void) { return "defuse_amd dsa 0.2 (gfx950) src " DSA_BUILD_HASH; }
+const char* dsa_version(void) { return "defuse_amd dsa 0.3 (gfx950) src " DSA_BUILD_HASH; }
+#ifndef DSA_BUILD_FLAGS
+#define DSA_BUILD_FLAGS "sched=unknown"
+#endif
+// what the split-read kernels were compiled with: "sched=<iterative-ilp|default> <compiler flags>" — the scheduler is the one
+// flag the fill kernel's speed depends on, and a compiler without it builds the library all the same (defuse_amd/build.py)
+const char* dsa_build_flags(void) { return DSA_BUILD_FLAGS; }
 
 int dsa_device_count(void)
 {
@@ -639,7 +651,10 @@ int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes)
     return DSA_OK;
 }
 
-int dsa_create(dsa_ctx** out, int device)
+// A context on `device`; with `share` it uses that context's pipeline lanes from the start (the slots of a dsa_stream: no
+// streams, events and pinned words of its own that dsa_share_scratch would throw away at once — creating a stream is
+// creating a hardware queue, tens of milliseconds each for the first few of a process).
+static int create_ctx(dsa_ctx** out, int device, dsa_ctx* share)
 {
     if (!out) return DSA_E_ARG;
     *out = nullptr;
@@ -648,18 +663,23 @@ int dsa_create(dsa_ctx** out, int device)
     if (hipSetDevice(device) != hipSuccess) return DSA_E_DEVICE;
     dsa_ctx* ctx = new dsa_ctx();
     ctx->device = device;
-    ctx->lanes = std::make_shared<LaneSet>();
-    ctx->lanes->device = device;
     bool ok = true;
-    for (int l = 0; l < 2; ++l) {
-        PipeLane& L = ctx->lanes->lane[l];
-        ok = ok && hipStreamCreate(&ctx->lanes->own[l]) == hipSuccess;
-        L.stream = ctx->lanes->own[l];
-        for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
+    if (share) {
+        ctx->lanes = share->lanes;
+        ctx->scratch_budget = share->scratch_budget;
+    } else {
+        ctx->lanes = std::make_shared<LaneSet>();
+        ctx->lanes->device = device;
+        for (int l = 0; l < 2; ++l) {
+            PipeLane& L = ctx->lanes->lane[l];
+            ok = ok && hipStreamCreate(&ctx->lanes->own[l]) == hipSuccess;
+            L.stream = ctx->lanes->own[l];
+            for (auto& e : L.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+            ok = ok && hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&L.host, sizeof(HostResult)) == hipSuccess;
+        }
     }
     for (auto& e : ctx->ev_pack) ok = ok && hipEventCreate(&e) == hipSuccess;
     for (auto& e : ctx->ev_plan) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -667,14 +687,16 @@ int dsa_create(dsa_ctx** out, int device)
         dsa_destroy(ctx);
         return DSA_E_DEVICE;
     }
-    ctx->stream = ctx->lanes->lane[0].stream;
-    if (const char* mb = getenv("DEFUSE_DSA_SCRATCH_MB")) {
-        long v = atol(mb);
-        if (v > 0) ctx->scratch_budget = (size_t)v << 20;
-    }
+    if (!share)
+        if (const char* mb = getenv("DEFUSE_DSA_SCRATCH_MB")) {
+            long v = atol(mb);
+            if (v > 0) ctx->scratch_budget = (size_t)v << 20;
+        }
     *out = ctx;
     return DSA_OK;
 }
+
+int dsa_create(dsa_ctx** out, int device) { return create_ctx(out, device, nullptr); }
 
 void dsa_destroy(dsa_ctx* ctx)
 {
@@ -703,7 +725,6 @@ int dsa_share_scratch(dsa_ctx* ctx, dsa_ctx* donor)
     HIPC(hipSetDevice(ctx->device));
     HIPC(hipDeviceSynchronize());
     ctx->lanes = donor->lanes;
-    ctx->stream = ctx->user_stream ? ctx->user_stream : ctx->lanes->lane[0].stream;
     ctx->scratch_budget = donor->scratch_budget;
     return DSA_OK;
 }
@@ -726,14 +747,13 @@ int dsa_set_stream(dsa_ctx* ctx, void* hip_stream)
     if (!ctx) return DSA_E_ARG;
     ctx->user_stream = (hipStream_t)hip_stream;
     ctx->lanes->lane[0].stream = hip_stream ? (hipStream_t)hip_stream : ctx->lanes->own[0];      // lane 1 keeps its private stream
-    ctx->stream = ctx->lanes->lane[0].stream;
     return DSA_OK;
 }
 
 int dsa_synchronize(dsa_ctx* ctx)
 {
     if (!ctx) return DSA_E_ARG;
-    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->main_stream()));
     return DSA_OK;
 }
 
@@ -757,6 +777,7 @@ int upload_enqueue(dsa_ctx* ctx, hipStream_t st, const uint8_t* ref_bytes, int64
     ctx->h_long.clear();
     ctx->h_long_fusions.clear();
     ctx->long_cells = 0;
+    ctx->long_blank_cells = 0;
     int nch_all = 1, maxwin = 0;
     for (int32_t f = 0; f < n_fusions; ++f) {
         const dsa_fusion& fu = fusions[f];
@@ -798,6 +819,7 @@ int upload_enqueue(dsa_ctx* ctx, hipStream_t st, const uint8_t* ref_bytes, int64
             d.min_score = min_score_for(pr.read_len);
             ctx->h_long.push_back(d);
             ctx->long_cells += (int64_t)(fu.ref0_len + 1 + fu.ref1_len + 1) * (pr.read_len + 1);
+            ctx->long_blank_cells += (fu.ref0_len > FAST_MAX_REF || fu.ref1_len > FAST_MAX_REF) ? 2 : fu.ref0_len + 1 + fu.ref1_len + 1;
             continue;
         }
         lqmax = std::max(lqmax, (int)pr.read_len);
@@ -861,9 +883,9 @@ int dsa_upload(dsa_ctx* ctx, const uint8_t* ref_bytes, int64_t ref_bytes_len, co
                int64_t n_pairs)
 {
     if (!ctx) return DSA_E_ARG;
-    if (int rc = upload_enqueue(ctx, ctx->stream, ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs)) return rc;
+    if (int rc = upload_enqueue(ctx, ctx->main_stream(), ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs)) return rc;
     if (int rc = enqueue_plan(ctx)) return rc;
-    HIPC(hipStreamSynchronize(ctx->stream));    // the caller's buffers are free again when dsa_upload returns
+    HIPC(hipStreamSynchronize(ctx->main_stream()));    // the caller's buffers are free again when dsa_upload returns
     HIPC(hipGetLastError());
     return DSA_OK;
 }
@@ -934,7 +956,7 @@ int run_long(dsa_ctx* ctx)
     hipLaunchKernelGGL(k_long_cols, dim3((unsigned)grid), dim3(LONG_THREADS), 0, st, ctx->d_long.p, ctx->d_long_state.p, nl, ctx->d_ref.p, ctx->d_reads.p,
                        ctx->d_long_work.p, ctx->d_long_rows.p, rows_max, ctx->d_long_bits.p);
     HIPC(hipGetLastError());
-    ctx->timing.cells += ctx->long_cells;
+    ctx->timing.cells += ctx->long_cells - ctx->long_blank_cells;
     return DSA_OK;
 }
 
@@ -1025,8 +1047,8 @@ int dsa_download(dsa_ctx* ctx, dsa_record* out, int64_t out_cap, int64_t* out_n)
     if (ctx->n_records > out_cap) return fail(ctx, DSA_E_CAPACITY, "need room for %lld records", (long long)ctx->n_records);
     if (ctx->n_records) {
         if (!out) return fail(ctx, DSA_E_ARG, "null output");
-        HIPC(hipMemcpyAsync(out, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToHost, ctx->stream));
-        HIPC(hipStreamSynchronize(ctx->stream));
+        HIPC(hipMemcpyAsync(out, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToHost, ctx->main_stream()));
+        HIPC(hipStreamSynchronize(ctx->main_stream()));
     }
     return DSA_OK;
 }
@@ -1038,8 +1060,8 @@ int dsa_copy_records_device(dsa_ctx* ctx, void* out_device, int64_t out_cap, int
     if (ctx->n_records > out_cap) return fail(ctx, DSA_E_CAPACITY, "need room for %lld records", (long long)ctx->n_records);
     if (ctx->n_records) {
         if (!out_device) return fail(ctx, DSA_E_ARG, "null output");
-        HIPC(hipMemcpyAsync(out_device, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, ctx->stream));
-        HIPC(hipStreamSynchronize(ctx->stream));
+        HIPC(hipMemcpyAsync(out_device, ctx->d_records.p, ctx->n_records * sizeof(dsa_record), hipMemcpyDeviceToDevice, ctx->main_stream()));
+        HIPC(hipStreamSynchronize(ctx->main_stream()));
     }
     return DSA_OK;
 }
@@ -1107,7 +1129,7 @@ void stream_worker(dsa_stream* s)
         dsa_ctx* ctx = s->slot[k % s->depth];
         dsa_stream::Job& j = s->job[k % s->depth];
         int64_t n = 0;
-        int rc = hipStreamWaitEvent(ctx->stream, j.ev_in, 0) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
+        int rc = hipStreamWaitEvent(ctx->main_stream(), j.ev_in, 0) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
         if (rc == DSA_OK) rc = enqueue_plan(ctx);
         if (rc == DSA_OK) rc = dsa_run(ctx, &n);
         j.copied = false;
@@ -1142,11 +1164,8 @@ int dsa_stream_create(dsa_stream** out, int device, int depth)
     bool ok = true;
     for (int k = 0; k < depth && ok; ++k) {
         dsa_ctx* c = nullptr;
-        ok = dsa_create(&c, device) == DSA_OK;
-        if (ok) {
-            s->slot.push_back(c);
-            if (k > 0) ok = dsa_share_scratch(c, s->slot[0]) == DSA_OK;
-        }
+        ok = create_ctx(&c, device, k > 0 ? s->slot[0] : nullptr) == DSA_OK;       // the slots share slot 0's pipeline lanes
+        if (ok) s->slot.push_back(c);
     }
     ok = ok && hipStreamCreateWithFlags(&s->s_in, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&s->s_out, hipStreamNonBlocking) == hipSuccess;
@@ -1278,6 +1297,18 @@ void* dsa_host_alloc(size_t bytes)
 void dsa_host_free(void* p)
 {
     if (p) (void)hipHostFree(p);
+}
+
+int dsa_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return DSA_E_ARG;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
+}
+
+int dsa_host_unregister(void* p)
+{
+    if (!p) return DSA_E_ARG;
+    return hipHostUnregister(p) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
 }
 
 }  // extern "C"

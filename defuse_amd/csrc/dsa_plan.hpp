@@ -237,7 +237,6 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     __shared__ int s_tile[2][PLAN_TILES];
     __shared__ unsigned s_best[PLAN_THREADS / 64];
     __shared__ int s_delta, s_delta_votes;
-    __shared__ unsigned long long s_cells;
 
     PlanRun run = runs[f];
     if (tid == 0) fidx[f] = f;
@@ -259,23 +258,16 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     const bool windows_ok = len0 >= PLAN_K && len0 < PLAN_MAXWIN && len1 >= PLAN_K && len1 < PLAN_MAXWIN;
     const bool full = n >= 2 && n <= PLAN_MAX && n <= 2 * slots && windows_ok && (prm.use_rank || prm.use_bound);
 
-    if (tid == 0) s_cells = 0;
     if (tid < 2 * PLAN_TILES) (&s_tile[0][0])[tid] = 0;
     if (!full) {
         // the caller's order inside the fusion, no bound, no tile vote
-        unsigned long long cells = 0;
         for (int k = tid; k < n; k += PLAN_THREADS) {
             rank[p0 + k] = k;
             bound_out[p0 + k] = 0;
-            cells += (unsigned long long)(pairs[p0 + k].read_len + 1);
         }
-        __syncthreads();
-        atomicAdd(&s_cells, cells);
-        __syncthreads();
         if (tid == 0) {
             runs[f].count = n;
             fkey[f] = plan_fusion_key(cls, 0, 255, 255);
-            atomicAdd(&glob->cells, s_cells * (unsigned long long)(len0 + 1 + len1 + 1));
         }
         return;
     }
@@ -436,14 +428,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
     PLAN_STAMP(3);
 
     // ---- per read: bound T', tile votes, sort key
-    unsigned long long cells = 0;
     for (int k = tid; k < n; k += PLAN_THREADS) {
         const bool first = k == tid;
         const dsa_pair pr = first ? pr_first : pairs[p0 + k];
         const ReadBits rb = first ? rb_first : load_read(pr);
         Diag dg = first ? dg_first : diagonals(rb);
         const int lq = pr.read_len;
-        cells += (unsigned long long)(lq + 1);
         // a read with one side only (its junction lies within a few bases of one end) takes the other diagonal from the
         // fusion's vote; any pair of diagonals gives a VALID bound below, a wrong guess only a weak one
         if (delta_votes > 0) {
@@ -511,7 +501,6 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         if (n <= 2 * PLAN_THREADS) keys_small[k] = key;
         else rank[p0 + k] = (int32_t)key;                  // parked in the output array until the tables are free
     }
-    atomicAdd(&s_cells, cells);
     __syncthreads();
     PLAN_STAMP(4);
 
@@ -559,7 +548,6 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
         }
         runs[f].count = n;
         fkey[f] = plan_fusion_key(cls, prm.use_lpt ? 4 - alive : 0, t[0], t[1]);
-        atomicAdd(&glob->cells, s_cells * (unsigned long long)(len0 + 1 + len1 + 1));
     }
 }
 
@@ -612,27 +600,38 @@ __global__ __launch_bounds__(PLACE_BLOCK) void k_plan_place_b(const int32_t* __r
 }
 
 // pair p of fusion f (one run) goes to sweep position new_start[f] + its rank inside the fusion (mirrored for every other
-// fusion); identity: the caller's order.  The bound travels in the padding bytes of the device copy.
-__global__ void k_plan_permute(const dsa_pair* __restrict__ pairs, int64_t n, const PlanRun* __restrict__ runs,
+// fusion); identity: the caller's order.  The bound travels in the padding bytes of the device copy.  The DP cells of the
+// slice (dsa_timing.cells: 2 matrices of (Lref + 1) x (Lread + 1)) are summed here, on every path — with or without a
+// sweep order, whatever the runs of the fusions look like.
+__global__ __launch_bounds__(256) void k_plan_permute(const dsa_pair* __restrict__ pairs, int64_t n, const dsa_fusion* __restrict__ fusions,
+                               const PlanRun* __restrict__ runs,
                                const int32_t* __restrict__ new_start, const uint8_t* __restrict__ flip, const int32_t* __restrict__ rank,
-                               const uint16_t* __restrict__ bound, const PlanGlobals* __restrict__ glob, int force_identity,
+                               const uint16_t* __restrict__ bound, PlanGlobals* __restrict__ glob, int force_identity,
                                dsa_pair* __restrict__ sweep, int32_t* __restrict__ orig)
 {
+    __shared__ unsigned long long s_cells[4];
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    dsa_pair pr = pairs[p];
-    int64_t q = p;
-    uint32_t b = 0;
-    if (!force_identity && glob->identity == 0) {
+    unsigned long long cells = 0;
+    if (p < n) {
+        dsa_pair pr = pairs[p];
         const int f = pr.fusion_idx;
-        const int r = rank[p], c = runs[f].count;
-        q = (int64_t)new_start[f] + (flip[f] ? c - 1 - r : r);
-        b = bound[p];
+        cells = (unsigned long long)(pr.read_len + 1) * (unsigned long long)(fusions[f].ref0_len + 1 + fusions[f].ref1_len + 1);
+        int64_t q = p;
+        uint32_t b = 0;
+        if (!force_identity && glob->identity == 0) {
+            const int r = rank[p], c = runs[f].count;
+            q = (int64_t)new_start[f] + (flip[f] ? c - 1 - r : r);
+            b = bound[p];
+        }
+        pr.pad_[0] = (uint8_t)(b & 0xFF);
+        pr.pad_[1] = (uint8_t)(b >> 8);
+        sweep[q] = pr;
+        orig[q] = (int32_t)p;
     }
-    pr.pad_[0] = (uint8_t)(b & 0xFF);
-    pr.pad_[1] = (uint8_t)(b >> 8);
-    sweep[q] = pr;
-    orig[q] = (int32_t)p;
+    for (int d = 32; d >= 1; d >>= 1) cells += __shfl_xor(cells, d, 64);
+    if ((threadIdx.x & 63) == 0) s_cells[threadIdx.x >> 6] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&glob->cells, s_cells[0] + s_cells[1] + s_cells[2] + s_cells[3]);
 }
 
 }  // namespace dsa

@@ -19,12 +19,13 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
                                              "ref_second", "read_first", "read_second", "score", "pair_idx")])
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
-EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
+EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_build_flags", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
            "dsa_upload", "dsa_plan", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize",
            "dsa_stream_create", "dsa_stream_destroy", "dsa_stream_submit", "dsa_stream_collect", "dsa_stream_recollect", "dsa_stream_last_error",
-           "dsa_host_alloc", "dsa_host_free"]
+           "dsa_host_alloc", "dsa_host_free", "dsa_host_register", "dsa_host_unregister"]
 
 DSA_E_CAPACITY = -1
+DSA_E_ARG = -3
 DSA_E_BUSY = -5
 
 
@@ -63,6 +64,7 @@ def load_library():
         lib.dsa_last_error.argtypes = [vp]
         lib.dsa_last_error.restype = ctypes.c_char_p
         lib.dsa_version.restype = ctypes.c_char_p
+        lib.dsa_build_flags.restype = ctypes.c_char_p
         batch = [vp, vp, i64, vp, i32, vp, i64, vp, i64]
         lib.dsa_align_batch.argtypes = batch + [vp, i64, ctypes.POINTER(i64)]
         lib.dsa_upload.argtypes = batch
@@ -88,6 +90,8 @@ def load_library():
         lib.dsa_host_alloc.restype = vp
         lib.dsa_host_free.argtypes = [vp]
         lib.dsa_host_free.restype = None
+        lib.dsa_host_register.argtypes = [vp, ctypes.c_size_t]
+        lib.dsa_host_unregister.argtypes = [vp]
         _lib = lib
     return _lib
 
@@ -290,17 +294,24 @@ class Stream:
         self._inflight.append((ref_bytes, fusions, read_bytes, pairs, out))
 
     def collect(self):
-        """Records of the oldest batch: a view of the `out` array of its submit (a fresh array if they did not fit)."""
+        """Records of the oldest batch: a view of the `out` array of its submit (a fresh array if they did not fit).
+        The C side has consumed the oldest batch on every return code except DSA_E_CAPACITY (it stays the oldest until
+        recollect took it) and the DSA_E_ARG of "nothing submitted": this side drops its entry in step, so that a caller
+        who catches a DsaError and carries on gets the following batches' own arrays."""
         n = ctypes.c_int64(0)
         rc = self.lib.dsa_stream_collect(self.h, ctypes.byref(n))
         if rc == DSA_E_CAPACITY:
             big = np.zeros(n.value, dtype=RECORD_DTYPE)
             rc = self.lib.dsa_stream_recollect(self.h, big.ctypes.data, len(big), ctypes.byref(n))
-            if rc != 0:
+            if rc == DSA_E_CAPACITY:          # (cannot happen with a buffer of the size just reported; the batch stays)
                 self._err(rc)
             self._inflight.pop(0)
+            if rc != 0:
+                self._err(rc)
             return big
         if rc != 0:
+            if self._inflight and rc != DSA_E_ARG:
+                self._inflight.pop(0)
             self._err(rc)
         out = self._inflight.pop(0)[4]
         return out[:n.value]

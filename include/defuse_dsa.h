@@ -91,7 +91,7 @@ typedef struct dsa_timing {
     float   total_ms;             /* elapsed host time of dsa_run (stage times overlap between slices) */
     int32_t fill_launches;        /* number of DP fill launches in fill_ms                       */
     int32_t n_generic_tasks;      /* of n_replay_tasks: tiles re-run by the generic replay kernel   */
-    int64_t cells;                /* DP cells filled: sum over pairs of 2*(Lref+1)*(Lread+1)     */
+    int64_t cells;                /* DP cells of the batch: sum over pairs of (Lref0+1 + Lref1+1)*(Lread+1), exact on every path */
     int64_t n_records;
     int64_t n_replay_tasks;       /* tiles re-run to enumerate tied columns                      */
     float   plan_ms;              /* the sweep planning that preceded this run (dsa_upload's or dsa_plan's) */
@@ -103,7 +103,10 @@ int  dsa_create(dsa_ctx** out, int device);     /* device = HIP ordinal; fails (
 void dsa_destroy(dsa_ctx* ctx);
 int  dsa_get_limits(const dsa_ctx* ctx, dsa_limits* out);
 const char* dsa_last_error(const dsa_ctx* ctx); /* human-readable text for the last failure      */
-const char* dsa_version(void);
+const char* dsa_version(void);                 /* "... src <hash of the sources and of the flags actually used>" */
+/* "sched=<iterative-ilp|default> <compiler flags>": the instruction scheduler the split-read kernels were built with (a
+ * compiler that lacks the flag still builds the library, with a slower fill kernel and another source hash). */
+const char* dsa_build_flags(void);
 /* HIP devices this process sees (0 without a GPU), and the ordinal a tool should use: DEFUSE_GPU if set, else
  * pid mod device count — the pipeline starts up to --parallel independent tool processes (scripts/defuse_run.pl:33,285;
  * SURVEY 8(b)), which spreads them over the GPUs of a node without any of them assuming it owns one. */
@@ -116,7 +119,8 @@ int dsa_pick_device_among(int n_devices);
 /* Upper bound of the per-slice scratch planes of one pipeline lane (default 16 GiB, or DEFUSE_DSA_SCRATCH_MB at
  * dsa_create): a caller that keeps several uploads resident side by side (one ctx each) sizes them with this. */
 int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes);
-/* ctx gives up its own pipeline lanes (streams, events, scratch planes) and uses donor's from now on; both must be on
+/* ctx gives up its own pipeline lanes (streams, events, scratch planes — and a stream given with dsa_set_stream: lane 0's
+ * stream is one per set of lanes, whoever of the sharers sets it) and uses donor's from now on; both must be on
  * the same device and must not run at the same time (dsa_run is synchronous, so a caller that runs its resident
  * uploads one after the other may let all of them share one set).  The lanes live until the last sharer is destroyed. */
 int dsa_share_scratch(dsa_ctx* ctx, dsa_ctx* donor);
@@ -180,6 +184,11 @@ const char* dsa_stream_last_error(const dsa_stream* s);
 /* pinned host memory for the buffers of a stream (NULL when it cannot be had) */
 void* dsa_host_alloc(size_t bytes);
 void  dsa_host_free(void* p);
+/* pins memory the caller already owns (e.g. a mapping it shares with another process) for the same purpose; pinning costs
+ * about 0.2 ms per MiB on an MI355X host, a copy from unpinned memory about 20 % more time than from pinned memory
+ * (profiles/r04/tools/fixed_costs.txt) — it pays for buffers that are reused many times */
+int   dsa_host_register(void* p, size_t bytes);
+int   dsa_host_unregister(void* p);
 
 #ifdef __cplusplus
 }

@@ -396,6 +396,44 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr)
 
 
+def test_stream_carries_on_after_a_failed_batch(built, ora):
+    """A batch of a stream that ends with a device / run error is consumed on the C side; the Python wrapper drops its entry
+    in step, so a caller that catches the DsaError gets the FOLLOWING batches' own records (round-3 advice: it used to
+    return views of the previous batch's array)."""
+    import subprocess
+    import sys
+    code = '''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from defuse_amd import dsa
+from oracle import dosplitalign_oracle as ora
+from tests import cases
+batches = [cases.mixed_batch(70 + k, n_fusions=3 + k, reads_per_fusion=30 + 10 * k, lq=40 + 5 * k, lr=(90, 200)) for k in range(4)]
+st = dsa.Stream(0, depth=2)
+outs = [np.zeros(4 * len(b[3]) + 64, dtype=dsa.RECORD_DTYPE) for b in batches]
+got, k_sub = [], 0
+for k in range(4):
+    while k_sub < 4 and k_sub - k < 2:
+        st.submit(*dsa._check_arrays(*batches[k_sub]), outs[k_sub])
+        k_sub += 1
+    try:
+        got.append(st.collect().copy())
+    except dsa.DsaError as e:
+        assert "injected" in str(e), e
+        got.append(None)
+assert got[1] is None and got[0] is not None, [g is None for g in got]     # the second run of the process fails
+for k in (0, 2, 3):
+    assert got[k].tobytes() == ora.align_batch(*batches[k]).tobytes(), k
+assert not st._inflight
+st.close()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, DEFUSE_DSA_TEST_FAIL_RUN="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr)
+
+
 def test_stream_of_batches_equals_the_oracle(built, ora):
     """The streaming entry points (what a tool that cuts its candidates into batches calls): seven different batches through
     a stream of depth 3 - pinned and ordinary host buffers, one batch whose records do not fit its buffer (collected

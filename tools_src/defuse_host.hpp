@@ -13,6 +13,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cerrno>
 #include <cctype>
 #include <cmath>
@@ -175,6 +178,85 @@ inline void run_threads(unsigned n, const std::function<void(unsigned)>& fn)
     for (std::thread& x : th) x.join();
 }
 
+// A team of n threads that lives as long as the object: run(fn) executes fn(t) for t = 0..n-1 (t = 0 on the caller) and
+// returns when all are done; inside fn, barrier() makes all n wait for each other.  The passes of a tool over one batch of
+// input (count, prefix, place, ...) run as ONE run() with barriers between them instead of a thread start per pass.
+class Team {
+public:
+    explicit Team(unsigned n) : n_(std::max(1u, n))
+    {
+        for (unsigned t = 1; t < n_; ++t) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~Team()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (std::thread& x : th_) x.join();
+    }
+    Team(const Team&) = delete;
+    Team& operator=(const Team&) = delete;
+    unsigned size() const { return n_; }
+    void run(const std::function<void(unsigned)>& fn)
+    {
+        if (n_ == 1) { fn(0); return; }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            pending_ = n_ - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    void barrier()
+    {
+        if (n_ == 1) return;
+        std::unique_lock<std::mutex> lk(bm_);
+        const unsigned g = bgen_;
+        if (++bcount_ == n_) {
+            bcount_ = 0;
+            ++bgen_;
+            bcv_.notify_all();
+        } else {
+            bcv_.wait(lk, [&] { return bgen_ != g; });
+        }
+    }
+    // [0, n) cut into the team's shares: the share of thread t
+    static size_t lo(size_t n, unsigned t, unsigned of) { return n * t / of; }
+private:
+    void loop(unsigned t)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)>* fn;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                fn = fn_;
+            }
+            (*fn)(t);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    const unsigned n_;
+    std::vector<std::thread> th_;
+    std::mutex m_, bm_;
+    std::condition_variable cv_, done_cv_, bcv_;
+    const std::function<void(unsigned)>* fn_ = nullptr;
+    unsigned gen_ = 0, pending_ = 0, bgen_ = 0, bcount_ = 0;
+    bool stop_ = false;
+};
+
 // 64-bit key -> 32-bit value, open addressing with linear probing (the bin pair tables of clustermatepairs: millions of
 // keys, looked up once per alignment); key ~0 is reserved.  find_or_add returns the slot's value reference and whether
 // the key was new.
@@ -237,20 +319,26 @@ struct MappedText {
     }
     void load(const std::string& name, const std::string& open_error)
     {
+        if (!try_load(name)) die(open_error + name);
+    }
+    // false: the file cannot be opened (or mapped); true otherwise, an empty file included.  "-" is stdin only when allowed.
+    bool try_load(const std::string& name, bool dash_is_stdin = true)
+    {
         FILE* in = stdin;
-        if (name != "-") {
+        if (name != "-" || !dash_is_stdin) {
             const int fd = open(name.c_str(), O_RDONLY);
-            if (fd < 0) die(open_error + name);
+            if (fd < 0) return false;
             struct stat st;
-            if (fstat(fd, &st) != 0) die(open_error + name);
+            if (fstat(fd, &st) != 0 || S_ISDIR(st.st_mode)) { close(fd); return false; }
             if (S_ISREG(st.st_mode) && st.st_size > 0) {
                 void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-                if (m == MAP_FAILED) die(open_error + name);
-                p = (char*)m; n = (size_t)st.st_size; mapped = true;
                 close(fd);
-                return;
+                if (m == MAP_FAILED) return false;
+                p = (char*)m; n = (size_t)st.st_size; mapped = true;
+                return true;
             }
             in = fdopen(fd, "rb");
+            if (!in) { close(fd); return false; }
         }
         for (;;) {
             if (cap - n < ((size_t)1 << 24)) {
@@ -263,6 +351,7 @@ struct MappedText {
             n += got;
         }
         if (in != stdin) fclose(in);
+        return true;
     }
     // one past the newline of the line that contains pos (or the end of the text)
     size_t line_end(size_t pos) const
@@ -313,8 +402,24 @@ public:
         for (int b : bad) ok_ = ok_ && !b;
         pos_ = at[texts.size()];
     }
+    // For a caller whose own threads write: reserves consecutive ranges for parts of the given sizes (in order) and returns
+    // where each begins; every thread then calls write_part with its own.  Not seekable: begin() returns false and the caller
+    // writes the parts in order with append().
+    bool seekable() const { return seekable_; }
+    std::vector<off_t> reserve_parts(const std::vector<size_t>& sizes)
+    {
+        std::vector<off_t> at(sizes.size());
+        for (size_t k = 0; k < sizes.size(); ++k) { at[k] = pos_; pos_ += (off_t)sizes[k]; }
+        return at;
+    }
+    void write_part(const char* p, size_t n, off_t at)
+    {
+        if (!write_all(p, n, at)) failed_.store(true, std::memory_order_relaxed);
+    }
+    void append(const char* p, size_t n) { ok_ = ok_ && write_all(p, n, -1); }
     bool close_file()
     {
+        if (failed_.load()) ok_ = false;
         if (fd_ >= 0 && close(fd_) != 0) ok_ = false;
         fd_ = -1;
         return ok_;
@@ -335,6 +440,7 @@ private:
     int fd_ = -1;
     off_t pos_ = 0;
     bool ok_ = true, seekable_ = true;
+    std::atomic<bool> failed_{false};
 };
 
 // A set of 64-bit keys for the hot de-duplication loops: open addressing, linear probing, grows at half full.
@@ -357,11 +463,18 @@ public:
         return x;
     }
     size_t size() const { return n_; }
+    // room for n keys without another rehash on the way there
+    void reserve(size_t n)
+    {
+        size_t want = slots_.size();
+        while (want < 2 * n + 2) want *= 2;
+        if (want > slots_.size()) grow(want);
+    }
 private:
     static constexpr uint64_t EMPTY = ~(uint64_t)0;
-    void grow()
+    void grow(size_t to = 0)
     {
-        std::vector<uint64_t> old(slots_.size() * 2, EMPTY);
+        std::vector<uint64_t> old(to ? to : slots_.size() * 2, EMPTY);
         old.swap(slots_);
         mask_ = slots_.size() - 1;
         n_ = 0;
@@ -381,6 +494,27 @@ inline void append_int(std::string& buf, long long v)
     do { *--p = (char)('0' + u % 10); u /= 10; } while (u);
     if (v < 0) *--p = '-';
     buf.append(p, (size_t)(tmp + sizeof tmp - p));
+}
+
+// the same text written at p (room for 11 bytes); returns one past the last byte
+inline char* put_int(char* p, int v)
+{
+    static const char D2[] = "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869"
+                             "707172737475767778798081828384858687888990919293949596979899";
+    uint32_t u = (uint32_t)v;
+    if (v < 0) { *p++ = '-'; u = 0u - u; }
+    const unsigned nd = u < 10 ? 1 : u < 100 ? 2 : u < 1000 ? 3 : u < 10000 ? 4 : u < 100000 ? 5 : u < 1000000 ? 6 : u < 10000000 ? 7 : u < 100000000 ? 8 : u < 1000000000 ? 9 : 10;
+    char* const e = p + nd;
+    char* q = e;
+    while (u >= 100) {
+        const unsigned r = u % 100;
+        u /= 100;
+        q -= 2;
+        std::memcpy(q, D2 + 2 * r, 2);
+    }
+    if (u >= 10) std::memcpy(q - 2, D2 + 2 * u, 2);
+    else q[-1] = (char)('0' + u);
+    return e;
 }
 
 // tools/Common.cpp:32-54
@@ -1121,6 +1255,160 @@ inline bool AddReads(const std::string& filename, ReadStore& reads, std::ostream
     fclose(in);
     return fatal->empty();
 }
+
+// The reads of one FASTQ file by ReadID, built by a team of threads from the mapped file: the same records, messages and
+// last-one-wins rule as AddReads / ReadStore above (tools/ReadStream.cpp:57-104, tools/SplitAlignment.cpp:253-264), but the
+// sequences stay where they are in the mapped text and the table is filled side by side.  The file is cut into one piece per
+// thread at line starts; a count of the newlines in front of every piece tells where its first whole record (four lines)
+// begins, so every record is parsed exactly once, by the piece it starts in.  A record that ends the reading (bad name, bad
+// end, ...) ends it for every later record too: the first such record in file order decides, as in a serial reader.
+class ReadTable {
+public:
+    bool load(const std::string& filename, Team& team, std::ostream& err, std::string* fatal)
+    {
+        const size_t dot = filename.find_last_of('.');
+        const std::string ext = filename.substr(dot + 1);
+        if (ext != "fastq" && ext != "fq") {
+            err << "Error: unrecognized extension " << ext << std::endl;
+            return false;
+        }
+        if (!text_.try_load(filename, false)) {
+            err << "Error: unable to open file " << filename << std::endl;
+            return false;
+        }
+        const unsigned np = (text_.size() < ((size_t)1 << 16)) ? 1u : team.size();
+        struct Entry { uint64_t off; uint32_t len; int frag; int end; };
+        struct Piece {
+            std::vector<Entry> entries;
+            size_t newlines = 0;
+            int stop = 0;                    // 0 none, 1 bad name, 2 bad end, 3 bad integer (fatal), 4 read too long (fatal)
+            std::string name;                // of the record that stopped the reading
+            int min_frag = INT_MAX, max_frag = INT_MIN;
+        };
+        std::vector<Piece> pieces(np);
+        const std::vector<size_t> cut = text_.cut_lines(0, text_.size(), np);
+        std::vector<size_t> lines_before(np + 1, 0);
+        const char* const txt = text_.data();
+        const size_t N = text_.size();
+        // a line exists at pos iff pos < N; it ends at the next newline or at N
+        auto line = [&](size_t pos, size_t& b, size_t& e, size_t& next) {
+            if (pos >= N) return false;
+            const char* nl = (const char*)memchr(txt + pos, '\n', N - pos);
+            b = pos;
+            e = nl ? (size_t)(nl - txt) : N;
+            next = nl ? e + 1 : N;
+            return true;
+        };
+        team.run([&](unsigned t) {
+            if (t >= np) { team.barrier(); return; }
+            Piece& pc = pieces[t];
+            pc.newlines = (size_t)std::count(txt + cut[t], txt + cut[t + 1], '\n');
+            team.barrier();
+            size_t before = 0;
+            for (unsigned u = 0; u < t; ++u) before += pieces[u].newlines;
+            size_t pos = cut[t], b, e, next;
+            for (size_t skip = (4 - before % 4) % 4; skip > 0; --skip) {
+                if (!line(pos, b, e, next)) return;
+                pos = next;
+            }
+            pc.entries.reserve((cut[t + 1] - cut[t]) / 128 + 16);
+            while (pos < cut[t + 1]) {
+                size_t nb, ne, sb, se, xb, xe;
+                if (!line(pos, nb, ne, next)) break;                       // records of four lines; an incomplete one ends the file
+                if (!line(next, sb, se, next)) break;
+                if (!line(next, xb, xe, next) || !line(next, xb, xe, next)) break;
+                pos = next;
+                const char* name = txt + nb;
+                const size_t nlen = ne - nb;
+                if (nlen == 0 || name[0] != '@') { pc.stop = 1; pc.name.assign(name, nlen); break; }
+                const char* slash = (const char*)memchr(name, '/', nlen);
+                const char endc = (slash && slash + 1 < name + nlen) ? slash[1] : '\0';
+                if (endc != '1' && endc != '2') { pc.stop = 2; pc.name.assign(name, nlen); break; }
+                int frag;
+                if (!field_int(name + 1, (size_t)(slash - name) - 1, frag)) { pc.stop = 3; pc.name.assign(name, nlen); break; }
+                if (se - sb >= ((size_t)1 << 24)) { pc.stop = 4; pc.name.assign(name, nlen); break; }
+                pc.entries.push_back(Entry{(uint64_t)sb, (uint32_t)(se - sb), frag, endc == '1' ? 0 : 1});
+                pc.min_frag = std::min(pc.min_frag, frag);
+                pc.max_frag = std::max(pc.max_frag, frag);
+            }
+        });
+        // the first stop in file order ends the file
+        unsigned used = np;
+        for (unsigned t = 0; t < np; ++t)
+            if (pieces[t].stop) { used = t + 1; break; }
+        size_t count = 0;
+        int min_frag = INT_MAX, max_frag = INT_MIN;
+        for (unsigned t = 0; t < used; ++t) {
+            count += pieces[t].entries.size();
+            min_frag = std::min(min_frag, pieces[t].min_frag);
+            max_frag = std::max(max_frag, pieces[t].max_frag);
+        }
+        if (used > 0 && pieces[used - 1].stop) {
+            const Piece& pc = pieces[used - 1];
+            if (pc.stop == 1) err << "Error: Unable to interpret read name " << pc.name << std::endl;
+            else if (pc.stop == 2) err << "Error: Unable to interpret read end " << pc.name << std::endl;
+            else if (pc.stop == 3) {
+                const size_t slash = pc.name.find_first_of('/');
+                *fatal = "Error: bad integer '" + pc.name.substr(1, slash - 1) + "' in read name " + pc.name;
+            } else *fatal = "Error: read longer than 16 M bases: " + pc.name;
+        }
+        if (count) {
+            // the table is relative to the smallest id of the file and as long as the ids are dense (at most eight slots per read
+            // stored, so its size follows the number of reads, not the largest id); ids beyond it go to a hash map
+            base_ = (int64_t)min_frag - ((int64_t)min_frag & 1023);
+            const uint64_t span = (uint64_t)((int64_t)max_frag - base_) * 2 + 2;
+            dense_n_ = (size_t)std::min<uint64_t>(span, 8 * (uint64_t)count + 4096);
+            dense_.reset(new std::atomic<uint64_t>[dense_n_]);
+            std::mutex sparse_mutex;
+            team.run([&](unsigned t) {
+                const unsigned nt = team.size();
+                for (size_t k = dense_n_ * t / nt; k < dense_n_ * (t + 1) / nt; ++k) dense_[k].store(0, std::memory_order_relaxed);
+                team.barrier();
+                for (unsigned u = t; u < used; u += nt)
+                    for (const Entry& en : pieces[u].entries) {
+                        const uint64_t v = (en.off << 24) | (uint64_t)en.len;          // a later record has the larger offset: max = last wins
+                        const uint64_t k = (uint64_t)((int64_t)en.frag - base_) * 2 + (uint64_t)en.end;
+                        if (k < dense_n_) {
+                            uint64_t cur = dense_[k].load(std::memory_order_relaxed);
+                            while (cur < v && !dense_[k].compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+                        } else {
+                            std::lock_guard<std::mutex> lk(sparse_mutex);
+                            uint64_t& slot = sparse_[pack_id(en.frag, en.end)];
+                            slot = std::max(slot, v);
+                        }
+                    }
+            });
+        }
+        return fatal->empty();
+    }
+    // false: no such read (it then aligns as the empty string, tools/SplitAlignment.cpp:286)
+    bool get(int frag, int end, const char*& s, size_t& n) const
+    {
+        uint64_t v = 0;
+        const int64_t rel = (int64_t)frag - base_;
+        if (rel >= 0 && (uint64_t)rel * 2 + (uint64_t)end < dense_n_) v = dense_[(size_t)rel * 2 + (size_t)end].load(std::memory_order_relaxed);
+        else if (!sparse_.empty()) {
+            auto it = sparse_.find(pack_id(frag, end));
+            if (it != sparse_.end()) v = it->second;
+        }
+        if (v == 0) return false;             // (a sequence never starts at offset 0 of its file: its name line comes first)
+        s = text_.data() + (v >> 24);
+        n = (size_t)(v & 0xFFFFFF);
+        return true;
+    }
+    size_t table_slots() const { return dense_n_; }
+private:
+    MappedText text_;
+    std::unique_ptr<std::atomic<uint64_t>[]> dense_;
+    size_t dense_n_ = 0;
+    std::unordered_map<int, uint64_t> sparse_;
+    int64_t base_ = 0;
+};
+
+struct ReadTablePair {
+    ReadTable file[2];
+    bool get(int frag, int end, const char*& s, size_t& n) const { return file[1].get(frag, end, s, n) || file[0].get(frag, end, s, n); }
+};
 
 // One SAM line (tools/AlignmentStream.cpp:39-130).  Returns 0 = a record, 1 = nothing to return (header line, rname "*"),
 // 2.. = the reference dies: 2 empty line, 3 fewer than ten fields, 4 flag or position not an integer, 5 qname "x/y" with y
