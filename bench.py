@@ -34,8 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MIN_TIMED_S = 1.0          # the timed region is at least this long whatever --steps says ("steps" reports what ran)
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+MIN_TIMED_S = 3.0          # the timed region is at least this long whatever --steps says ("steps" reports what ran)
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
 WORKLOADS = {"config2": dict(fusions=10000, reads=100, lq=76, lr=389),
              "config4": dict(fusions=1000000, reads=200, lq=100, lr=390)}
 UPLOAD_FUSIONS = 50000     # fusions per upload of a multi-upload share: 10 M aligns, 1 GB of read bytes at config 4
@@ -46,6 +46,25 @@ def library_hash():
     from defuse_amd import dsa
     lib = dsa.load_library()
     return lib.dsa_version().decode().split()[-1]
+
+
+def library_build_flags():
+    from defuse_amd import dsa
+    return dsa.load_library().dsa_build_flags().decode()
+
+
+def hip_runtime_mapped():
+    """The libamdhip64 this process has mapped.  PyTorch-ROCm brings its own copy under the same SONAME as the system one the
+    library links to; whichever is loaded first serves both, and exactly one may be mapped — two copies would mean two HIP
+    runtimes with two sets of streams and contexts behind one process's kernels."""
+    paths = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                paths.add(line.split()[-1])
+    if len(paths) != 1:
+        raise SystemExit("bench.py: expected exactly one libamdhip64 in this process, found %s" % (sorted(paths) or "none"))
+    return paths.pop()
 
 
 def profile_block(name, workload, lib_hash):
@@ -65,12 +84,12 @@ def profile_block(name, workload, lib_hash):
     return d, os.path.relpath(path, ROOT)
 
 
-def valu_issue(workload, lib_hash, launch_ms):
+def valu_issue(workload, lib_hash, launch_ms, suffix=""):
     """The unit that binds this integer kernel (not HBM, not MFMA) is VALU issue.  Wave instructions per launch
     by kind come from the SQ counter passes of this build (pmc_sq.json); the duration is this run's HIP-event time; the
     peak prices every kind at its measured issue rate (profiles/microbench/valu_rate*.hip: 2 cycles per wave for
     v_add_u32 / v_sub / v_xor and the other plain VOP2 integer ops, 4 for VOP3P and max3), per SIMD, at the nominal 2.4 GHz."""
-    d, src = profile_block("pmc_sq.json", workload, lib_hash)
+    d, src = profile_block("pmc_sq%s.json" % suffix, workload, lib_hash)
     if d is None:
         return None, src
     n = d["launches"]
@@ -119,6 +138,59 @@ def cpu_baseline(ref, fus, reads, pairs, budget_s=12.0):
     return {"value": total / dt, "unit": "aligns/s", "cores": len(chunks), "kind": "port",
             "sample": "first %d aligns of the same batch in %d shares, oracle/dsa_oracle.c, one thread per share, %.1f s "
                       "(one thread alone: %.0f aligns/s)" % (total, len(chunks), dt, 1.0 / per)}, res[0], len(chunks[0])
+
+
+def oracle_records(batch, n_pairs, threads=16):
+    """The CPU oracle's records of the first n_pairs pairs of a batch (the checker of the sensitivity legs), on host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from oracle import dosplitalign_oracle as ora
+    ref, fus, reads, pairs = batch
+    per = -(-n_pairs // threads)
+    chunks = [(k, pairs[k:min(n_pairs, k + per)]) for k in range(0, n_pairs, per)]
+    with ThreadPoolExecutor(max_workers=len(chunks)) as ex:
+        res = list(ex.map(lambda c: ora.align_batch(ref, fus, reads, c[1]), chunks))
+    for (k, _), r in zip(chunks, res):
+        r["pair_idx"] += k
+    return np.concatenate(res)
+
+
+def sensitivity(dsa, synth, main_ctx, workload, main_batch, min_s=0.5, check_pairs=20000):
+    """Secondary legs beside the headline, never the value: the headline batch makes EVERY read cross the junction, which is
+    the friendliest case for the exact pruning (DoAlignment really enumerates every mate whose partner falls in a mate region,
+    tools/SplitAlignment.cpp:266-303).  Each leg: plan + run per step on a resident batch of the same sizes, its records
+    compared with the CPU oracle on the first pairs."""
+    import numpy as np
+    legs = {}
+    F, P, lq, lr = workload["fusions"], workload["reads"], workload["lq"], workload["lr"]
+    specs = [("decoys_50pct", dict(decoy_frac=0.5), 0, "half of the reads replaced by random sequence (candidates that do not align)"),
+             ("inside_one_window_50pct", dict(inside_frac=0.5), 0, "half of the reads lie wholly inside one window (one matrix scores 2 Lq, the other side stays zero)"),
+             ("no_per_pair_bound", None, dsa.PLAN_NO_TIGHTEN, "the headline batch without the per-pair score bounds (pruning against minScore only)")]
+    for name, kw, flags, what in specs:
+        batch = main_batch if kw is None else synth.make_batch(F, P, lq=lq, lr=lr, seed=2, **kw)
+        ctx = dsa.Context(main_ctx.device)
+        ctx.share_scratch(main_ctx)
+        ctx.set_plan_options(flags)
+        ctx.upload(*batch)
+        n_rec = ctx.run()
+        t = ctx.timing()
+        got = ctx.download()
+        nchk = min(check_pairs, len(batch[3]))
+        exp = oracle_records(batch, nchk)
+        if got[got["pair_idx"] < nchk].tobytes() != exp.tobytes():
+            raise SystemExit("bench.py: sensitivity leg %s: GPU records differ from the oracle on the sample" % name)
+        k, dt = 0, 0.0
+        t0 = time.perf_counter()
+        while dt < min_s:
+            ctx.plan()
+            ctx.run()
+            k += 1
+            dt = time.perf_counter() - t0
+        t = ctx.timing()
+        legs[name] = {"aligns_per_s": len(batch[3]) * k / dt, "ms_per_step": dt / k * 1e3, "steps": k, "fill_ms": t.fill_ms, "plan_ms": t.plan_ms,
+                      "finish_ms": t.finish_ms, "records_per_align": round(n_rec / len(batch[3]), 4), "oracle_checked_pairs": nchk, "what": what}
+        ctx.close()
+    return legs
 
 
 def one_shot(ctx, batch, reps=5, stream_batches=12, depth=3):
@@ -309,6 +381,7 @@ def main():
     ap.add_argument("--lq", type=int, default=None)
     ap.add_argument("--lr", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the secondary workload-mix legs (N = 1)")
     ap.add_argument("--dump-records", default=None, help="N > 1: rank 0 writes the gathered records of the job (numpy .npy) here")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 passes: exactly --steps timed steps and nothing else (no minimum duration, no resident re-run, "
@@ -394,6 +467,20 @@ def main():
     n_rec = 0
     for _ in range(args.warmup):
         n_rec, _ = share.run()
+    hip_path = hip_runtime_mapped()       # after the first kernels of both torch and the library: one runtime serves them
+    # The CPU baseline runs BEFORE the timed GPU region (rank 0, N = 1): ten seconds of host threads at the end of the run
+    # would leave the GPU idle in every utilisation sample an observer takes there.
+    base = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline and not args.profile_run:
+        if not args.warmup:
+            n_rec, _ = share.run()
+        ref, fus, reads, pairs = share.first_batch
+        base, ora_recs, n_checked = cpu_baseline(ref, fus, reads, pairs)
+        got = share.ctxs[0].download()
+        got = got[got["pair_idx"] < n_checked]
+        base["gpu_records_equal_on_first_share"] = bool(got.tobytes() == ora_recs.tobytes())
+        if not base["gpu_records_equal_on_first_share"]:
+            raise SystemExit("bench.py: GPU records differ from the oracle on the sample")
     steps_requested = steps
     elapsed, stage = timed(steps)
     if elapsed < MIN_TIMED_S and not args.profile_run:
@@ -444,14 +531,41 @@ def main():
         aligns_per_launch = share.total_pairs / max(1.0, n_launch)
         achieved = bytes_per_align * aligns_per_launch / (launch_ms * 1e-3) / 1e9
         cells = synth.cells_per_align(workload["lq"], workload["lr"])
-        tr, tr_src = profile_block("pmc_traffic.json", workload, lib_hash)
+        # counters are per launch: a launch is one upload (the whole batch at N = 1, UPLOAD_FUSIONS fusions of the configs[3] shape else)
+        per_upload = dict(workload, fusions=share.n_pairs[0] // workload["reads"])
+        suffix = "" if name == "config2" and not multi else "_config4"
+        tr, tr_src = profile_block("pmc_traffic%s.json" % suffix, per_upload, lib_hash)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
-        vi, vi_src = valu_issue(workload, lib_hash, launch_ms)
+        vi, vi_src = valu_issue(per_upload, lib_hash, launch_ms, suffix)
+        hbm = {"hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
+               "hbm_traffic_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None}
+        if vi:
+            # the unit that binds this integer kernel: VALU issue slots (4 cycles per wave instruction and SIMD, flat)
+            roof = {"bound": "valu_issue", "achieved": vi["issue_cycles_flat4"], "peak": vi["kernel_cycles_nominal"], "unit": "issue cycles per SIMD and launch (2.4 GHz nominal)",
+                    "frac": vi["frac_flat4"]}
+        else:
+            # no counters of this build at hand: the line can only answer the metric's HBM question
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+        roof.update(hbm)
+        roof.update({"traffic": traffic, "traffic_source": tr_src,
+                     "traffic_over_algorithmic": (traffic / (bytes_per_align * aligns_per_launch)) if traffic else None,
+                     "kernel": "k_fill_fast", "kernel_ms": launch_ms, "launches_per_step": n_launch,
+                     "algorithmic_bytes_per_align": round(bytes_per_align, 2),
+                     "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
+                     "valu_issue": vi, "valu_issue_source": vi_src, "library_source_hash": lib_hash,
+                     "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)) - frac prices every VALU wave instruction at "
+                             "4 issue cycles; the hbm_* fields answer the metric's HBM question (algorithmic bytes / kernel time against 8 TB/s); traffic >> "
+                             "algorithmic bytes because tile checkpoints and tile maxima (needed for exact tie enumeration) stream through HBM, see "
+                             "DESIGN.md 5; traffic / valu_issue are null unless the committed counters carry this library's source hash"})
         out = {
             "metric": "split-read DP aligns/sec", "value": total_aligns / elapsed, "unit": "aligns/s",
             "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "scaling_note": "N > 1 splits ONE job (BASELINE configs[3], 200 M aligns) over the GPUs; the default N = 1 line runs BASELINE configs[1] "
+                            "(1 M aligns of another shape): the N = 1 point of the configs[3] curve is `bench.py --gpus 1 --workload config4`, and every "
+                            "N > 1 line carries it per GPU as strong_scaling.n1_aligns_per_s",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic", "sched": library_build_flags().split()[0].split("=", 1)[-1],
+            "hip_runtime": hip_path,
             "config": {"workload": "BASELINE %s%s: %s synthetic candidate fusions x %d reads, 2x%d bp (Lref %d), split-read DP + split search, "
                                    "bit-exact; whole job = %d aligns per step" % (
                                        "configs[1]" if name == "config2" else "configs[3]", " (custom sizes)" if custom else "",
@@ -460,18 +574,7 @@ def main():
                        "aligns_per_step_this_gpu": share.total_pairs, "uploads_this_gpu": len(share.ctxs), "cells_per_align": cells,
                        "records_per_align": round(rec_per_align, 4), "job_records": job_records,
                        "parallelism": "contiguous fusion ranges over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tr_src,
-                         "traffic_over_algorithmic": (traffic / (bytes_per_align * aligns_per_launch)) if traffic else None,
-                         "kernel": "k_fill_fast", "kernel_ms": launch_ms, "launches_per_step": n_launch,
-                         "algorithmic_bytes_per_align": round(bytes_per_align, 2),
-                         "gcups_kernel": cells * aligns_per_launch / (launch_ms * 1e-3) / 1e9,
-                         "binding_unit": "valu_issue",      # what limits this integer kernel; "bound"/"frac" above answer the metric's HBM question
-                         "binding_frac": (vi or {}).get("frac_flat4"),
-                         "valu_issue": vi, "valu_issue_source": vi_src, "library_source_hash": lib_hash,
-                         "note": "integer DP: the binding unit is VALU issue, not HBM or MFMA (SURVEY 8(d)); traffic >> algorithmic "
-                                 "bytes because tile checkpoints and tile maxima (needed for exact tie enumeration) stream through HBM, "
-                                 "see DESIGN.md 5; traffic / valu_issue are null unless the committed counters carry this library's source hash"},
+            "roofline": roof,
             "step": "dsa_plan + dsa_run per upload: sweep planning (fusion order, in-fusion order, per-pair score bounds), reference "
                     "packing, DP fill with combine / replay in its tail, left-over replay, count, scan, emit; inputs resident in HBM",
             "stage_ms": {"plan": float(np.mean(plan_ms)), "pack": float(np.mean(pack_ms)), "fill": float(np.mean(fill_ms)),
@@ -487,15 +590,15 @@ def main():
             out["job_aligns_per_s_with_one_gather"] = total_aligns / (elapsed + steps * gather["ms"] * 1e-3)
         if alone is not None:
             out["one_gpu_same_share"] = alone
-        if world == 1 and not args.no_cpu_baseline and not args.profile_run:
-            ref, fus, reads, pairs = share.first_batch
-            base, ora_recs, n_checked = cpu_baseline(ref, fus, reads, pairs)
-            got = share.ctxs[0].download()
-            got = got[got["pair_idx"] < n_checked]
-            base["gpu_records_equal_on_first_share"] = bool(got.tobytes() == ora_recs.tobytes())
-            if not base["gpu_records_equal_on_first_share"]:
-                raise SystemExit("bench.py: GPU records differ from the oracle on the sample")
+            out["strong_scaling"] = {"n_gpus": world, "aligns_per_s": total_aligns / elapsed, "n1_aligns_per_s": alone["aligns_per_s"],
+                                     "efficiency": alone["efficiency_vs_this"],
+                                     "n1_measured_on": "the same workload in this run: rank 0's share (1/%d of the job, same shape and upload size) repeated with the "
+                                                       "other ranks idle; a GPU runs its uploads one after the other, so the whole job on one GPU runs at this rate "
+                                                       "(`bench.py --gpus 1 --workload config4` measures exactly that)" % world}
+        if base is not None:
             out["cpu_baseline"] = base
+        if world == 1 and len(share.ctxs) == 1 and not args.profile_run and not multi and not args.no_sensitivity:
+            out["sensitivity"] = sensitivity(dsa, synth, share.ctxs[0], workload, share.first_batch)
         if world == 1 and len(share.ctxs) == 1 and not args.profile_run:
             out["one_shot"] = one_shot(share.ctxs[0], share.first_batch)
         print(json.dumps(out), flush=True)

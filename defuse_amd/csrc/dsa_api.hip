@@ -147,6 +147,7 @@ struct dsa_ctx {
     hipStream_t user_stream = nullptr;
     std::string err;
     size_t scratch_budget = (size_t)16 << 30;
+    unsigned plan_flags = 0;         // DSA_PLAN_NO_*: parts of the sweep planning switched off (dsa_set_plan_options; DEFUSE_DSA_NO_* at creation)
 
     // resident batch
     int64_t n_pairs = 0, ref_bytes_len = 0, read_bytes_len = 0;
@@ -279,10 +280,8 @@ int enqueue_plan(dsa_ctx* ctx)
     const int64_t n_pairs = ctx->n_pairs;
     if (n_pairs == 0 || nf == 0 || ctx->slices.empty()) return DSA_OK;
     hipStream_t st = ctx->main_stream();
-    static const bool no_reorder = [] { const char* e = getenv("DEFUSE_DSA_NO_REORDER"); return e && atoi(e) != 0; }();
-    static const bool no_rank = [] { const char* e = getenv("DEFUSE_DSA_NO_RANK"); return e && atoi(e) != 0; }();
-    static const bool no_tighten = [] { const char* e = getenv("DEFUSE_DSA_NO_TIGHTEN"); return e && atoi(e) != 0; }();
-    static const bool no_lpt = [] { const char* e = getenv("DEFUSE_DSA_NO_LPT"); return e && atoi(e) != 0; }();
+    const bool no_reorder = ctx->plan_flags & DSA_PLAN_NO_REORDER, no_rank = ctx->plan_flags & DSA_PLAN_NO_RANK,
+               no_tighten = ctx->plan_flags & DSA_PLAN_NO_TIGHTEN, no_lpt = ctx->plan_flags & DSA_PLAN_NO_LPT;
     int64_t max_chunk = 0;
     for (const Slice& sl : ctx->slices) max_chunk = std::max(max_chunk, sl.pair_end - sl.pair_begin);
     const int nb = (nf + PLACE_BLOCK - 1) / PLACE_BLOCK;
@@ -644,6 +643,13 @@ int dsa_pick_device(void)
     return dsa_pick_device_among(dsa_device_count());
 }
 
+int dsa_set_plan_options(dsa_ctx* ctx, unsigned flags)
+{
+    if (!ctx || (flags & ~(DSA_PLAN_NO_REORDER | DSA_PLAN_NO_RANK | DSA_PLAN_NO_TIGHTEN | DSA_PLAN_NO_LPT))) return DSA_E_ARG;
+    ctx->plan_flags = flags;
+    return DSA_OK;
+}
+
 int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes)
 {
     if (!ctx || bytes <= 0) return DSA_E_ARG;
@@ -664,6 +670,11 @@ static int create_ctx(dsa_ctx** out, int device, dsa_ctx* share)
     dsa_ctx* ctx = new dsa_ctx();
     ctx->device = device;
     bool ok = true;
+    for (const auto& sw : {std::pair<const char*, unsigned>{"DEFUSE_DSA_NO_REORDER", DSA_PLAN_NO_REORDER}, {"DEFUSE_DSA_NO_RANK", DSA_PLAN_NO_RANK},
+                           {"DEFUSE_DSA_NO_TIGHTEN", DSA_PLAN_NO_TIGHTEN}, {"DEFUSE_DSA_NO_LPT", DSA_PLAN_NO_LPT}}) {
+        const char* e = getenv(sw.first);
+        if (e && atoi(e) != 0) ctx->plan_flags |= sw.second;
+    }
     if (share) {
         ctx->lanes = share->lanes;
         ctx->scratch_budget = share->scratch_budget;

@@ -19,11 +19,12 @@ RECORD_DTYPE = np.dtype([(n, "<i4") for n in ("fusion_id", "frag", "read_end", "
                                              "ref_second", "read_first", "read_second", "score", "pair_idx")])
 assert FUSION_DTYPE.itemsize == 20 and PAIR_DTYPE.itemsize == 20 and RECORD_DTYPE.itemsize == 40
 
-EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_build_flags", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
+EXPORTS = ["dsa_create", "dsa_destroy", "dsa_get_limits", "dsa_last_error", "dsa_version", "dsa_build_flags", "dsa_device_count", "dsa_pick_device", "dsa_pick_device_among", "dsa_set_plan_options", "dsa_set_scratch_budget", "dsa_share_scratch", "dsa_align_batch",
            "dsa_upload", "dsa_plan", "dsa_run", "dsa_download", "dsa_copy_records_device", "dsa_get_timing", "dsa_set_stream", "dsa_synchronize",
            "dsa_stream_create", "dsa_stream_destroy", "dsa_stream_submit", "dsa_stream_collect", "dsa_stream_recollect", "dsa_stream_last_error",
            "dsa_host_alloc", "dsa_host_free", "dsa_host_register", "dsa_host_unregister"]
 
+PLAN_NO_REORDER, PLAN_NO_RANK, PLAN_NO_TIGHTEN, PLAN_NO_LPT = 1, 2, 4, 8
 DSA_E_CAPACITY = -1
 DSA_E_ARG = -3
 DSA_E_BUSY = -5
@@ -76,6 +77,7 @@ def load_library():
         lib.dsa_set_stream.argtypes = [vp, vp]
         lib.dsa_synchronize.argtypes = [vp]
         lib.dsa_set_scratch_budget.argtypes = [vp, i64]
+        lib.dsa_set_plan_options.argtypes = [vp, ctypes.c_uint]
         lib.dsa_share_scratch.argtypes = [vp, vp]
         lib.dsa_pick_device_among.argtypes = [ctypes.c_int]
         lib.dsa_stream_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int]
@@ -134,6 +136,12 @@ class Context:
         lim = Limits()
         self.lib.dsa_get_limits(self.h, ctypes.byref(lim))
         return lim
+
+    def set_plan_options(self, flags):
+        """dsa_set_plan_options: PLAN_NO_* bits; effective from the next upload() / plan()."""
+        rc = self.lib.dsa_set_plan_options(self.h, int(flags))
+        if rc != 0:
+            self._err(rc)
 
     def set_scratch_budget(self, nbytes):
         rc = self.lib.dsa_set_scratch_budget(self.h, int(nbytes))

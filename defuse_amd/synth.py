@@ -21,10 +21,13 @@ def window_length(ufrag, sfrag, min_read, max_read, region_len):
 
 
 def make_batch(n_fusions, reads_per_fusion, lq=76, lr=389, seed=2, sub_rate=0.01, n_rate=0.005,
-               decoy_frac=0.0):
+               decoy_frac=0.0, inside_frac=0.0):
     """Returns (ref_bytes, fusions, read_bytes, pairs) as numpy arrays in the C-ABI layout.
 
-    decoy_frac: fraction of reads replaced by random sequence (candidates that do not align)."""
+    decoy_frac: fraction of reads replaced by random sequence (candidates that do not align);
+    inside_frac: fraction of reads that lie wholly inside one of the two windows, nowhere near the junction — what most of the
+    mates DoAlignment enumerates look like (tools/SplitAlignment.cpp:266-303 takes every mate whose partner falls in a mate
+    region): one matrix scores 2 * lq, the other side stays below the split minimum (the zero-side rule)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     F, P = int(n_fusions), int(reads_per_fusion)
     ref = _ACGT[rng.integers(0, 4, size=(F, 2, lr), dtype=np.uint8)]
@@ -58,6 +61,11 @@ def make_batch(n_fusions, reads_per_fusion, lq=76, lr=389, seed=2, sub_rate=0.01
     if has_n.any():
         rows = np.nonzero(has_n)[0]
         reads[rows, rng.integers(0, lq, size=rows.size)] = ord("N")
+    if inside_frac > 0:
+        ins = np.nonzero(rng.random(size=n) < inside_frac)[0]
+        side = rng.integers(0, 2, size=ins.size)
+        start = rng.integers(0, lr - lq + 1, size=ins.size)
+        reads[ins] = ref_bytes[(fidx[ins] * 2 * lr + side * lr + start)[:, None] + k]
     if decoy_frac > 0:
         dec = np.nonzero(rng.random(size=n) < decoy_frac)[0]
         reads[dec] = _ACGT[rng.integers(0, 4, size=(dec.size, lq), dtype=np.uint8)]

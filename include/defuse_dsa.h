@@ -116,6 +116,15 @@ int dsa_pick_device(void);
  * ($DEFUSE_GPU_LOCK_DIR or /tmp)/defuse_gpu.<d>.lock this process can take with flock (kept until the process ends);
  * pid mod n when all are taken.  Up to n concurrent tool processes therefore use n different GPUs. */
 int dsa_pick_device_among(int n_devices);
+/* The sweep planning (order of the fusions and of a fusion's pairs, per-pair score bounds) is a speed heuristic: any order
+ * and any true lower bound give the same records.  Its parts can be switched off per context — for measurements of what
+ * each is worth and for tests; a new context starts from the environment (DEFUSE_DSA_NO_REORDER / _NO_RANK / _NO_TIGHTEN /
+ * _NO_LPT = 1).  Takes effect with the next dsa_upload / dsa_plan. */
+#define DSA_PLAN_NO_REORDER  1u   /* the caller's pair order, no bounds                              */
+#define DSA_PLAN_NO_RANK     2u   /* no ordering of a fusion's pairs by their estimated read split   */
+#define DSA_PLAN_NO_TIGHTEN  4u   /* no per-pair score bound: pruning against minScore only          */
+#define DSA_PLAN_NO_LPT      8u   /* no cost ranking of the fusions inside a size class              */
+int dsa_set_plan_options(dsa_ctx* ctx, unsigned flags);
 /* Upper bound of the per-slice scratch planes of one pipeline lane (default 16 GiB, or DEFUSE_DSA_SCRATCH_MB at
  * dsa_create): a caller that keeps several uploads resident side by side (one ctx each) sizes them with this. */
 int dsa_set_scratch_budget(dsa_ctx* ctx, int64_t bytes);

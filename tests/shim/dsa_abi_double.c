@@ -49,6 +49,22 @@ int dsa_stream_submit(dsa_stream* s, const uint8_t* ref_bytes, int64_t ref_bytes
     s->job[k].full = NULL;
     s->job[k].out = out;
     s->job[k].out_cap = out_cap;
+    if (getenv("DSA_DOUBLE_FAKE")) {
+        /* host-side profiling without a GPU (profiles/microbench/tool_host_profile.sh): no alignment at all, every pair gets one
+         * made-up record (two for every third pair) so that formatting and writing have their usual amount of work */
+        for (int64_t p = 0; p < n_pairs; p++)
+            for (int r = 0; r < (p % 3 == 0 ? 2 : 1); r++) {
+                if (n < out_cap) {
+                    dsa_record* o = &out[n];
+                    o->fusion_id = fusions[pairs[p].fusion_idx].fusion_id; o->frag = pairs[p].frag; o->read_end = pairs[p].read_end; o->revcomp = pairs[p].revcomp;
+                    o->ref_first = 200 + r; o->ref_second = 150; o->read_first = 37; o->read_second = 38; o->score = 70; o->pair_idx = (int32_t)p;
+                }
+                n++;
+            }
+        s->job[k].n = n < out_cap ? n : out_cap;
+        s->n_submitted++;
+        return DSA_OK;
+    }
     int rc = ora_align_batch(ref_bytes, ref_bytes_len, fusions, n_fusions, read_bytes, read_bytes_len, pairs, n_pairs, out, out_cap, &n);
     if (rc == DSA_E_CAPACITY) {
         s->job[k].full = (dsa_record*)malloc(sizeof(dsa_record) * (size_t)n);

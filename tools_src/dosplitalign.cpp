@@ -102,7 +102,7 @@ struct Channel {
     struct Slot {
         int64_t ref_len, read_len, n_pairs, n_records;
         int32_t n_fusions, rc;
-        double t_submit, t_done;       // worker's clock: submit call entered, records in place
+        double t_submit, t_submitted, t_done;       // worker's clock: submit call entered / returned, records in place
     } slot[DEPTH];
     double t_start, t_loaded, t_stream, t_ready;     // worker's clock (same steady clock as the main process: one machine)
 };
@@ -116,12 +116,28 @@ struct Regions {
     dsa_pair* pairs[DEPTH];
     dsa_record* recs[DEPTH];
     size_t cap_ref = 0, cap_reads = 0, cap_fusions = 0, cap_pairs = 0, cap_recs = 0;      // elements
+    size_t hint_pairs = 0, hint_read_bytes = 0;       // what a batch usually holds: that much is made to exist ahead of its use
 };
 
 void* map_shared(size_t bytes)
 {
     void* p = mmap(nullptr, std::max<size_t>(bytes, 4096), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-    return p == MAP_FAILED ? nullptr : p;
+    if (p == MAP_FAILED) return nullptr;
+    (void)madvise(p, bytes, MADV_HUGEPAGE);          // (takes effect where shared memory may use huge pages; harmless elsewhere)
+    return p;
+}
+
+// Makes the first `bytes` of a slot buffer exist before anybody needs them.  A fresh page of a shared mapping costs a fault of
+// 2-3 microseconds when it is first written — 15 ms for the records of a batch if the one thread that receives them pays, per
+// slot; here the kernel allocates them in one call, on a helper thread, while the GPU runtime starts and the inputs are parsed.
+void prefault(void* p, size_t bytes)
+{
+    if (!p || !bytes) return;
+#ifdef MADV_POPULATE_WRITE
+    if (madvise(p, bytes, MADV_POPULATE_WRITE) == 0) return;
+#endif
+    volatile char* c = (volatile char*)p;
+    for (size_t k = 0; k < bytes; k += 4096) c[k] = 0;
 }
 
 // ---- the GPU worker ---------------------------------------------------------------------------------------------------
@@ -142,6 +158,13 @@ void worker_fail(Channel* ch, const std::string& msg)
 void worker_main(Channel* ch, const Regions* R)
 {
     ch->t_start = now();
+    std::thread recs_ahead([R] {                      // the pages the records of the first batches land in
+        for (int s = 0; s < DEPTH; ++s) prefault(R->recs[s], std::min(R->cap_recs, 2 * R->hint_pairs + 4096) * sizeof(dsa_record));
+    });
+    recs_ahead.detach();
+    // two hardware queues are all this process uses (one compute lane at a time and the copies): each of a process's first
+    // four costs 8-20 ms to create (profiles/r04/tools/init_exit.txt); the user's own setting wins
+    setenv("GPU_MAX_HW_QUEUES", "2", 0);
     DsaLib dsa;
     if (!dsa.load()) return worker_fail(ch, "Error: cannot load the split alignment library: " + dsa.error);
     ch->t_loaded = now();
@@ -214,6 +237,7 @@ void worker_main(Channel* ch, const Regions* R)
         // (room for the records a batch of this size usually has; more are fetched by the collector into the whole mapping)
         const int64_t out_cap = (int64_t)std::min<size_t>(R->cap_recs, (size_t)sl.n_pairs * 4 + 4096);
         const int rc = dsa.stream_submit(st, R->ref[s], sl.ref_len, R->fusions[s], sl.n_fusions, R->reads[s], sl.read_len, R->pairs[s], sl.n_pairs, R->recs[s], out_cap);
+        sl.t_submitted = now();
         if (rc != DSA_OK) {
             std::snprintf(ch->error, sizeof ch->error, "Error: split alignment on the GPU failed: %s", dsa.stream_last_error(st));
             sl.rc = rc;
@@ -348,6 +372,8 @@ int main(int argc, char* argv[])
         R.cap_ref = ((size_t)1 << 31) - 1;
         R.cap_reads = ((size_t)1 << 31) - 1;
         R.cap_recs = std::max<size_t>(8 * R.cap_pairs, (size_t)64 << 20);
+        R.hint_pairs = std::min(batch_pairs, R.cap_pairs);
+        R.hint_read_bytes = std::min<size_t>(R.hint_pairs * (size_t)std::max(cmd.integer("maxread"), 32), (size_t)256 << 20);
         ch = (Channel*)map_shared(sizeof(Channel));
         bool ok = ch != nullptr;
         for (int s = 0; s < DEPTH && ok; ++s) {
@@ -389,6 +415,18 @@ int main(int argc, char* argv[])
         }
         if (inprocess) worker_thread = std::thread(worker_main, ch, &R);
         have_worker = true;
+    }
+    std::thread inputs_ahead;
+    if (have_worker) {
+        inputs_ahead = std::thread([&R] {             // the pages the first batches are built in
+            for (int s = 0; s < DEPTH; ++s) {
+                prefault(R.pairs[s], R.hint_pairs * sizeof(dsa_pair));
+                prefault(R.reads[s], std::min(R.cap_reads, R.hint_read_bytes));
+                prefault(R.ref[s], std::min<size_t>(R.cap_ref, (size_t)8 << 20));
+                prefault(R.fusions[s], std::min<size_t>(R.cap_fusions, 65536) * sizeof(dsa_fusion));
+            }
+        });
+        inputs_ahead.detach();
     }
     // waits for a slot's records; notices a worker process that is gone
     auto wait_done = [&](int s) {
@@ -482,6 +520,8 @@ int main(int argc, char* argv[])
     std::vector<std::string> collected;
     double t_wait_gpu = 0, t_format = 0, t_service = 0, t_first_wait = 0;
     uint64_t n_batches = 0;
+    double svc_ms[8][2] = {};
+    int n_svc = 0;
     std::thread writer([&] {
         Team wteam(nThreads);
         std::vector<int32_t> first, count;
@@ -504,6 +544,7 @@ int main(int argc, char* argv[])
             t_wait_gpu += t1 - t0;
             if (k == 0) t_first_wait = t1 - t0;
             t_service += sl.t_done - sl.t_submit;
+            if (k < 8) { svc_ms[k][0] = 1e3 * (sl.t_submitted - sl.t_submit); svc_ms[k][1] = 1e3 * (sl.t_done - sl.t_submit); n_svc = (int)k + 1; }
             const BatchMeta& M = meta[s];
             const size_t nc = M.n, nr = (size_t)sl.n_records;
             const dsa_record* recs = R.recs[s];
@@ -584,7 +625,7 @@ int main(int argc, char* argv[])
     // batch is built in its slot by the whole team: fusion table and windows, counting sort of the pairs by fusion (the
     // device plans its sweep per fusion and wants a fusion's pairs together), oriented read bytes.
     MappedText sam;
-    sam.load(cmd.str("improper"), "Error: Unable to open sam file ");
+    sam.load(cmd.str("improper"), "Error: Unable to open sam file ", false);
     unsigned nPieces = nThreads;
     if (sam.size() < ((size_t)1 << 20) && !std::getenv("DEFUSE_THREADS")) nPieces = 1;
     Team team(nPieces);
@@ -617,6 +658,14 @@ int main(int argc, char* argv[])
     size_t lineBase = 0;
     int carryReadEnd = 0;                                                // the reference's RawAlignment starts with read end 0
     double t_build = 0, t_slot_wait = 0;
+    uint8_t comp[256];                                                   // ReverseComplement's table (tools/Common.cpp:32-54): ACGT and acgt swap, anything else stays
+    {
+        std::string all(256, '\0');
+        for (int c = 0; c < 256; ++c) all[(size_t)c] = (char)c;
+        std::string rc = all;
+        ReverseComplement(rc);                                           // the one definition of the complement
+        for (int c = 0; c < 256; ++c) comp[(uint8_t)all[(size_t)c]] = (uint8_t)rc[(size_t)(255 - c)];
+    }
     auto key_of = [](int fusion_id, int rid, int revcomp) {
         return ((uint64_t)(uint32_t)fusion_id << 33) | ((uint64_t)(uint32_t)rid << 1) | (uint64_t)revcomp;
     };
@@ -717,7 +766,6 @@ int main(int argc, char* argv[])
             }
             team.barrier();
             // ... and every candidate goes to its place: pair, oriented read bytes
-            std::string tmp;
             for (size_t c = lo; c < hi; ++c) {
                 const Cand& cd = cands[c];
                 const size_t sl = (size_t)fusion_slot[(size_t)(cd.cid & 0x7FFFFFFF)];
@@ -734,11 +782,8 @@ int main(int argc, char* argv[])
                 M.slot_of[c - c0] = (int32_t)k;
                 uint8_t* dst = readb + (cd.roff - rbase);
                 if (!revcomp) std::memcpy(dst, cd.rs, cd.rn);
-                else {
-                    tmp.assign(cd.rs, cd.rn);
-                    ReverseComplement(tmp);                               // the one definition of the complement (tools/Common.cpp)
-                    std::memcpy(dst, tmp.data(), cd.rn);
-                }
+                else
+                    for (uint32_t j = 0; j < cd.rn; ++j) dst[j] = comp[(uint8_t)cd.rs[cd.rn - 1 - j]];
             }
         });
         if (!fits) return false;
@@ -835,7 +880,21 @@ int main(int argc, char* argv[])
         }
         team.run([&](unsigned t) {                                       // (2)
             FlatSet64& mine = seen[t];
-            mine.reserve(mine.size() + ids_total / nPieces + ids_total / (4 * nPieces) + 64);
+            // room for the round's keys — and, from what the first round found per byte of text, for the whole file's, so that
+            // the tables are not rebuilt round after round
+            const size_t whole = lo == 0 ? (size_t)((double)ids_total * (double)sam.size() / (double)(hi - lo)) : 0;
+            mine.reserve(std::max(mine.size() + ids_total / nPieces + ids_total / (4 * nPieces) + 64, whole / nPieces + whole / (4 * nPieces)));
+            // the thread's own keys are inserted a few dozen behind the scan, their slots asked for as they are met: the
+            // tables grow to tens of megabytes per thread and every insert would otherwise wait for memory
+            constexpr int AHEAD = 32;
+            uint64_t pend_key[AHEAD];
+            uint8_t* pend_keep[AHEAD];
+            int np = 0;
+            auto drain = [&] {
+                for (int k = 0; k < np; ++k)
+                    if (mine.insert(pend_key[k])) *pend_keep[k] = 1;
+                np = 0;
+            };
             for (SamPiece& pc : pieces)
                 for (const Hit& h : pc.hits) {
                     const int mateReadEnd = h.readEnd < 0 ? pc.carryIn : h.readEnd;
@@ -844,9 +903,13 @@ int main(int argc, char* argv[])
                         const int cid = pc.ids[h.first + k];
                         const uint64_t key = key_of(fusion_id_of[(size_t)(cid & 0x7FFFFFFF)], rid, cid < 0 ? 0 : 1);
                         if (FlatSet64::hash(key ^ 0x9e3779b97f4a7c15ULL) % nPieces != t) continue;
-                        if (mine.insert(key)) pc.keep[h.first + k] = 1;
+                        mine.prefetch(key);
+                        pend_key[np] = key;
+                        pend_keep[np] = &pc.keep[h.first + k];
+                        if (++np == AHEAD) drain();
                     }
                 }
+            drain();
         });
         stage("  de-duplication of a round");
         if (ids_total) report_reads();
@@ -1007,6 +1070,9 @@ int main(int argc, char* argv[])
         std::cerr << "[dosplitalign] " << n_batches << " batches: building " << t_build << " s (waiting for a free slot " << t_slot_wait
                   << " s), of which GPU calls " << t_service << " s (submit to records in place, worker's clock), the writer waited " << t_wait_gpu
                   << " s for records (" << t_first_wait << " s of it for the first batch), formatting and writing " << t_format << " s" << std::endl;
+        std::cerr << "[dosplitalign] first batches, ms in dsa_stream_submit / until the records were in place:";
+        for (int k = 0; k < n_svc; ++k) std::cerr << " " << svc_ms[k][0] << "/" << svc_ms[k][1];
+        std::cerr << std::endl;
     }
     if (!out.close_file()) die("Error: failed writing " + cmd.str("align"));
     if (have_worker) {
