@@ -39,7 +39,7 @@ DSA_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 def lib_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + \
-           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h", "defuse_cov.h")]
+           [os.path.join(ROOT, "include", h) for h in ("defuse_dsa.h", "defuse_sc.h", "defuse_mpe.h", "defuse_la.h", "defuse_hc.h", "defuse_cov.h", "defuse_cmp.h")]
 
 
 _dsa_flags_probe = {}
@@ -110,7 +110,7 @@ def compile_lib(out, extra_flags=()):
     try:
         _run([HIPCC] + [f for f in LIB_FLAGS if f != "-shared"] + dsa_flags + extra + define + ["-c", "-o", obj, os.path.join(CSRC, "dsa_api.hip")])
         _run([HIPCC] + LIB_FLAGS + extra + define + ["-o", tmp_out, obj] +
-             [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip")])
+             [os.path.join(CSRC, f) for f in ("sc_api.hip", "mpe_api.hip", "la_api.hip", "hc_api.hip", "cov_api.hip", "cmp_api.hip")])
         os.replace(tmp_out, out)
     finally:
         for f in (obj, tmp_out):
@@ -133,7 +133,8 @@ def build_tools(force=False):
         out = os.path.join(bindir, t)
         deps = [src, os.path.join(ROOT, "tools_src", "defuse_host.hpp"), os.path.join(ROOT, "tools_src", "evaluate.hpp"), os.path.join(ROOT, "include", "defuse_dsa.h"),
                 os.path.join(ROOT, "include", "defuse_sc.h"), os.path.join(ROOT, "include", "defuse_mpe.h"),
-                os.path.join(ROOT, "include", "defuse_la.h"), os.path.join(ROOT, "include", "defuse_cov.h"), lib]
+                os.path.join(ROOT, "include", "defuse_la.h"), os.path.join(ROOT, "include", "defuse_cov.h"),
+                os.path.join(ROOT, "include", "defuse_cmp.h"), lib]
         if force or _newer(out, deps):
             if t == "dosplitalign":          # opens the C-ABI library at run time (on a helper thread), see tools_src/dosplitalign.cpp
                 _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-pthread", "-o", out, src, "-ldl"])

@@ -529,6 +529,36 @@ def read_fragments(lines):
         yield cur
 
 
+def add_fragment(als, min_fusion_range, bin_pairs):
+    """One fragment's alignments (dicts with frag, readEnd, ref, strand, region) into the map of bin pairs:
+    CheckConcordant (:211-244), then AddBinPairs (:246-290)."""
+    conc = [set(), set()]
+    for a in als:
+        for b in get_bins(a["region"], min_fusion_range, min_fusion_range):
+            conc[a["readEnd"]].add((a["ref"], b))
+    if conc[0] & conc[1]:
+        return
+    binned = [{}, {}]
+    for a in als:
+        for b in get_bins(a["region"], BIN_LENGTH, min_fusion_range):
+            pid = pack_id(a["ref"], a["strand"], b)
+            rs = a["region"][0] - b * BIN_LENGTH + BIN_LENGTH // 2
+            re_ = a["region"][1] - b * BIN_LENGTH + BIN_LENGTH // 2
+            if not (0 <= rs < 65536 and 0 <= re_ < 65536):
+                raise SystemExit("Error: relativeStart out of range")
+            binned[a["readEnd"]].setdefault(pid, []).append((a["frag"], a["readEnd"], rs, re_))
+    for b1 in sorted(binned[0]):
+        for b2 in sorted(binned[1]):
+            if b1 < b2:
+                e = bin_pairs.setdefault((b1, b2), ([], []))
+                e[0].extend(binned[0][b1])
+                e[1].extend(binned[1][b2])
+            else:
+                e = bin_pairs.setdefault((b2, b1), ([], []))
+                e[0].extend(binned[1][b2])
+                e[1].extend(binned[0][b1])
+
+
 def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size, em="python"):
     """Returns (output text, number of clusters).  em="c" runs MatePairEM::DoClustering through the C restatement
     (oracle/mpe_oracle.c, same arithmetic, ~100x faster) instead of the Python one below; tests compare the two."""
@@ -543,33 +573,7 @@ def clustermatepairs(lines, frag_mean, frag_sd, precision, min_cluster_size, em=
                 ref_names.append(r["reference"])
             als.append(dict(frag=int(r["fragment"]), readEnd=r["readEnd"], ref=ref_index[r["reference"]],
                             strand=r["strand"], region=r["region"]))
-        # CheckConcordant :211-244
-        conc = [set(), set()]
-        for a in als:
-            for b in get_bins(a["region"], min_fusion_range, min_fusion_range):
-                conc[a["readEnd"]].add((a["ref"], b))
-        if conc[0] & conc[1]:
-            continue
-        # AddBinPairs :246-290
-        binned = [{}, {}]
-        for a in als:
-            for b in get_bins(a["region"], BIN_LENGTH, min_fusion_range):
-                pid = pack_id(a["ref"], a["strand"], b)
-                rs = a["region"][0] - b * BIN_LENGTH + BIN_LENGTH // 2
-                re_ = a["region"][1] - b * BIN_LENGTH + BIN_LENGTH // 2
-                if not (0 <= rs < 65536 and 0 <= re_ < 65536):
-                    raise SystemExit("Error: relativeStart out of range")
-                binned[a["readEnd"]].setdefault(pid, []).append((a["frag"], a["readEnd"], rs, re_))
-        for b1 in sorted(binned[0]):
-            for b2 in sorted(binned[1]):
-                if b1 < b2:
-                    e = bin_pairs.setdefault((b1, b2), ([], []))
-                    e[0].extend(binned[0][b1])
-                    e[1].extend(binned[1][b2])
-                else:
-                    e = bin_pairs.setdefault((b2, b1), ([], []))
-                    e[0].extend(binned[1][b2])
-                    e[1].extend(binned[0][b1])
+        add_fragment(als, min_fusion_range, bin_pairs)
     use_c = em == "c"
     em_obj = MatePairEM(frag_mean, frag_sd, precision, min_cluster_size)
     out = []

@@ -122,19 +122,120 @@ def test_tool_large_bin_pairs(built, tmp_path):
 @pytest.mark.parametrize("seed", [3, 6])
 def test_host_stages_same_for_every_thread_count(built, tmp_path, seed):
     """No GPU needed: DEFUSE_CMP_DUMP_PROBLEMS writes what the host stages hand to the device (bin pairs in canonical order,
-    mate pair coordinates, sort ranks, alignment tables) and stops.  Pieces cut at fragment boundaries, parsed and binned side
-    by side, must give the bytes a single reader gives — also when there are more threads than fragments."""
+    mate pair coordinates, sort ranks, alignment tables) and stops — here with the host transcription of the bin-pair
+    bucketing (DEFUSE_CMP_HOST_BINNING=1, the cross-check of the device path; test_device_bin_pairs_* hold the two against
+    each other on a GPU).  Pieces cut at fragment boundaries, parsed and binned side by side, must give the bytes a single
+    reader gives — also when there are more threads than fragments."""
     from defuse_amd import build
     build.build_tools()
     lines = cmp_cases.many_loci(seed)
     dumps = []
     for threads in ("1", "2", "3", "7", "16", "100"):
         dump = tmp_path / ("dump." + threads)
-        r, _ = run_tool(lines, tmp_path, env={"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(dump)})
+        r, _ = run_tool(lines, tmp_path, env={"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(dump), "DEFUSE_CMP_HOST_BINNING": "1"})
         assert r.returncode == 0, r.stderr
         dumps.append(dump.read_bytes())
     assert len(dumps[0]) > 1000
     assert all(d == dumps[0] for d in dumps[1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,threads", [(3, "1"), (6, "7"), (12, "16")])
+def test_device_bin_pairs_give_the_host_cross_checks_problems(built, tmp_path, seed, threads):
+    """The bin pairs built on the GPU (the default: include/defuse_cmp.h — concordance filter, AddBinPairs, a stable radix
+    sort by bin-pair key) against the host transcription of tools/clustermatepairs.cpp:211-290 (DEFUSE_CMP_HOST_BINNING=1):
+    everything downstream of them — problems, mate pair coordinates, ranks, alignment tables — dumped by
+    DEFUSE_CMP_DUMP_PROBLEMS, byte for byte; on loci with multi-mapping ends and on the 20 000-fragment config-3 sample."""
+    from defuse_amd import build
+    build.build_tools()
+    for name, lines in (("loci", cmp_cases.many_loci(seed)), ("config3", None)):
+        if lines is None:
+            path = tmp_path / "c3.txt"
+            cmp_cases.config3_write(20000, str(path))
+            lines = open(path).read().splitlines(True)
+        dumps = {}
+        for mode in ("device", "host"):
+            dump = tmp_path / ("dump.%s.%s" % (name, mode))
+            env = {"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(dump)}
+            if mode == "host":
+                env["DEFUSE_CMP_HOST_BINNING"] = "1"
+            r, _ = run_tool(lines, tmp_path, env=env)
+            assert r.returncode == 0, r.stderr
+            dumps[mode] = dump.read_bytes()
+        assert len(dumps["host"]) > 1000 and dumps["device"] == dumps["host"], name
+
+
+@pytest.mark.gpu
+def test_device_bin_pairs_through_the_c_abi(built):
+    """cmp_bin_* (ctypes) on fragments with dozens of alignments per end, both ends in the same bins, alignments over several
+    bins and concordant pairs: keys, offsets and both lists of every bin pair equal the oracle's map (CheckConcordant +
+    AddBinPairs, oracle/clustermatepairs_oracle.py:add_fragment), list by list in the reference's order of appends; the
+    records uploaded in three pieces; a stop condition comes back as the first offending alignment in file order."""
+    import ctypes
+    import numpy as np
+    from defuse_amd import build
+    from tests import test_cmp_bins as tb
+    lib = ctypes.CDLL(build.build_lib())
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+
+    class Stats(ctypes.Structure):
+        _fields_ = [("n_fragments", i64), ("n_concordant", i64), ("n_keys", i64), ("n_first", i64), ("n_second", i64), ("err_record", i64),
+                    ("err_kind", ctypes.c_int32), ("err_value", ctypes.c_int32), ("device_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
+    lib.cmp_bin_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.cmp_bin_destroy.argtypes = [vp]
+    lib.cmp_bin_reserve.argtypes = [vp, i64, i64]
+    lib.cmp_bin_upload_records.argtypes = [vp, vp, i64, i64]
+    lib.cmp_bin_upload_fragments.argtypes = [vp, vp, i64, i64]
+    lib.cmp_bin_run.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(Stats)]
+    lib.cmp_bin_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.cmp_last_error.restype = ctypes.c_char_p
+    h = vp()
+    assert lib.cmp_bin_create(ctypes.byref(h), 0) == 0
+
+    def run(frs, mfr):
+        recs, starts = tb.to_records(frs)
+        assert lib.cmp_bin_reserve(h, len(recs), len(starts) - 1) == 0
+        cut = [0, len(recs) // 3, 2 * len(recs) // 3, len(recs)]
+        for a, b in zip(cut, cut[1:]):
+            part = np.ascontiguousarray(recs[a:b])
+            assert lib.cmp_bin_upload_records(h, part.ctypes.data, len(part), a) == 0
+        assert lib.cmp_bin_upload_fragments(h, starts.ctypes.data, len(starts), 0) == 0
+        st = Stats()
+        assert lib.cmp_bin_run(h, mfr, ctypes.byref(st)) == 0, lib.cmp_last_error()
+        return st, starts
+
+    for seed, mfr in ((1, 600), (5, 1500), (7, 250)):
+        frs = tb.random_fragments(seed, 3000)
+        st, _ = run(frs, mfr)
+        exp, conc = tb.oracle_bin_pairs(frs, mfr)
+        assert st.err_record == -1 and st.n_concordant == conc and st.n_keys == len(exp)
+        keys = np.zeros(st.n_keys, dtype=np.uint64)
+        off1, off2 = np.zeros(st.n_keys + 1, dtype=np.int64), np.zeros(st.n_keys + 1, dtype=np.int64)
+        p1, p2 = np.zeros(st.n_first, dtype=tb.PACKED), np.zeros(st.n_second, dtype=tb.PACKED)
+        assert lib.cmp_bin_fetch(h, keys.ctypes.data, off1.ctypes.data, off2.ctypes.data, p1.ctypes.data, p2.ctypes.data) == 0
+        assert list(keys) == sorted(keys) and len(set(keys.tolist())) == len(keys)
+        got = tb.as_lists(keys, off1, off2, p1.tolist(), p2.tolist())
+        assert got == {k: (v[0], v[1]) for k, v in exp.items()}
+    frs = tb.random_fragments(9, 50)
+    frs[20][0]["ref"] = (1 << 18) + 5
+    frs[30][0]["region"] = ((1 << 13) * 32768 + 10, (1 << 13) * 32768 + 80)
+    st, starts = run(frs, 600)
+    from oracle import clustermatepairs_oracle as ora
+    first = None
+    for k, als in enumerate(frs):
+        try:
+            ora.add_fragment(als, 600, {})
+        except SystemExit as e:
+            first = (k, 2 if "too many reference" in str(e) else 3)
+            break
+    assert first and st.err_kind == first[1] and int(starts[first[0]]) <= st.err_record < int(starts[first[0] + 1])
+    # an empty input
+    assert lib.cmp_bin_reserve(h, 0, 0) == 0
+    z = np.zeros(1, dtype=np.uint32)
+    assert lib.cmp_bin_upload_fragments(h, z.ctypes.data, 1, 0) == 0
+    st = Stats()
+    assert lib.cmp_bin_run(h, 600, ctypes.byref(st)) == 0 and st.n_keys == 0
+    lib.cmp_bin_destroy(h)
 
 
 @pytest.mark.gpu

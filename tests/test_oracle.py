@@ -92,7 +92,7 @@ def test_library_exports(built):
         assert getattr(lib, name) is not None
     assert b"gfx950" in ctypes.cast(lib.dsa_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
     # and every function the other headers of include/ declare
-    for h, prefix in (("defuse_sc.h", "sc"), ("defuse_mpe.h", "mpe"), ("defuse_la.h", "la"), ("defuse_hc.h", "hc"), ("defuse_cov.h", "cov")):
+    for h, prefix in (("defuse_sc.h", "sc"), ("defuse_mpe.h", "mpe"), ("defuse_la.h", "la"), ("defuse_hc.h", "hc"), ("defuse_cov.h", "cov"), ("defuse_cmp.h", "cmp")):
         text = open(os.path.join(ROOT, "include", h)).read()
         names = set(re.findall(r"\b(%s_[a-z_]+)\s*\(" % prefix, text))
         assert names, h

@@ -45,13 +45,13 @@ def test_clustermatepairs_host_stages(san, tmp_path):
     for threads in ("1", "7"):
         d = tmp_path / ("dump" + threads)
         run(san, "clustermatepairs", ["-a", str(span), "-c", str(tmp_path / "c"), "-u", "300", "-s", "30", "-p", "0.95", "-m", "5"],
-            env={"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(d)})
+            env={"DEFUSE_THREADS": threads, "DEFUSE_CMP_DUMP_PROBLEMS": str(d), "DEFUSE_CMP_HOST_BINNING": "1"})
         dumps.append(d.read_bytes())
     assert dumps[0] == dumps[1] and len(dumps[0]) > 1000
     big = tmp_path / "big.txt"
     cmp_cases.config3_write(20000, str(big))
     run(san, "clustermatepairs", ["-a", str(big), "-c", str(tmp_path / "c"), "-u", "300", "-s", "30", "-p", "0.95", "-m", "5"],
-        env={"DEFUSE_THREADS": "6", "DEFUSE_CMP_DUMP_EM": str(tmp_path / "em.bin")})
+        env={"DEFUSE_THREADS": "6", "DEFUSE_CMP_DUMP_EM": str(tmp_path / "em.bin"), "DEFUSE_CMP_HOST_BINNING": "1"})
     assert os.path.getsize(tmp_path / "em.bin") > 10000
 
 

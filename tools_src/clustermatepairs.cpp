@@ -1,8 +1,11 @@
 // clustermatepairs — drop-in replacement of the reference tool (tools/clustermatepairs.cpp:389-589):
 // same command line (-a may be "-" for stdin), same compact alignment input, same cluster output
-// lines and progress lines.  The host part (concordance filter, 32 kb bin-pair bucketing, per-bin-pair
-// filters, output) follows tools/clustermatepairs.cpp:146-375,478-584; MatePairEM::DoClustering for
-// all bin pairs runs on the GPU in one batch through include/defuse_mpe.h (no CPU fallback).
+// lines and progress lines.  The input is parsed by host threads; the concordance filter and the 32 kb bin-pair
+// bucketing of all fragments (tools/clustermatepairs.cpp:146-290) run on the GPU through include/defuse_cmp.h (one
+// thread per fragment, a stable radix sort by bin-pair key in place of the reference's hash map); the per-bin-pair
+// filters and the output (:292-375,478-584) are host code; MatePairEM::DoClustering for all bin pairs runs on the
+// GPU in batches through include/defuse_mpe.h.  No CPU fallback: DEFUSE_CMP_HOST_BINNING=1 selects the host
+// transcription of the bucketing as a cross-check (tests compare the two), it is never taken by itself.
 // Iteration orders the reference leaves to boost::unordered_map are the canonical ascending-key
 // orders of SURVEY.md 8(c).
 #include <condition_variable>
@@ -10,6 +13,7 @@
 #include <chrono>
 #include <numeric>
 
+#include "../include/defuse_cmp.h"
 #include "../include/defuse_dsa.h"
 #include "../include/defuse_mpe.h"
 #include "defuse_host.hpp"
@@ -75,6 +79,17 @@ Region StrandRemap(const Region& r, int strand)   // tools/MatePairEM.cpp:75-83
     out.end = strand == PlusStrand ? r.end : -r.start;
     return out;
 }
+
+static_assert(sizeof(AlignmentPacked) == sizeof(cmp_packed) && sizeof(AlignmentPacked) == 12, "AlignmentPacked is cmp_packed");
+
+// the two lists of a bin pair, wherever they live (the device's sorted arrays, or the host cross-check's vectors)
+struct ListView {
+    const AlignmentPacked* p = nullptr;
+    size_t n = 0;
+    size_t size() const { return n; }
+    const AlignmentPacked& operator[](size_t k) const { return p[k]; }
+};
+struct PairView { ListView first, second; };
 
 // one surviving bin pair, ready for clustering and for writing its clusters afterwards
 struct Problem {
@@ -298,145 +313,208 @@ int main(int argc, char* argv[])
     }
 
     typedef std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>> PackedPair;
-    auto bin_piece = [&](unsigned t) {
-        Piece& pc = pieces[t];
-        auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
-            const uint64_t key = ((uint64_t)lo << 32) | hi;
-            bool added;
-            uint32_t& slot = pc.binPairIndex.find_or_add(key, added);
-            if (added) {
-                slot = (uint32_t)pc.binPairStore.size();
-                pc.binPairKey.push_back(key);
-                pc.binPairStore.emplace_back();
-            }
-            return pc.binPairStore[slot];
-        };
-        std::vector<std::pair<int, int>> conc[2];
-        std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
-        for (size_t fr = 0; fr + 1 < pc.fragStart.size(); ++fr) {
-            const CompactAlignment* first = pc.recs.data() + pc.fragStart[fr];
-            const CompactAlignment* last = pc.recs.data() + pc.fragStart[fr + 1];
-            // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
-            conc[0].clear(); conc[1].clear();
-            for (const CompactAlignment* a = first; a != last; ++a) {
-                const int startBin = (a->region.start - minFusionRange) / minFusionRange, endBin = (a->region.end + minFusionRange) / minFusionRange;
-                for (int b = startBin; b <= endBin; ++b) conc[a->readEnd].push_back(std::make_pair(a->referenceIndex, b));
-            }
-            bool concordant = false;
-            for (const auto& rb : conc[0])
-                if (std::find(conc[1].begin(), conc[1].end(), rb) != conc[1].end()) { concordant = true; break; }
-            if (concordant) continue;
-            // AddBinPairs (:246-290): per read end the packed alignments by bin id ascending, arrival order inside a bin
-            binned[0].clear(); binned[1].clear();
-            for (const CompactAlignment* a = first; a != last; ++a) {
-                const int startBin = (a->region.start - minFusionRange) / binLength, endBin = (a->region.end + minFusionRange) / binLength;
-                for (int b = startBin; b <= endBin; ++b) {
-                    const int rs = a->region.start - b * binLength + binLength / 2, re = a->region.end - b * binLength + binLength / 2;
-                    if (rs < 0 || re < 0 || rs >= (1 << 16) || re >= (1 << 16)) {
-                        pc.errorLine = 1;
-                        pc.error = "Error: relativeStart >= 0 failed (alignment does not fit its bin)";
-                        return;
-                    }
-                    if (a->referenceIndex >= (1 << 18) || b >= (1 << 13)) {        // RefBinPacked (:28-65)
-                        const bool refs = a->referenceIndex >= (1 << 18);
-                        pc.errorLine = 1;
-                        pc.errorStdout = {std::to_string(refs ? a->referenceIndex : b), std::to_string(refs ? (1 << 18) : (1 << 13))};
-                        pc.error = refs ? "Packing failed, too many reference sequences" : "Packing failed, chromosome too large";
-                        return;
-                    }
-                    binned[a->readEnd].push_back(std::make_pair(pack_ref_bin(a->referenceIndex, a->strand, b),
-                                                                AlignmentPacked{a->fragmentIndex, a->readEnd, (unsigned short)rs, (unsigned short)re}));
-                }
-            }
-            for (int e = 0; e < 2; ++e)
-                std::stable_sort(binned[e].begin(), binned[e].end(), [](const std::pair<unsigned, AlignmentPacked>& x,
-                                                                        const std::pair<unsigned, AlignmentPacked>& y) { return x.first < y.first; });
-            for (size_t i0 = 0; i0 < binned[0].size();) {
-                size_t i1 = i0;
-                while (i1 < binned[0].size() && binned[0][i1].first == binned[0][i0].first) ++i1;
-                for (size_t j0 = 0; j0 < binned[1].size();) {
-                    size_t j1 = j0;
-                    while (j1 < binned[1].size() && binned[1][j1].first == binned[1][j0].first) ++j1;
-                    const unsigned id1 = binned[0][i0].first, id2 = binned[1][j0].first;
-                    const bool fwd = id1 < id2;
-                    PackedPair& e = fwd ? bin_pair(id1, id2) : bin_pair(id2, id1);
-                    std::vector<AlignmentPacked>& d1 = fwd ? e.first : e.second;
-                    std::vector<AlignmentPacked>& d2 = fwd ? e.second : e.first;
-                    for (size_t k = i0; k < i1; ++k) d1.push_back(binned[0][k].second);
-                    for (size_t k = j0; k < j1; ++k) d2.push_back(binned[1][k].second);
-                    j0 = j1;
-                }
-                i0 = i1;
-            }
-        }
-        pc.recs.clear();
-        pc.recs.shrink_to_fit();
-        pc.binPairIndex.release();
-    };
-    run_threads(bin_piece);
-    stage("  binned");
-    for (const Piece& pc : pieces)
-        if (pc.errorLine) {
-            for (const std::string& l : pc.errorStdout) std::cout << l << std::endl;
-            die(pc.error);
-        }
-
-    // bin pairs by (first.id, second.id), the pieces joined in file order; visited in ascending key order afterwards (canonical)
-    // Thread t joins the keys whose hash falls to it, walking the pieces in file order; the joined lists stay where they are
-    // (one table of pointers over all threads' shares instead of a copy), and every thread frees its own piece at the end.
-    struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
-    std::vector<Joined> joined(nThreads);
-    {
-        auto join_keys = [&](unsigned t) {
-            Joined& j = joined[t];
-            if (nThreads == 1) {
-                j.key.swap(pieces[0].binPairKey);
-                j.store.swap(pieces[0].binPairStore);
-                return;
-            }
-            size_t mine = 0;
-            for (const Piece& pc : pieces)
-                for (uint64_t key : pc.binPairKey) mine += ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads == t) ? 1 : 0;
-            j.key.reserve(mine);                              // upper bound: no regrowth, the lists are never moved twice
-            j.store.reserve(mine);
-            FlatMap64 index(1 << 16);
-            for (Piece& pc : pieces)
-                for (size_t k = 0; k < pc.binPairKey.size(); ++k) {
-                    const uint64_t key = pc.binPairKey[k];
-                    if ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads != t) continue;
-                    bool added;
-                    uint32_t& slot = index.find_or_add(key, added);
-                    if (added) {
-                        slot = (uint32_t)j.store.size();
-                        j.key.push_back(key);
-                        j.store.push_back(std::move(pc.binPairStore[k]));
-                    } else {
-                        PackedPair& d = j.store[slot];
-                        d.first.insert(d.first.end(), pc.binPairStore[k].first.begin(), pc.binPairStore[k].first.end());
-                        d.second.insert(d.second.end(), pc.binPairStore[k].second.begin(), pc.binPairStore[k].second.end());
-                    }
-                }
-        };
-        run_threads(join_keys);
-        run_threads([&](unsigned t) { pieces[t] = Piece(); });          // millions of small lists: freed side by side
-    }
+    // The bin pairs: key (first.id << 32 | second.id) and the two lists of each.  By default they are built on the GPU
+    // (include/defuse_cmp.h); DEFUSE_CMP_HOST_BINNING=1 runs the host transcription below instead — a cross-check the tests
+    // hold against the device path, never a fallback.
+    const bool host_binning = [] { const char* e = std::getenv("DEFUSE_CMP_HOST_BINNING"); return e && std::atoi(e) != 0; }();
     std::vector<uint64_t> binPairKey;
-    std::vector<PackedPair*> binPairStorePtr;
-    {
+    std::vector<PairView> binPairStore;
+    struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
+    std::vector<Joined> joined(host_binning ? nThreads : 0);                  // owner of the lists (host path)
+    std::vector<AlignmentPacked> devFirst, devSecond;                         // owner of the lists (device path)
+    int gpu_device = -1;                                                      // the device of this process's first GPU call
+    auto first_device = [&] {
+        if (gpu_device < 0) gpu_device = dsa_pick_device();
+        return gpu_device;
+    };
+    if (host_binning) {
+        auto bin_piece = [&](unsigned t) {
+            Piece& pc = pieces[t];
+            auto bin_pair = [&](unsigned lo, unsigned hi) -> PackedPair& {
+                const uint64_t key = ((uint64_t)lo << 32) | hi;
+                bool added;
+                uint32_t& slot = pc.binPairIndex.find_or_add(key, added);
+                if (added) {
+                    slot = (uint32_t)pc.binPairStore.size();
+                    pc.binPairKey.push_back(key);
+                    pc.binPairStore.emplace_back();
+                }
+                return pc.binPairStore[slot];
+            };
+            std::vector<std::pair<int, int>> conc[2];
+            std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
+            for (size_t fr = 0; fr + 1 < pc.fragStart.size(); ++fr) {
+                const CompactAlignment* first = pc.recs.data() + pc.fragStart[fr];
+                const CompactAlignment* last = pc.recs.data() + pc.fragStart[fr + 1];
+                // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
+                conc[0].clear(); conc[1].clear();
+                for (const CompactAlignment* a = first; a != last; ++a) {
+                    const int startBin = (a->region.start - minFusionRange) / minFusionRange, endBin = (a->region.end + minFusionRange) / minFusionRange;
+                    for (int b = startBin; b <= endBin; ++b) conc[a->readEnd].push_back(std::make_pair(a->referenceIndex, b));
+                }
+                bool concordant = false;
+                for (const auto& rb : conc[0])
+                    if (std::find(conc[1].begin(), conc[1].end(), rb) != conc[1].end()) { concordant = true; break; }
+                if (concordant) continue;
+                // AddBinPairs (:246-290): per read end the packed alignments by bin id ascending, arrival order inside a bin
+                binned[0].clear(); binned[1].clear();
+                for (const CompactAlignment* a = first; a != last; ++a) {
+                    const int startBin = (a->region.start - minFusionRange) / binLength, endBin = (a->region.end + minFusionRange) / binLength;
+                    for (int b = startBin; b <= endBin; ++b) {
+                        const int rs = a->region.start - b * binLength + binLength / 2, re = a->region.end - b * binLength + binLength / 2;
+                        if (rs < 0 || re < 0 || rs >= (1 << 16) || re >= (1 << 16)) {
+                            pc.errorLine = 1;
+                            pc.error = "Error: relativeStart >= 0 failed (alignment does not fit its bin)";
+                            return;
+                        }
+                        if (a->referenceIndex >= (1 << 18) || b >= (1 << 13)) {        // RefBinPacked (:28-65)
+                            const bool refs = a->referenceIndex >= (1 << 18);
+                            pc.errorLine = 1;
+                            pc.errorStdout = {std::to_string(refs ? a->referenceIndex : b), std::to_string(refs ? (1 << 18) : (1 << 13))};
+                            pc.error = refs ? "Packing failed, too many reference sequences" : "Packing failed, chromosome too large";
+                            return;
+                        }
+                        binned[a->readEnd].push_back(std::make_pair(pack_ref_bin(a->referenceIndex, a->strand, b),
+                                                                    AlignmentPacked{a->fragmentIndex, a->readEnd, (unsigned short)rs, (unsigned short)re}));
+                    }
+                }
+                for (int e = 0; e < 2; ++e)
+                    std::stable_sort(binned[e].begin(), binned[e].end(), [](const std::pair<unsigned, AlignmentPacked>& x,
+                                                                            const std::pair<unsigned, AlignmentPacked>& y) { return x.first < y.first; });
+                for (size_t i0 = 0; i0 < binned[0].size();) {
+                    size_t i1 = i0;
+                    while (i1 < binned[0].size() && binned[0][i1].first == binned[0][i0].first) ++i1;
+                    for (size_t j0 = 0; j0 < binned[1].size();) {
+                        size_t j1 = j0;
+                        while (j1 < binned[1].size() && binned[1][j1].first == binned[1][j0].first) ++j1;
+                        const unsigned id1 = binned[0][i0].first, id2 = binned[1][j0].first;
+                        const bool fwd = id1 < id2;
+                        PackedPair& e = fwd ? bin_pair(id1, id2) : bin_pair(id2, id1);
+                        std::vector<AlignmentPacked>& d1 = fwd ? e.first : e.second;
+                        std::vector<AlignmentPacked>& d2 = fwd ? e.second : e.first;
+                        for (size_t k = i0; k < i1; ++k) d1.push_back(binned[0][k].second);
+                        for (size_t k = j0; k < j1; ++k) d2.push_back(binned[1][k].second);
+                        j0 = j1;
+                    }
+                    i0 = i1;
+                }
+            }
+            pc.recs.clear();
+            pc.recs.shrink_to_fit();
+            pc.binPairIndex.release();
+        };
+        run_threads(bin_piece);
+        stage("  binned");
+        for (const Piece& pc : pieces)
+            if (pc.errorLine) {
+                for (const std::string& l : pc.errorStdout) std::cout << l << std::endl;
+                die(pc.error);
+            }
+
+        // bin pairs by (first.id, second.id), the pieces joined in file order; visited in ascending key order afterwards (canonical)
+        // Thread t joins the keys whose hash falls to it, walking the pieces in file order; the joined lists stay where they are
+        // (one table of pointers over all threads' shares instead of a copy), and every thread frees its own piece at the end.
+        {
+            auto join_keys = [&](unsigned t) {
+                Joined& j = joined[t];
+                if (nThreads == 1) {
+                    j.key.swap(pieces[0].binPairKey);
+                    j.store.swap(pieces[0].binPairStore);
+                    return;
+                }
+                size_t mine = 0;
+                for (const Piece& pc : pieces)
+                    for (uint64_t key : pc.binPairKey) mine += ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads == t) ? 1 : 0;
+                j.key.reserve(mine);                              // upper bound: no regrowth, the lists are never moved twice
+                j.store.reserve(mine);
+                FlatMap64 index(1 << 16);
+                for (Piece& pc : pieces)
+                    for (size_t k = 0; k < pc.binPairKey.size(); ++k) {
+                        const uint64_t key = pc.binPairKey[k];
+                        if ((key * 0x9E3779B97F4A7C15ULL >> 40) % nThreads != t) continue;
+                        bool added;
+                        uint32_t& slot = index.find_or_add(key, added);
+                        if (added) {
+                            slot = (uint32_t)j.store.size();
+                            j.key.push_back(key);
+                            j.store.push_back(std::move(pc.binPairStore[k]));
+                        } else {
+                            PackedPair& d = j.store[slot];
+                            d.first.insert(d.first.end(), pc.binPairStore[k].first.begin(), pc.binPairStore[k].first.end());
+                            d.second.insert(d.second.end(), pc.binPairStore[k].second.begin(), pc.binPairStore[k].second.end());
+                        }
+                    }
+            };
+            run_threads(join_keys);
+            run_threads([&](unsigned t) { pieces[t] = Piece(); });          // millions of small lists: freed side by side
+        }
         size_t total = 0;
         for (const Joined& j : joined) total += j.key.size();
         binPairKey.reserve(total);
-        binPairStorePtr.reserve(total);
+        binPairStore.reserve(total);
         for (Joined& j : joined) {
             binPairKey.insert(binPairKey.end(), j.key.begin(), j.key.end());
-            for (PackedPair& pp : j.store) binPairStorePtr.push_back(&pp);
+            for (PackedPair& pp : j.store)
+                binPairStore.push_back(PairView{ListView{pp.first.data(), pp.first.size()}, ListView{pp.second.data(), pp.second.size()}});
         }
+    } else {
+        // records and fragment starts go to the device piece by piece (every piece from its own thread), the device does the
+        // rest: CheckConcordant, AddBinPairs, the map of bin pairs as a stable sort by key (defuse_amd/csrc/cmp_api.hip)
+        if (refNames.size() >= ((size_t)1 << 28)) die("Error: more than 2^28 reference sequences");
+        std::vector<size_t> recBase(nThreads + 1, 0), fragBase(nThreads + 1, 0);
+        for (unsigned t = 0; t < nThreads; ++t) {
+            recBase[t + 1] = recBase[t] + pieces[t].recs.size();
+            fragBase[t + 1] = fragBase[t] + pieces[t].fragStart.size() - 1;
+        }
+        cmp_binner* binner = nullptr;
+        if (cmp_bin_create(&binner, first_device()) != DSA_OK) die(std::string("Error: no usable MI355X/HIP device (") + cmp_last_error() + ")");
+        if (cmp_bin_reserve(binner, (int64_t)recBase[nThreads], (int64_t)fragBase[nThreads]) != DSA_OK) die(std::string("Error: ") + cmp_last_error());
+        std::vector<int> rcs(nThreads, DSA_OK);
+        run_threads([&](unsigned t) {
+            Piece& pc = pieces[t];
+            std::vector<cmp_record> out(pc.recs.size());
+            for (size_t k = 0; k < pc.recs.size(); ++k) {
+                const CompactAlignment& a = pc.recs[k];
+                out[k] = cmp_record{a.fragmentIndex, a.region.start, a.region.end, CMP_META(a.referenceIndex, a.strand, a.readEnd)};
+            }
+            rcs[t] = cmp_bin_upload_records(binner, out.data(), (int64_t)out.size(), (int64_t)recBase[t]);
+            if (rcs[t] != DSA_OK) return;
+            std::vector<uint32_t> fs(pc.fragStart.size() - (t + 1 < nThreads ? 1 : 0));      // the last piece brings the end
+            for (size_t k = 0; k < fs.size(); ++k) fs[k] = (uint32_t)(pc.fragStart[k] + recBase[t]);
+            rcs[t] = cmp_bin_upload_fragments(binner, fs.data(), (int64_t)fs.size(), (int64_t)fragBase[t]);
+        });
+        for (int rc : rcs)
+            if (rc != DSA_OK) die(std::string("Error: bin pairs on the GPU failed: ") + cmp_last_error());
+        stage("  records on the device");
+        cmp_stats st{};
+        if (cmp_bin_run(binner, minFusionRange, &st) != DSA_OK) die(std::string("Error: bin pairs on the GPU failed: ") + cmp_last_error());
+        if (st.err_record >= 0) {
+            // the alignment on which the reference stops (:178-192 DebugChecks, :28-65 packing limits): its message and exit
+            unsigned t = 0;
+            while (t + 1 < nThreads && (size_t)st.err_record >= recBase[t + 1]) ++t;
+            const CompactAlignment& a = pieces[t].recs[(size_t)st.err_record - recBase[t]];
+            if (st.err_kind == 1) die("Error: relativeStart >= 0 failed (alignment does not fit its bin)");
+            const bool refs = st.err_kind == 2;
+            const int startBin = (a.region.start - minFusionRange) / binLength;
+            std::cout << (refs ? a.referenceIndex : std::max(startBin, 1 << 13)) << std::endl << (refs ? (1 << 18) : (1 << 13)) << std::endl;
+            die(refs ? "Packing failed, too many reference sequences" : "Packing failed, chromosome too large");
+        }
+        std::vector<int64_t> off1((size_t)st.n_keys + 1), off2((size_t)st.n_keys + 1);
+        binPairKey.resize((size_t)st.n_keys);
+        devFirst.resize((size_t)st.n_first);
+        devSecond.resize((size_t)st.n_second);
+        if (cmp_bin_fetch(binner, binPairKey.data(), off1.data(), off2.data(), (cmp_packed*)devFirst.data(), (cmp_packed*)devSecond.data()) != DSA_OK)
+            die(std::string("Error: bin pairs on the GPU failed: ") + cmp_last_error());
+        cmp_bin_destroy(binner);
+        binPairStore.resize((size_t)st.n_keys);
+        for (size_t k = 0; k < (size_t)st.n_keys; ++k)
+            binPairStore[k] = PairView{ListView{devFirst.data() + off1[k], (size_t)(off1[k + 1] - off1[k])},
+                                       ListView{devSecond.data() + off2[k], (size_t)(off2[k + 1] - off2[k])}};
+        if (timing)
+            std::cerr << "[clustermatepairs]   bin pairs on the device: " << st.n_fragments << " fragments, " << st.n_concordant << " concordant, " << st.n_keys
+                      << " bin pairs, " << st.n_first + st.n_second << " entries, kernels + sorts " << st.device_ms << " ms" << std::endl;
+        run_threads([&](unsigned t) { pieces[t] = Piece(); });
     }
-    struct StoreView {                                        // binPairStore[i] as before
-        std::vector<PackedPair*>* p;
-        PackedPair& operator[](size_t i) const { return *(*p)[i]; }
-        size_t size() const { return p->size(); }
-    } binPairStore{&binPairStorePtr};
 
     stage("read + bin pairs");
     std::cout << "Initializing clusterer" << std::endl;
@@ -477,7 +555,7 @@ int main(int argc, char* argv[])
         std::vector<uint16_t> member;
     };
     size_t totalAlignments = 0;
-    for (const PackedPair* pp : binPairStorePtr) totalAlignments += pp->first.size() + pp->second.size();
+    for (const PairView& pp : binPairStore) totalAlignments += pp.first.size() + pp.second.size();
     const bool dumping = std::getenv("DEFUSE_CMP_DUMP_PROBLEMS") || std::getenv("DEFUSE_CMP_DUMP_EM");
     unsigned nChunks = totalAlignments >= ((size_t)8 << 20) ? 4u : 1u;
     if (const char* e = std::getenv("DEFUSE_CMP_CHUNKS")) nChunks = (unsigned)std::max(1, std::atoi(e));
@@ -507,10 +585,10 @@ int main(int argc, char* argv[])
         FragmentGroups fr1, fr2, fr2all;
         for (size_t oi = lo; oi < hi; ++oi) {
         const uint32_t bpi = bpOrder[oi];
-        PackedPair& pp = binPairStore[bpi];
+        const PairView& pp = binPairStore[bpi];
         if ((int)pp.first.size() < minClusterSize || (int)pp.second.size() < minClusterSize) continue;
         Problem prob;
-        auto unpack = [&](unsigned id, const std::vector<AlignmentPacked>& packed, std::vector<CompactAlignment>& al) {
+        auto unpack = [&](unsigned id, const ListView& packed, std::vector<CompactAlignment>& al) {
             const int ref = (int)(id & 0x3FFFFu), strand = (int)((id >> 18) & 1u), bin = (int)(id >> 19);
             al.resize(packed.size());
             for (size_t k = 0; k < packed.size(); ++k) {
@@ -556,7 +634,6 @@ int main(int argc, char* argv[])
         for (size_t r = 0; r < n; ++r) o.toYO[base + ord[r]] = (int32_t)r;
         o.sizes.push_back((int64_t)n);
         o.problems.push_back(std::move(prob));
-        PackedPair().swap(pp);                              // the packed lists of this bin pair are not needed again
     }
     };
     run_threads(build_share);
@@ -591,7 +668,7 @@ int main(int argc, char* argv[])
                 else if (spec.find(',') != std::string::npos) for (const std::string& f : split_tabs(spec, ',')) devices.push_back(std::atoi(f.c_str()));
                 else for (int d = 0; d < std::atoi(spec.c_str()); ++d) devices.push_back(have > 0 ? d % have : d);
             }
-            if (devices.empty()) devices.push_back(dsa_pick_device());
+            if (devices.empty()) devices.push_back(first_device());
         }
         std::vector<int32_t> status(ck.problems.size(), 0);
         mpe_timing t;
@@ -620,7 +697,10 @@ int main(int argc, char* argv[])
         auto format_share = [&](unsigned t) {
             std::string& buf = texts[t];
             std::vector<int> usedFragments;
-            auto put_int = [&](long long v) { append_int(buf, v); };
+            auto put_int = [&](long long v) {
+                char tmp[16];
+                buf.append(tmp, (size_t)(defuse::put_int(tmp, (int)v) - tmp));
+            };
             for (size_t p = outShare[t]; p < outShare[t + 1]; ++p) {
                 const Problem& prob = problems[p];
                 const int64_t base = probOff[p];
@@ -745,5 +825,11 @@ int main(int argc, char* argv[])
     if (!out.close_file()) die("Error: failed writing the clusters file");
     stage("problems + clustering + output");
     std::cout << "Created " << clusterID << " clusters" << std::endl;
-    return 0;
+    // The clusters file is complete and closed.  The process ends here without destroying its tables one by one (gigabytes in
+    // millions of blocks at full size: more than a second of the round-3 tool's 8.9 s) and without the GPU runtime's own
+    // shutdown; the system takes all of it back at once.
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(nullptr);
+    _exit(0);
 }
