@@ -447,15 +447,23 @@ int cmp_bin_fetch(cmp_binner* b, uint64_t* keys, int64_t* off_first, int64_t* of
         if (nk) CMP_HIP(hipMemcpy(tmp.data(), S.off.p, ((size_t)nk + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
         else tmp[0] = 0;
         for (int64_t k = 0; k <= nk; ++k) outs[s][k] = tmp[(size_t)k];
-        if (S.n) {
-            if (!pays[s]) return DSA_E_ARG;
+        if (S.n && pays[s])           // (NULL: the caller takes the lists in parts, cmp_bin_fetch_part)
             CMP_HIP(hipMemcpy(pays[s], S.pay_sorted.p, (size_t)S.n * sizeof(cmp_packed), hipMemcpyDeviceToHost));
-        }
     }
     if (nk) {
         if (!keys) return DSA_E_ARG;
         CMP_HIP(hipMemcpy(keys, b->side[0].uniq.p, (size_t)nk * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
+    return DSA_OK;
+}
+
+
+int cmp_bin_fetch_part(cmp_binner* b, int which, int64_t from, int64_t n, cmp_packed* out)
+{
+    if (!b || !b->ran) { g_cmp_err = "cmp_bin_fetch_part before a successful cmp_bin_run"; return DSA_E_ARG; }
+    if (which < 0 || which > 1 || from < 0 || n < 0 || from + n > b->side[which].n || (n && !out)) return DSA_E_ARG;
+    CMP_HIP(hipSetDevice(b->device));
+    if (n) CMP_HIP(hipMemcpy(out, b->side[which].pay_sorted.p + from, (size_t)n * sizeof(cmp_packed), hipMemcpyDeviceToHost));
     return DSA_OK;
 }
 

@@ -1140,14 +1140,25 @@ void stream_worker(dsa_stream* s)
         dsa_ctx* ctx = s->slot[k % s->depth];
         dsa_stream::Job& j = s->job[k % s->depth];
         int64_t n = 0;
+        static const bool trace = [] { const char* e = getenv("DEFUSE_DSA_STREAM_TRACE"); return e && atoi(e) != 0; }();
+        const auto t0 = std::chrono::steady_clock::now();
         int rc = hipStreamWaitEvent(ctx->main_stream(), j.ev_in, 0) == hipSuccess ? DSA_OK : DSA_E_DEVICE;
         if (rc == DSA_OK) rc = enqueue_plan(ctx);
+        const auto t1 = std::chrono::steady_clock::now();
         if (rc == DSA_OK) rc = dsa_run(ctx, &n);
+        const auto t2 = std::chrono::steady_clock::now();
         j.copied = false;
         if (rc == DSA_OK && n <= j.out_cap) {
             if (n && hipMemcpyAsync(j.out, ctx->d_records.p, (size_t)n * sizeof(dsa_record), hipMemcpyDeviceToHost, s->s_out) != hipSuccess) rc = DSA_E_DEVICE;
             if (hipEventRecord(j.ev_out, s->s_out) != hipSuccess) rc = DSA_E_DEVICE;
             j.copied = rc == DSA_OK;
+        }
+        if (trace) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[dsa_stream] batch %llu: %lld pairs, plan queued %.2f ms, run %.2f ms (device: plan %.2f pack %.2f fill %.2f finish %.2f; %d fill launches), "
+                            "records copy issued %.2f ms, %lld records\n", (unsigned long long)k, (long long)ctx->n_pairs, ms(t0, t1), ms(t1, t2), ctx->timing.plan_ms,
+                    ctx->timing.pack_ms, ctx->timing.fill_ms, ctx->timing.finish_ms, ctx->timing.fill_launches, ms(t2, t3), (long long)n);
         }
         j.n = n;
         j.rc = rc;

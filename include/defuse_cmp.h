@@ -69,6 +69,9 @@ int  cmp_bin_run(cmp_binner* b, int32_t min_fusion_range, cmp_stats* stats);
 /* bin pair k: key = (first.id << 32) | second.id (RefBinPacked ids), ascending; its lists are
  * first[off_first[k] .. off_first[k+1]) and second[off_second[k] .. off_second[k+1]) (n_keys + 1 offsets each) */
 int  cmp_bin_fetch(cmp_binner* b, uint64_t* keys, int64_t* off_first, int64_t* off_second, cmp_packed* first, cmp_packed* second);
+/* entries [from, from + n) of all `first` (which = 0) or all `second` (1) lists: a caller with several host threads passes
+ * NULL for the lists above and lets every thread copy its own share into memory it touches for the first time itself */
+int  cmp_bin_fetch_part(cmp_binner* b, int which, int64_t from, int64_t n, cmp_packed* out);
 const char* cmp_last_error(void);
 
 #ifdef __cplusplus

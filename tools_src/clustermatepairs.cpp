@@ -215,9 +215,10 @@ int main(int argc, char* argv[])
     }
 
     struct Piece {
-        std::vector<CompactAlignment> recs;                  // referenceIndex: piece-local until remapped
+        std::vector<cmp_record> recs;                        // reference index (in meta): piece-local until remapped
         std::vector<uint32_t> fragStart;                     // first record of every fragment, plus the end
         std::vector<std::string> refNames;
+        std::vector<int> remap;                              // piece-local reference index -> index over the whole file
         std::unordered_map<std::string, int> refIndex;
         size_t lines = 0;
         size_t errorLine = 0;                                // 1-based line inside the piece, 0 = none
@@ -264,18 +265,18 @@ int main(int argc, char* argv[])
                 curName = fs[0];
                 curLen = flen(0);
             }
-            CompactAlignment a;
-            if (!field_int(fs[0], flen(0), a.fragmentIndex)) { fail("Error: bad integer '" + std::string(fs[0], flen(0)) + "' as fragment name on line "); return; }
-            a.readEnd = (flen(1) == 1 && fs[1][0] == '1') ? 0 : 1;
+            cmp_record a;
+            if (!field_int(fs[0], flen(0), a.fragment)) { fail("Error: bad integer '" + std::string(fs[0], flen(0)) + "' as fragment name on line "); return; }
+            const int readEnd = (flen(1) == 1 && fs[1][0] == '1') ? 0 : 1;
             refKey.assign(fs[2], flen(2));
             auto ri = pc.refIndex.find(refKey);
             if (ri == pc.refIndex.end()) {
                 ri = pc.refIndex.emplace(refKey, (int)pc.refNames.size()).first;
                 pc.refNames.push_back(refKey);
             }
-            a.referenceIndex = ri->second;
-            a.strand = (flen(3) == 1 && fs[3][0] == '-') ? MinusStrand : PlusStrand;
-            if (!field_int(fs[4], flen(4), a.region.start) || !field_int(fs[5], flen(5), a.region.end)) {
+            const int strand = (flen(3) == 1 && fs[3][0] == '-') ? MinusStrand : PlusStrand;
+            a.meta = CMP_META(ri->second, strand, readEnd);
+            if (!field_int(fs[4], flen(4), a.start) || !field_int(fs[5], flen(5), a.end)) {
                 fail("Error: bad integer '" + std::string(fs[4], (size_t)(line + len - fs[4])) + "' on line ");
                 return;
             }
@@ -307,10 +308,15 @@ int main(int argc, char* argv[])
                 }
                 remap[k] = ri->second;
             }
-            for (CompactAlignment& a : pc.recs) a.referenceIndex = remap[a.referenceIndex];
+            pc.remap.swap(remap);
             pc.fragStart.push_back((uint32_t)pc.recs.size());
         }
     }
+    if (refNames.size() >= ((size_t)1 << 28)) die("Error: more than 2^28 reference sequences");
+    run_threads([&](unsigned t) {
+        Piece& pc = pieces[t];
+        for (cmp_record& a : pc.recs) a.meta = (a.meta & ~0x0FFFFFFFu) | (uint32_t)pc.remap[a.meta & 0x0FFFFFFFu];
+    });
 
     typedef std::pair<std::vector<AlignmentPacked>, std::vector<AlignmentPacked>> PackedPair;
     // The bin pairs: key (first.id << 32 | second.id) and the two lists of each.  By default they are built on the GPU
@@ -321,7 +327,7 @@ int main(int argc, char* argv[])
     std::vector<PairView> binPairStore;
     struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
     std::vector<Joined> joined(host_binning ? nThreads : 0);                  // owner of the lists (host path)
-    std::vector<AlignmentPacked> devFirst, devSecond;                         // owner of the lists (device path)
+    std::unique_ptr<AlignmentPacked[]> devFirst, devSecond;                   // owner of the lists (device path)
     int gpu_device = -1;                                                      // the device of this process's first GPU call
     auto first_device = [&] {
         if (gpu_device < 0) gpu_device = dsa_pick_device();
@@ -343,9 +349,14 @@ int main(int argc, char* argv[])
             };
             std::vector<std::pair<int, int>> conc[2];
             std::vector<std::pair<unsigned, AlignmentPacked>> binned[2];
+            std::vector<CompactAlignment> recs(pc.recs.size());
+            for (size_t k = 0; k < recs.size(); ++k) {
+                const cmp_record& r = pc.recs[k];
+                recs[k] = CompactAlignment{r.fragment, (int)((r.meta >> 29) & 1u), (int)(r.meta & 0x0FFFFFFFu), (int)((r.meta >> 28) & 1u), Region{r.start, r.end}};
+            }
             for (size_t fr = 0; fr + 1 < pc.fragStart.size(); ++fr) {
-                const CompactAlignment* first = pc.recs.data() + pc.fragStart[fr];
-                const CompactAlignment* last = pc.recs.data() + pc.fragStart[fr + 1];
+                const CompactAlignment* first = recs.data() + pc.fragStart[fr];
+                const CompactAlignment* last = recs.data() + pc.fragStart[fr + 1];
                 // CheckConcordant (:211-244): a (reference, bin) shared by the two ends
                 conc[0].clear(); conc[1].clear();
                 for (const CompactAlignment* a = first; a != last; ++a) {
@@ -460,7 +471,6 @@ int main(int argc, char* argv[])
     } else {
         // records and fragment starts go to the device piece by piece (every piece from its own thread), the device does the
         // rest: CheckConcordant, AddBinPairs, the map of bin pairs as a stable sort by key (defuse_amd/csrc/cmp_api.hip)
-        if (refNames.size() >= ((size_t)1 << 28)) die("Error: more than 2^28 reference sequences");
         std::vector<size_t> recBase(nThreads + 1, 0), fragBase(nThreads + 1, 0);
         for (unsigned t = 0; t < nThreads; ++t) {
             recBase[t + 1] = recBase[t] + pieces[t].recs.size();
@@ -472,12 +482,7 @@ int main(int argc, char* argv[])
         std::vector<int> rcs(nThreads, DSA_OK);
         run_threads([&](unsigned t) {
             Piece& pc = pieces[t];
-            std::vector<cmp_record> out(pc.recs.size());
-            for (size_t k = 0; k < pc.recs.size(); ++k) {
-                const CompactAlignment& a = pc.recs[k];
-                out[k] = cmp_record{a.fragmentIndex, a.region.start, a.region.end, CMP_META(a.referenceIndex, a.strand, a.readEnd)};
-            }
-            rcs[t] = cmp_bin_upload_records(binner, out.data(), (int64_t)out.size(), (int64_t)recBase[t]);
+            rcs[t] = cmp_bin_upload_records(binner, pc.recs.data(), (int64_t)pc.recs.size(), (int64_t)recBase[t]);
             if (rcs[t] != DSA_OK) return;
             std::vector<uint32_t> fs(pc.fragStart.size() - (t + 1 < nThreads ? 1 : 0));      // the last piece brings the end
             for (size_t k = 0; k < fs.size(); ++k) fs[k] = (uint32_t)(pc.fragStart[k] + recBase[t]);
@@ -492,24 +497,32 @@ int main(int argc, char* argv[])
             // the alignment on which the reference stops (:178-192 DebugChecks, :28-65 packing limits): its message and exit
             unsigned t = 0;
             while (t + 1 < nThreads && (size_t)st.err_record >= recBase[t + 1]) ++t;
-            const CompactAlignment& a = pieces[t].recs[(size_t)st.err_record - recBase[t]];
+            const cmp_record& a = pieces[t].recs[(size_t)st.err_record - recBase[t]];
             if (st.err_kind == 1) die("Error: relativeStart >= 0 failed (alignment does not fit its bin)");
             const bool refs = st.err_kind == 2;
-            const int startBin = (a.region.start - minFusionRange) / binLength;
-            std::cout << (refs ? a.referenceIndex : std::max(startBin, 1 << 13)) << std::endl << (refs ? (1 << 18) : (1 << 13)) << std::endl;
+            const int startBin = (a.start - minFusionRange) / binLength;
+            std::cout << (refs ? (int)(a.meta & 0x0FFFFFFFu) : std::max(startBin, 1 << 13)) << std::endl << (refs ? (1 << 18) : (1 << 13)) << std::endl;
             die(refs ? "Packing failed, too many reference sequences" : "Packing failed, chromosome too large");
         }
         std::vector<int64_t> off1((size_t)st.n_keys + 1), off2((size_t)st.n_keys + 1);
         binPairKey.resize((size_t)st.n_keys);
-        devFirst.resize((size_t)st.n_first);
-        devSecond.resize((size_t)st.n_second);
-        if (cmp_bin_fetch(binner, binPairKey.data(), off1.data(), off2.data(), (cmp_packed*)devFirst.data(), (cmp_packed*)devSecond.data()) != DSA_OK)
+        devFirst.reset(new AlignmentPacked[(size_t)st.n_first + 1]);              // (not value-initialised: every thread touches its own share first)
+        devSecond.reset(new AlignmentPacked[(size_t)st.n_second + 1]);
+        if (cmp_bin_fetch(binner, binPairKey.data(), off1.data(), off2.data(), nullptr, nullptr) != DSA_OK)
             die(std::string("Error: bin pairs on the GPU failed: ") + cmp_last_error());
+        run_threads([&](unsigned t) {
+            const int64_t a0 = st.n_first * t / nThreads, a1 = st.n_first * (t + 1) / nThreads;
+            const int64_t b0 = st.n_second * t / nThreads, b1 = st.n_second * (t + 1) / nThreads;
+            rcs[t] = cmp_bin_fetch_part(binner, 0, a0, a1 - a0, (cmp_packed*)devFirst.get() + a0);
+            if (rcs[t] == DSA_OK) rcs[t] = cmp_bin_fetch_part(binner, 1, b0, b1 - b0, (cmp_packed*)devSecond.get() + b0);
+        });
+        for (int rc : rcs)
+            if (rc != DSA_OK) die(std::string("Error: bin pairs on the GPU failed: ") + cmp_last_error());
         cmp_bin_destroy(binner);
         binPairStore.resize((size_t)st.n_keys);
         for (size_t k = 0; k < (size_t)st.n_keys; ++k)
-            binPairStore[k] = PairView{ListView{devFirst.data() + off1[k], (size_t)(off1[k + 1] - off1[k])},
-                                       ListView{devSecond.data() + off2[k], (size_t)(off2[k + 1] - off2[k])}};
+            binPairStore[k] = PairView{ListView{devFirst.get() + off1[k], (size_t)(off1[k + 1] - off1[k])},
+                                       ListView{devSecond.get() + off2[k], (size_t)(off2[k + 1] - off2[k])}};
         if (timing)
             std::cerr << "[clustermatepairs]   bin pairs on the device: " << st.n_fragments << " fragments, " << st.n_concordant << " concordant, " << st.n_keys
                       << " bin pairs, " << st.n_first + st.n_second << " entries, kernels + sorts " << st.device_ms << " ms" << std::endl;
@@ -734,8 +747,8 @@ int main(int argc, char* argv[])
                 outShare[t] = std::min(std::max(at, outShare[t - 1]), hi);
             }
             run_threads(format_share);
-            out.write_round(texts, nThreads);
-            for (std::string& tbuf : texts) tbuf.clear();
+            out.write_round_async(std::move(texts), nThreads);          // copied into the file while the next round is formatted
+            texts = std::vector<std::string>(nThreads);
             lo = hi;
         }
     };

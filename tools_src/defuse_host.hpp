@@ -413,6 +413,25 @@ public:
         for (int b : bad) ok_ = ok_ && !b;
         pos_ = at[texts.size()];
     }
+    // The same round written behind the caller's back: the texts are taken over, a writer thread copies them into the file
+    // while the caller formats the next round (one round in flight; the next call, and close_file, wait for it).  The copy
+    // into the page cache is one core's work whatever the number of writers (the file's lock), so a tool whose output is
+    // gigabytes overlaps it with its formatting instead of alternating the two.
+    void write_round_async(std::vector<std::string>&& texts, unsigned threads)
+    {
+        std::unique_lock<std::mutex> lk(am_);
+        if (!athread_.joinable()) athread_ = std::thread([this] { async_loop(); });
+        acv_.wait(lk, [&] { return !ahave_; });
+        atexts_ = std::move(texts);
+        athreads_ = threads;
+        ahave_ = true;
+        acv_.notify_all();
+    }
+    void wait_async()
+    {
+        std::unique_lock<std::mutex> lk(am_);
+        acv_.wait(lk, [&] { return !ahave_ && !abusy_; });
+    }
     // For a caller whose own threads write: reserves consecutive ranges for parts of the given sizes (in order) and returns
     // where each begins; every thread then calls write_part with its own.  Not seekable: begin() returns false and the caller
     // writes the parts in order with append().
@@ -430,6 +449,15 @@ public:
     void append(const char* p, size_t n) { ok_ = ok_ && write_all(p, n, -1); }
     bool close_file()
     {
+        if (athread_.joinable()) {
+            wait_async();
+            {
+                std::lock_guard<std::mutex> lk(am_);
+                astop_ = true;
+            }
+            acv_.notify_all();
+            athread_.join();
+        }
         if (failed_.load()) ok_ = false;
         if (fd_ >= 0 && close(fd_) != 0) ok_ = false;
         fd_ = -1;
@@ -448,10 +476,40 @@ private:
         }
         return true;
     }
+    void async_loop()
+    {
+        for (;;) {
+            std::vector<std::string> texts;
+            unsigned threads;
+            {
+                std::unique_lock<std::mutex> lk(am_);
+                acv_.wait(lk, [&] { return ahave_ || astop_; });
+                if (!ahave_) return;
+                texts.swap(atexts_);
+                threads = athreads_;
+                ahave_ = false;
+                abusy_ = true;
+            }
+            acv_.notify_all();
+            write_round(texts, threads);
+            texts.clear();
+            {
+                std::lock_guard<std::mutex> lk(am_);
+                abusy_ = false;
+            }
+            acv_.notify_all();
+        }
+    }
     int fd_ = -1;
     off_t pos_ = 0;
     bool ok_ = true, seekable_ = true;
     std::atomic<bool> failed_{false};
+    std::thread athread_;
+    std::mutex am_;
+    std::condition_variable acv_;
+    std::vector<std::string> atexts_;
+    unsigned athreads_ = 1;
+    bool ahave_ = false, abusy_ = false, astop_ = false;
 };
 
 // A set of 64-bit keys for the hot de-duplication loops: open addressing, linear probing, grows at half full.
