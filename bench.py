@@ -67,16 +67,19 @@ def hip_runtime_mapped():
     return paths.pop()
 
 
-def profile_block(name, workload, lib_hash):
-    """A committed rocprofv3 counter summary (profiles/r02/<name>), only if it was taken on this workload AND on the
-    kernels that are running now (same hash of defuse_amd/csrc + flags as the loaded library reports)."""
+def profile_block(name, workload, lib_hash, same_size=True):
+    """A committed rocprofv3 counter summary (profiles/r04/<name>), only if it was taken on this workload AND on the
+    kernels that are running now (same hash of defuse_amd/csrc + flags as the loaded library reports).  same_size=False
+    accepts counters of the same shape (reads per fusion, read and window length) taken on another number of fusions: the
+    caller scales per-launch figures by the aligns per launch (the kernels' work per align does not depend on the count)."""
     path = os.path.join(PROFILE_DIR, name)
     try:
         d = json.load(open(path))
     except (OSError, ValueError):
         return None, "no %s" % os.path.relpath(path, ROOT)
     w = d.get("workload", {})
-    if workload is not None and tuple(w.get(k) for k in ("fusions", "reads", "lq", "lr")) != tuple(workload[k] for k in ("fusions", "reads", "lq", "lr")):
+    keys = ("fusions", "reads", "lq", "lr") if same_size else ("reads", "lq", "lr")
+    if workload is not None and tuple(w.get(k) for k in keys) != tuple(workload[k] for k in keys):
         return None, "%s was taken on another workload" % os.path.relpath(path, ROOT)
     if d.get("source_hash") != lib_hash:
         return None, "%s was taken on other kernels (source hash %s, library %s): re-profile" % (
@@ -84,17 +87,20 @@ def profile_block(name, workload, lib_hash):
     return d, os.path.relpath(path, ROOT)
 
 
-def valu_issue(workload, lib_hash, launch_ms, suffix=""):
+def valu_issue(workload, lib_hash, launch_ms, suffix="", aligns_per_launch=None):
     """The unit that binds this integer kernel (not HBM, not MFMA) is VALU issue.  Wave instructions per launch
     by kind come from the SQ counter passes of this build (pmc_sq.json); the duration is this run's HIP-event time; the
     peak prices every kind at its measured issue rate (profiles/microbench/valu_rate*.hip: 2 cycles per wave for
     v_add_u32 / v_sub / v_xor and the other plain VOP2 integer ops, 4 for VOP3P and max3), per SIMD, at the nominal 2.4 GHz."""
-    d, src = profile_block("pmc_sq%s.json" % suffix, workload, lib_hash)
+    d, src = profile_block("pmc_sq%s.json" % suffix, workload, lib_hash, same_size=not suffix)
     if d is None:
         return None, src
     n = d["launches"]
-    instr = d["pass1"]["SQ_INSTS_VALU"] / n
-    busy_quads = d["pass1"].get("SQ_ACTIVE_INST_VALU", 0) / n            # quad-cycles in which a SIMD issued VALU
+    scale = 1.0
+    if suffix and aligns_per_launch and d.get("aligns_per_launch"):
+        scale = aligns_per_launch / d["aligns_per_launch"]              # counters of the same shape at another launch size
+    instr = scale * d["pass1"]["SQ_INSTS_VALU"] / n
+    busy_quads = scale * d["pass1"].get("SQ_ACTIVE_INST_VALU", 0) / n   # quad-cycles in which a SIMD issued VALU
     simds = 256 * 4
     kernel_cycles = launch_ms * 1e-3 * 2.4e9
     out = {"valu_instructions_per_launch": instr,
@@ -534,9 +540,11 @@ def main():
         # counters are per launch: a launch is one upload (the whole batch at N = 1, UPLOAD_FUSIONS fusions of the configs[3] shape else)
         per_upload = dict(workload, fusions=share.n_pairs[0] // workload["reads"])
         suffix = "" if name == "config2" and not multi else "_config4"
-        tr, tr_src = profile_block("pmc_traffic%s.json" % suffix, per_upload, lib_hash)
+        tr, tr_src = profile_block("pmc_traffic%s.json" % suffix, per_upload, lib_hash, same_size=not suffix)
         traffic = tr["hbm_bytes_per_launch"] if tr else None
-        vi, vi_src = valu_issue(per_upload, lib_hash, launch_ms, suffix)
+        if tr and suffix and tr.get("aligns_per_launch"):
+            traffic *= aligns_per_launch / tr["aligns_per_launch"]
+        vi, vi_src = valu_issue(per_upload, lib_hash, launch_ms, suffix, aligns_per_launch)
         hbm = {"hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
                "hbm_traffic_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None}
         if vi:

@@ -57,7 +57,7 @@ def text_rows(n, parts):
     return out
 
 
-def generate(out, n_fragments, seed=7, n_chrom=24, chrom_len=60_000_000, chunk=1_000_000, lo=20, hi=60):
+def generate(out, n_fragments, seed=7, n_chrom=24, chrom_len=60_000_000, chunk=1_000_000, lo=100, hi=300):
     rng = np.random.default_rng(seed)
     os.makedirs(out, exist_ok=True)
     P = lambda n: os.path.join(out, n)
@@ -206,15 +206,16 @@ class Stages:
         return row, err
 
 
-def pipeline(out, n_chunks, stages, parallel=1, tag=""):
+def pipeline(out, n_chunks, stages, parallel=1, threads=16):
     """The chain on the files generate() wrote; returns the paths of the final files."""
     P = lambda n: os.path.join(out, n)
     T = lambda n: os.path.join(BIN, n)
     cm = ["-u", str(UFRAG), "-s", str(SFRAG)]
+    th = {"DEFUSE_THREADS": str(threads)}
     stages.run("clustermatepairs", [T("clustermatepairs"), "-m", "5", "-p", "0.95"] + cm + ["-a", P("spanning.txt"), "-c", P("clusters.0")],
-               [P("spanning.txt")], [P("clusters.0")])
+               [P("spanning.txt")], [P("clusters.0")], env=th)
     stages.run("merge_clusters", [T("defuse_glue"), "merge_clusters", P("clusters.0")], [P("clusters.0")], [P("clusters.all")], stdout=P("clusters.all"))
-    stages.run("setcover", [T("setcover"), "-m", "5", "-c", P("clusters.all"), "-o", P("clusters.sc.all")], [P("clusters.all")], [P("clusters.sc.all")])
+    stages.run("setcover", [T("setcover"), "-m", "5", "-c", P("clusters.all"), "-o", P("clusters.sc.all")], [P("clusters.all")], [P("clusters.sc.all")], env=th)
     stages.run("remove_duplicates", [T("defuse_glue"), "remove_duplicates", "5"], [P("clusters.sc.all")], [P("clusters.sc")], stdin=P("clusters.sc.all"),
                stdout=P("clusters.sc"))
     stages.run("get_align_regions", [T("defuse_glue"), "get_align_regions"], [P("clusters.sc")], [P("clusters.sc.regions")], stdin=P("clusters.sc"),
@@ -245,7 +246,7 @@ def pipeline(out, n_chunks, stages, parallel=1, tag=""):
     last_err = res[-1][1]
     stages.rows.append({"stage": "dosplitalign x %d chunks%s" % (n_chunks, (", %d at a time" % parallel) if parallel > 1 else ""), "wall_s": round(time.time() - t0, 3),
                         "gpu_s": round(gpu, 4), "bytes_in": bi, "bytes_out": bo, "per_chunk_wall_s": detail,
-                        "last_chunk_timing": [l for l in last_err.splitlines() if l.startswith("[dosplitalign]") and "  " not in l[:18]][-6:]})
+                        "last_chunk_timing": [l for l in last_err.splitlines() if l.startswith("[dosplitalign]")]})
     t0 = time.time()
     for c in range(n_chunks):
         subprocess.check_call("LC_ALL=C sort -n -k 1 %s > %s" % (P("split.%d" % c), P("split.%d.sorted" % c)), shell=True)
@@ -266,7 +267,7 @@ def recovered(break_file, planted, names):
         found.add((f[2], f[3], int(f[4])))
     ok = n = 0
     for k in range(len(planted["support"])):
-        if planted["support"][k] < 20:
+        if planted["support"][k] < 20:            # (the last fusion of a data set may have fewer)
             continue
         n += 1
         a = (names[planted["chr_a"][k]], "+-"[planted["strand_a"][k]], int(planted["break_a"][k]))
@@ -312,10 +313,15 @@ def main():
     ap.add_argument("--chrom-len", type=int, default=60_000_000)
     ap.add_argument("--chunk", type=int, default=1_000_000)
     ap.add_argument("--parallel", type=int, default=4, help="a second pass over the dosplitalign chunks with this many processes at a time")
+    ap.add_argument("--support", type=int, nargs=2, default=[100, 300], metavar=("LO", "HI"),
+                    help="fragments per fusion, uniform in [LO, HI]: 100 300 is the proportion of BASELINE configs[3] (200 reads per fusion); 20 60 makes five "
+                         "times as many fusions with a couple of candidates each per chunk (the table tiers of the fill kernel cannot amortise a fusion's tables then)")
+    ap.add_argument("--threads", type=int, default=16, help="DEFUSE_THREADS of clustermatepairs and setcover (dosplitalign: its own default)")
     ap.add_argument("--check", action="store_true", help="small sizes: compare the final files with the oracle chain and time it (the CPU baseline)")
     ap.add_argument("--generate-only", action="store_true")
     args = ap.parse_args()
-    info, planted, names = generate(args.out, args.fragments, chrom_len=args.chrom_len, chunk=args.chunk)
+    info, planted, names = generate(args.out, args.fragments, chrom_len=args.chrom_len, chunk=args.chunk, lo=args.support[0], hi=args.support[1])
+    info["fragments_per_fusion"] = args.support
     res = {"what": "BASELINE configs[4] shape on one GPU: %d fragments 2x%d bp, mu %g sigma %g, %d fusions, dosplitalign per chunk of %d fragments"
                    % (args.fragments, RL, UFRAG, SFRAG, info["fusions"], args.chunk), "input": info}
     if args.generate_only:
@@ -323,7 +329,7 @@ def main():
         return
     st = Stages()
     t0 = time.time()
-    brk = pipeline(args.out, info["chunks"], st)
+    brk = pipeline(args.out, info["chunks"], st, threads=args.threads)
     wall = time.time() - t0
     ok, n = recovered(brk, planted, names)
     res["stages"] = st.rows

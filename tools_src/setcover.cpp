@@ -235,6 +235,7 @@ int main(int argc, char* argv[])
             pc = Piece();
             std::string& buf = texts[t];
             buf.clear();
+            buf.reserve((rc[t + 1] - rc[t]) * 3 / 4 + 4096);
             // lines in batches: the owner of a line's fragment is a random word of a table far larger than the caches, so the
             // batch's words are asked for while its lines are parsed and looked at afterwards
             constexpr int BATCH = 32;
@@ -269,12 +270,18 @@ int main(int argc, char* argv[])
             lineBase += round[t].lines;
         }
         const double t1 = now();
-        out.write_round(texts, nThreads);
+        out.write_round_async(std::move(texts), nThreads);              // copied into the file while the next round is filtered
+        texts = std::vector<std::string>(nThreads);
         tFilter += t1 - t0;
         tWrite += now() - t1;
         lo = hi;
     }
-    if (timing) std::cerr << "[setcover]   lines filtered " << tFilter << " s, written " << tWrite << " s" << std::endl;
+    {
+        const double t1 = now();
+        out.wait_async();
+        tWrite += now() - t1;
+    }
+    if (timing) std::cerr << "[setcover]   lines filtered " << tFilter << " s, waited for the writer " << tWrite << " s" << std::endl;
     stage("write");
     warm.join();
     // the process ends here: unmapping the input and the runtime's own shutdown cost tenths of a second that produce nothing
