@@ -496,6 +496,26 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_plan_fusion(const uint8_t* __r
                 }
             }
         }
+        if (prm.use_bound && tprime == 0 && lq >= PLAN_K && lq <= PLAN_LQ) {
+            // A read that lies on ONE side as a whole — most of the mates DoAlignment enumerates do not cross the junction
+            // (tools/SplitAlignment.cpp:266-303) — has no split with both sides above the anchor minimum, but the split a = Lq
+            // (everything in M1, the M2 side empty and counted as 0, tools/SplitReadAligner.cpp:156-298) or a = 0 competes with
+            // its one side's score: the ungapped path of the WHOLE read along its diagonal is a lower bound of the final score
+            // too.  Without it such a read is swept with the slack of minScore alone.
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const bool have = side ? dg.have2 : dg.have1;
+                const int d = side ? dg.d2 : dg.d1, len = side ? len1 : len0;
+                if (have && d >= 0 && d + lq <= len) {
+                    int matches = 0;
+#pragma unroll
+                    for (int c = 0; c < PLAN_CHUNKS; ++c)
+                        if (32 * c < lq) matches += __builtin_popcount(plan_match32(rb.c[c], side ? codes1 : codes0, side ? valid1 : valid0, 32 * c, d));
+                    const int whole = 3 * matches - lq;
+                    if (whole >= DSA_MIN_SPLIT) tprime = max(tprime, min(whole, 65535));
+                }
+            }
+        }
         bound_out[p0 + k] = (uint16_t)tprime;
         const uint32_t key = ((uint32_t)(prm.use_rank ? diag : 0) << 16) | (uint32_t)k;
         if (n <= 2 * PLAN_THREADS) keys_small[k] = key;

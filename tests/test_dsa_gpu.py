@@ -396,6 +396,26 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout, r.stderr)
 
 
+@pytest.mark.parametrize("mix", [dict(decoy_frac=0.5), dict(inside_frac=0.5), dict(inside_frac=1.0), dict(inside_frac=0.4, decoy_frac=0.2, lq=150, lr=590)],
+                         ids=["decoys-50", "inside-50", "inside-100", "2x150-mixed"])
+def test_workload_mixes_equal_the_oracle(built, mix):
+    """The mixes bench.py reports beside the headline (what DoAlignment really enumerates, tools/SplitAlignment.cpp:266-303:
+    mates that do not cross the junction, mates that do not align at all), 100 000 pairs each, every record against the CPU
+    oracle — with the planner's bounds (whole-read-on-one-side bound included) and without them."""
+    import bench
+    from defuse_amd import dsa, synth
+    kw = dict(mix)
+    lq, lr = kw.pop("lq", 76), kw.pop("lr", 389)
+    batch = synth.make_batch(1000, 100, lq=lq, lr=lr, seed=11, **kw)
+    exp = bench.oracle_records(batch, len(batch[3]))
+    ctx = dsa.Context(0)
+    for flags in (0, dsa.PLAN_NO_TIGHTEN):
+        ctx.set_plan_options(flags)
+        got = ctx.align_batch(*batch)
+        assert len(got) == len(exp) and got.tobytes() == exp.tobytes(), (mix, flags)
+    ctx.close()
+
+
 def test_stream_carries_on_after_a_failed_batch(built, ora):
     """A batch of a stream that ends with a device / run error is consumed on the C side; the Python wrapper drops its entry
     in step, so a caller that catches the DsaError gets the FOLLOWING batches' own records (round-3 advice: it used to

@@ -117,8 +117,6 @@ struct Regions {
     dsa_record* recs[DEPTH];
     size_t cap_ref = 0, cap_reads = 0, cap_fusions = 0, cap_pairs = 0, cap_recs = 0;      // elements
     size_t hint_pairs = 0, hint_read_bytes = 0;       // what a batch usually holds: that much is made to exist ahead of its use
-    int hint_read_len = 0, hint_window = 0;           // read length and longest reference window the worker sizes its device buffers for
-    size_t hint_fusions = 0;
 };
 
 void* map_shared(size_t bytes)
@@ -180,44 +178,29 @@ void worker_main(Channel* ch, const Regions* R)
         return worker_fail(ch, "Error: no usable MI355X/HIP device (dsa_stream_create failed)");
     ch->t_stream = now();
     {
-        // Batches of the size the run will bring through every slot of the stream, before the first real one: the code objects
-        // are loaded, every kernel of the path has run, and the device buffers of all slots and of the shared lanes have their
-        // sizes — a slot's first batch otherwise spends 15-20 ms growing them (a hipFree waits for the device every time).
-        // Only the first reads are copies of their windows' junction (every stage has something to do); the others are poly-A,
-        // which the pruning drops after a few rows: the rehearsal has the real sizes at a fraction of the real work.  Buffers:
-        // the worker's own.
-        const int L = std::max(8, R->hint_read_len), W = std::max(L + 8, R->hint_window);
-        const size_t NP = std::max<size_t>(64, R->hint_pairs), NF = std::max<size_t>(1, std::min(R->hint_fusions, NP / 8));
-        std::vector<uint8_t> ref(NF * 2 * (size_t)W), reads(NP * (size_t)L);
-        uint32_t x = 12345;
-        for (size_t i = 0; i < ref.size(); ++i) { x = x * 1664525u + 1013904223u; ref[i] = (uint8_t)"ACGT"[x >> 30]; }
-        std::vector<dsa_fusion> fus(NF);
-        for (size_t f = 0; f < NF; ++f) fus[f] = dsa_fusion{(int32_t)f, (int32_t)(f * 2 * W), W, (int32_t)(f * 2 * W + W), W};
+        // One tiny batch through the stream: the code objects are loaded, every kernel of the path has run once and the small
+        // buffers exist — 40 ms that would otherwise sit in front of the first real batch.  Its buffers are the worker's own.
+        const int L = 40, W = 96, NP = 64;
+        std::vector<uint8_t> ref(2 * W), reads((size_t)NP * L);
+        for (int i = 0; i < 2 * W; ++i) ref[(size_t)i] = (uint8_t)"ACGT"[(i * 7 + i / 5) & 3];
+        for (int p = 0; p < NP; ++p)
+            for (int j = 0; j < L; ++j) reads[(size_t)p * L + j] = j < L / 2 ? ref[(size_t)(p % 8 + j)] : ref[(size_t)(W + 10 + p % 8 + j - L / 2)];
+        dsa_fusion fu{1, 0, W, W, W};
         std::vector<dsa_pair> pairs(NP);
-        for (size_t p = 0; p < NP; ++p) {
-            const size_t f = p * NF / NP;
-            const int a = 4 + (int)(p % (size_t)(L - 7));                       // read = window 0 [W-a, W) + window 1 [0, L-a)
-            if (p < 64) {
-                std::memcpy(&reads[p * L], &ref[f * 2 * W + (size_t)(W - a)], (size_t)a);
-                std::memcpy(&reads[p * L + a], &ref[f * 2 * W + W], (size_t)(L - a));
-            } else std::memset(&reads[p * L], 'A', (size_t)L);
-            pairs[p] = dsa_pair{};
-            pairs[p].fusion_idx = (int32_t)f;
-            pairs[p].read_off = (int32_t)(p * L);
-            pairs[p].read_len = L;
-            pairs[p].frag = (int32_t)p;
+        for (int p = 0; p < NP; ++p) {
+            pairs[(size_t)p] = dsa_pair{};
+            pairs[(size_t)p].read_off = p * L;
+            pairs[(size_t)p].read_len = L;
+            pairs[(size_t)p].frag = p;
         }
-        std::vector<dsa_record> out(4 * NP + 4096);
-        for (int k = 0; k < DEPTH; ++k) {
-            int64_t n = 0;
-            int rc = dsa.stream_submit(st, ref.data(), (int64_t)ref.size(), fus.data(), (int32_t)NF, reads.data(), (int64_t)reads.size(), pairs.data(), (int64_t)NP,
-                                       out.data(), (int64_t)out.size());
-            if (rc == DSA_OK) rc = dsa.stream_collect(st, &n);
-            if (rc == DSA_E_CAPACITY) {                   // (keep the stream in step all the same)
-                std::vector<dsa_record> big((size_t)n);
-                rc = dsa.stream_recollect(st, big.data(), n, &n);
-            }
-            if (rc != DSA_OK) return worker_fail(ch, std::string("Error: split alignment on the GPU failed: ") + dsa.stream_last_error(st));
+        std::vector<dsa_record> out(4096);
+        int64_t n = 0;
+        int rc = dsa.stream_submit(st, ref.data(), (int64_t)ref.size(), &fu, 1, reads.data(), (int64_t)reads.size(), pairs.data(), NP, out.data(), (int64_t)out.size());
+        if (rc == DSA_OK) rc = dsa.stream_collect(st, &n);
+        if (rc != DSA_OK && rc != DSA_E_CAPACITY) return worker_fail(ch, std::string("Error: split alignment on the GPU failed: ") + dsa.stream_last_error(st));
+        if (rc == DSA_E_CAPACITY) {                   // (cannot happen with 64 pairs; keep the stream in step all the same)
+            std::vector<dsa_record> big((size_t)n);
+            (void)dsa.stream_recollect(st, big.data(), n, &n);
         }
     }
     if (const char* e = std::getenv("DEFUSE_DSA_PINNED"))
@@ -396,23 +379,6 @@ int main(int argc, char* argv[])
         R.cap_recs = std::max<size_t>(8 * R.cap_pairs, (size_t)64 << 20);
         R.hint_pairs = std::min(batch_pairs, R.cap_pairs);
         R.hint_read_bytes = std::min<size_t>(R.hint_pairs * (size_t)std::max(cmd.integer("maxread"), 32), (size_t)256 << 20);
-        {   // the longest reference window the regions will give (SplitAlignmentTask::Initialize, tools/SplitAlignment.cpp:61-76: break
-            // length + maximum read length), the read length and the number of fusions: what the worker sizes its device buffers for
-            const int maxFrag = (int)(cmd.real("ufrag") + 3 * cmd.real("sfrag")), minRead = cmd.integer("minread"), maxRead = cmd.integer("maxread");
-            int longest = 0;
-            for (const auto& kv : regions)
-                for (const Location& loc : kv.second) {
-                    const int len = loc.end - loc.start + 1;
-                    longest = std::max(longest, maxFrag - len - minRead + 2 * std::min(maxRead, (int)(0.5 * len)) + maxRead);
-                }
-            R.hint_window = std::min(std::max(longest, 16), 4096);
-            R.hint_read_len = std::min(std::max(maxRead, 8), 1024);
-            R.hint_fusions = regions.size();
-            // (a run with few candidates would pay for a full-size rehearsal it does not need: the SAM file's size bounds them)
-            struct stat sst;
-            if (stat(cmd.str("improper").c_str(), &sst) == 0 && S_ISREG(sst.st_mode))
-                R.hint_pairs = std::min(R.hint_pairs, std::max<size_t>(64, (size_t)sst.st_size / 64));
-        }
         ch = (Channel*)map_shared(sizeof(Channel));
         bool ok = ch != nullptr;
         for (int s = 0; s < DEPTH && ok; ++s) {
