@@ -42,7 +42,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 #include "../../include/defuse_dsa.h"
 #include "dsa_diag.hpp"
@@ -1159,7 +1158,7 @@ __device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(differs) : "v"(v ^ m), "v"(one2));
     return (differs ^ one2) << c;
 }
-struct TileStops { int v[16]; };   // stored row groups of a wave's first tiles (wave-uniform)
+struct TileStops { int v[8]; };    // stored row groups of a wave's first tiles (wave-uniform)
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
                                                uint32_t* __restrict__ tmask, const int32_t* tstop, const TileStops& stops,
                                                const Geom& g, int w, int lane, int nch_wave, int lq)
@@ -1170,11 +1169,9 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
     uint4* tout = reinterpret_cast<uint4*>(tmask + (int64_t)w * g.lq1 * WAVE) + lane;
     const uint4* src = reinterpret_cast<const uint4*>(cmax + (int64_t)w * g.nch * g.lq1 * WAVE) + lane;
     const int64_t cstride = (int64_t)(g.lq1 >> 2) * WAVE;       // uint4 elements between two tiles
-    // all tiles of a row group in registers: one round of independent loads, then max and masks — for up to 8 tiles (windows
-    // of up to 512 bases: the 2x76 and 2x100 configurations) and for up to 16 (2x150: windows of 590 bases are ten tiles; with
-    // the tile-by-tile loop below this reduction was 37 % of the fill kernel's wave cycles there, profiles/r04/mix_stats.txt)
-    auto in_registers = [&](auto nc_tag) {
-        constexpr int NC = decltype(nc_tag)::value;
+    constexpr int NC = 8;
+    if (nch_wave <= NC) {
+        // all tiles of a row group in registers: one round of independent loads, then max and masks
         for (int gq = 0; gq < ngq; ++gq) {
             uint4 v[NC];
 #pragma unroll
@@ -1201,9 +1198,43 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
             out[(int64_t)gq * WAVE] = m;
             tout[(int64_t)gq * WAVE] = t;
         }
-    };
-    if (nch_wave <= 8) { in_registers(std::integral_constant<int, 8>{}); return; }
-    if (nch_wave <= 16) { in_registers(std::integral_constant<int, 16>{}); return; }
+        return;
+    }
+#ifndef DSA_NO_RM16
+    if (nch_wave <= 2 * NC) {
+        // 9 to 16 tiles (2x150 bp: windows of 590 bases are ten tiles): the same in two rounds of eight, the stops of the tiles
+        // beyond the eighth read back (wave-uniform).  With the tile-by-tile loop below this reduction was 37 % of the fill
+        // kernel's wave cycles at 2x150 (profiles/r04/mix_stats.txt).
+        int stop_hi[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) stop_hi[c] = NC + c < nch_wave ? load_tstop(tstop + (int64_t)w * g.nch + NC + c) : 0;
+        for (int gq = 0; gq < ngq; ++gq) {
+            uint4 v[NC], u[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                v[c] = gq < stops.v[c] ? src[c * cstride + (int64_t)gq * WAVE] : dead4;
+                u[c] = NC + c < nch_wave ? (gq < stop_hi[c] ? src[(NC + c) * cstride + (int64_t)gq * WAVE] : dead4) : make_uint4(0, 0, 0, 0);
+            }
+            uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                m.x = max2(m.x, v[c].x); m.y = max2(m.y, v[c].y); m.z = max2(m.z, v[c].z); m.w = max2(m.w, v[c].w);
+                if (NC + c < nch_wave) { m.x = max2(m.x, u[c].x); m.y = max2(m.y, u[c].y); m.z = max2(m.z, u[c].z); m.w = max2(m.w, u[c].w); }
+            }
+            uint4 t = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                t.x |= eq_bits(v[c].x, m.x, c); t.y |= eq_bits(v[c].y, m.y, c); t.z |= eq_bits(v[c].z, m.z, c); t.w |= eq_bits(v[c].w, m.w, c);
+                if (NC + c < nch_wave) {
+                    t.x |= eq_bits(u[c].x, m.x, NC + c); t.y |= eq_bits(u[c].y, m.y, NC + c); t.z |= eq_bits(u[c].z, m.z, NC + c); t.w |= eq_bits(u[c].w, m.w, NC + c);
+                }
+            }
+            out[(int64_t)gq * WAVE] = m;
+            tout[(int64_t)gq * WAVE] = t;
+        }
+        return;
+    }
+#endif
     for (int gq = 0; gq < ngq; ++gq) {
         uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         for (int c = 0; c < nch_wave; ++c) {
@@ -1284,7 +1315,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
             if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = stop;
             stop_prev = stop;
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (k == c) stops.v[k] = stop;
             l_in = wave_max(last_bnd);
         }
@@ -1593,7 +1624,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
         if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = gq;
         stop_prev = gq;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < 8; ++k)
             if (k == c) stops.v[k] = gq;
         l_in = wave_max(last_bnd);
     }

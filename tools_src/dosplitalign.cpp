@@ -477,6 +477,7 @@ int main(int argc, char* argv[])
     } reads_joiner{reads_thread};
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
                                                          cmd.integer("minread"), cmd.integer("maxread"), regions);
+    stage("  tasks (windows from the FASTA, mate regions)");
 
     // SplitReadRealigner::AddTask (tools/SplitAlignment.cpp:236-251): 2000 bp bins over the mate regions
     // The ids in the bins are task ORDINALS (position in ascending fusion id order) rather than fusion ids: they sort the
