@@ -451,14 +451,16 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     const unsigned mask = L.tier_hint | 1u;
     L.tiers_launched = mask;
     g.tiers_launched = mask;
-    hipLaunchKernelGGL(k_fill_fast<0>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
-                       L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
-    if (mask & 2u)
-        hipLaunchKernelGGL(k_fill_fast<1>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
-                           L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
-    if (mask & 4u)
-        hipLaunchKernelGGL(k_fill_fast<2>, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, ctx->d_reads.p,
-                           L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);
+    // (the instantiation with the in-register row-maximum reduction for 9-16 tiles only where a slice has that many:
+    // windows beyond 512 bases, e.g. 2x150 bp reads)
+#define DSA_LAUNCH_FILL(TIER, WIDE)                                                                                                              \
+    hipLaunchKernelGGL((k_fill_fast<TIER, WIDE>), dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, \
+                       ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g)
+    const bool wide = g.nch > 8 && g.nch <= 16;
+    if (wide) DSA_LAUNCH_FILL(0, true); else DSA_LAUNCH_FILL(0, false);
+    if (mask & 2u) { if (wide) DSA_LAUNCH_FILL(1, true); else DSA_LAUNCH_FILL(1, false); }
+    if (mask & 4u) { if (wide) DSA_LAUNCH_FILL(2, true); else DSA_LAUNCH_FILL(2, false); }
+#undef DSA_LAUNCH_FILL
     if (mask & 8u)
         hipLaunchKernelGGL(k_fill_generic, dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, ctx->d_fusions.p, L.d_wg_tier.p, ctx->d_refcodes.p,
                            ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g);

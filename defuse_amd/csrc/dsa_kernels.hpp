@@ -1159,6 +1159,10 @@ __device__ __forceinline__ uint32_t eq_bits(uint32_t v, uint32_t m, int c)
     return (differs ^ one2) << c;
 }
 struct TileStops { int v[8]; };    // stored row groups of a wave's first tiles (wave-uniform)
+// WIDE: with the in-register path for 9 to 16 tiles.  It is a template parameter of the fill kernels (the host picks the
+// instantiation by the slice's tile count) because its mere presence in a kernel costs the sweep of the common, narrower
+// shapes 4 % — the compiler's schedule of the sweep loop is sensitive to what else the kernel holds (profiles/r04/ab_rm16.txt).
+template <bool WIDE>
 __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax, uint32_t* __restrict__ rmax,
                                                uint32_t* __restrict__ tmask, const int32_t* tstop, const TileStops& stops,
                                                const Geom& g, int w, int lane, int nch_wave, int lq)
@@ -1200,8 +1204,7 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
         }
         return;
     }
-#ifndef DSA_NO_RM16
-    if (nch_wave <= 2 * NC) {
+    if (WIDE && nch_wave <= 2 * NC) {
         // 9 to 16 tiles (2x150 bp: windows of 590 bases are ten tiles): the same in two rounds of eight, the stops of the tiles
         // beyond the eighth read back (wave-uniform).  With the tile-by-tile loop below this reduction was 37 % of the fill
         // kernel's wave cycles at 2x150 (profiles/r04/mix_stats.txt).
@@ -1234,7 +1237,6 @@ __device__ __forceinline__ void reduce_row_max(const uint32_t* __restrict__ cmax
         }
         return;
     }
-#endif
     for (int gq = 0; gq < ngq; ++gq) {
         uint4 m = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
         for (int c = 0; c < nch_wave; ++c) {
@@ -1320,7 +1322,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
             l_in = wave_max(last_bnd);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-        reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
+        reduce_row_max<false>(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
     }
     WgView wgi = {};                             // no tables, no groups: every task goes to k_replay
     wgi.list = nullptr;
@@ -1509,7 +1511,7 @@ __host__ __device__ constexpr int tier_of(int n_groups) { return n_groups <= GMA
 #ifndef DSA_FAST_WGS
 #define DSA_FAST_WGS 4        // workgroups (of four waves) per CU the table tiers 0 and 1 are compiled for
 #endif
-template <int TIER>
+template <int TIER, bool WIDE = false>
 __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill_fast(const dsa_pair* __restrict__ pairs,
                                                            uint8_t* __restrict__ wg_tier,
                                                            const uint32_t* __restrict__ refcodes,
@@ -1633,7 +1635,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     if (DIAG_TAIL) {
         if (live) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // own stores before own re-reads
-            reduce_row_max(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
+            reduce_row_max<WIDE>(cmax, rmax, tmask, fb.tstop, stops, g, w, lane, wi.nch_max, wi.lq_max);
         }
         t_rowmax = clk.lap();
         // The latency-bound finish work of this workgroup runs here, in the shadow of the other resident

@@ -11,7 +11,7 @@ for v in "$@"; do
 import csv, glob, sys
 ks = glob.glob(sys.argv[1] + "/kt/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(ks)):
-    if any(k in r["Name"] for k in ("k_emit", "k_replay", "k_fill_fast<0>")):
+    if any(k in r["Name"] for k in ("k_emit", "k_replay", "k_fill_fast<0")):
         print("  %-30s avg_us %10.1f" % (r["Name"].split("(")[0][-30:], float(r["AverageNs"]) / 1e3))
 PY
 done

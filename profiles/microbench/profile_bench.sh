@@ -48,7 +48,7 @@ def per_kernel(path, counters):
 
 FILL = "k_fill_fast<0>"
 def pick(tot):
-    ks = [k for k in tot if "k_fill_fast" in k and "<0>" in k] or [k for k in tot if "k_fill_fast" in k]
+    ks = [k for k in tot if "k_fill_fast<0" in k] or [k for k in tot if "k_fill_fast" in k]
     return max(ks, key=lambda k: sum(tot[k].values()))
 
 raw = {}
