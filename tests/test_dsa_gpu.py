@@ -416,6 +416,43 @@ def test_workload_mixes_equal_the_oracle(built, mix):
     ctx.close()
 
 
+def test_timing_cells_is_exact_on_every_planning_path(built):
+    """dsa_timing.cells = sum over pairs of (Lref0 + 1 + Lref1 + 1) * (Lread + 1), whatever the planning did: the planned
+    sweep, the caller's order (PLAN_NO_REORDER), a fusion whose pairs are not contiguous (the identity path of the slice),
+    reads beyond the 16-bit kernels (their blanked copies must not count twice), several slices."""
+    from defuse_amd import dsa
+
+    def expected(b):
+        ref, fus, reads, pairs = b
+        f = fus[pairs["fusion_idx"]]
+        return int(((f["ref0_len"].astype(np.int64) + 1 + f["ref1_len"] + 1) * (pairs["read_len"].astype(np.int64) + 1)).sum())
+    ctx = dsa.Context(0)
+    b = cases.mixed_batch(31, n_fusions=9, reads_per_fusion=70, lq=60, lr=(150, 400))
+    for flags in (0, dsa.PLAN_NO_REORDER, dsa.PLAN_NO_TIGHTEN | dsa.PLAN_NO_RANK):
+        ctx.set_plan_options(flags)
+        ctx.align_batch(*b)
+        assert ctx.timing().cells == expected(b), flags
+    ctx.set_plan_options(0)
+    ref, fus, reads, pairs = b
+    shuffled = pairs[np.random.default_rng(3).permutation(len(pairs))]           # fusions in several runs
+    ctx.align_batch(ref, fus, reads, shuffled)
+    assert ctx.timing().cells == expected((ref, fus, reads, shuffled))
+    ctx.set_scratch_budget(1 << 20)                                              # several slices
+    ctx.align_batch(*b)
+    assert ctx.timing().fill_launches > 1 and ctx.timing().cells == expected(b)
+    ctx.close()
+    ctx = dsa.Context(0)
+    long_b = cases.mixed_batch(32, n_fusions=2, reads_per_fusion=6, lq=60, lr=(150, 300))
+    ref, fus, reads, pairs = long_b
+    big = np.frombuffer(cases.rnd(np.random.default_rng(5), 8000), dtype=np.uint8)      # one read of 8000 bases: the 32-bit path
+    reads2 = np.concatenate([reads, big])
+    pairs2 = np.concatenate([pairs, pairs[:1]])
+    pairs2[-1]["read_off"], pairs2[-1]["read_len"] = len(reads), len(big)
+    ctx.align_batch(ref, fus, reads2, pairs2)
+    assert ctx.timing().cells == expected((ref, fus, reads2, pairs2))
+    ctx.close()
+
+
 def test_stream_carries_on_after_a_failed_batch(built, ora):
     """A batch of a stream that ends with a device / run error is consumed on the C side; the Python wrapper drops its entry
     in step, so a caller that catches the DsaError gets the FOLLOWING batches' own records (round-3 advice: it used to

@@ -46,6 +46,10 @@ int main(int argc, char* argv[])
     // finds — no device, say — is sc_cover's to report, at the place the tool has always reported it.  An error exit first
     // lets that thread leave the runtime, then ends the process without running exit handlers beside it.
     std::thread warm([] { (void)sc_prepare(dsa_pick_device()); });
+    struct Joiner {                                      // (an exception that unwinds main must not meet a joinable thread)
+        std::thread& th;
+        ~Joiner() { if (th.joinable()) th.join(); }
+    } warm_joiner{warm};
     static std::mutex die_mutex;
     die_hook() = [&] {
         die_mutex.lock();
