@@ -6,6 +6,8 @@ timeout -k 10 500 python -m pytest tests/test_clustermatepairs.py tests/test_cmp
 tail -2 $O/pytest.txt
 timeout -k 10 300 python profiles/microbench/e2e_scale.py --fragments 6000 --chrom-len 600000 --chunk 3000 --out /tmp/e2e_small --check --json $O/e2e_check.json > $O/e2e_check.log 2>&1 || { tail -30 $O/e2e_check.log; exit 1; }
 grep -E "tools_equal|fragments_per_s|exactly" $O/e2e_check.json
+timeout -k 10 400 python profiles/microbench/tool_throughput.py 10000 100 10 > $O/tool_throughput.txt 2>&1 || { tail -20 $O/tool_throughput.txt; exit 1; }
+grep -E "best|summary|candidates/s" $O/tool_throughput.txt
 timeout -k 10 600 bash profiles/microbench/cmp50_stages.sh > $O/cmp50.log 2>&1 || { tail -20 $O/cmp50.log; exit 1; }
 cp gpurun_out/cmp50/timing.txt $O/cmp50_stage_timing.txt
 grep -E "real|user|sys|kernel|stages overlapped|records on|read \+ bin|bin pairs on" $O/cmp50_stage_timing.txt | head -12
