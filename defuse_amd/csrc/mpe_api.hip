@@ -943,13 +943,38 @@ __device__ unsigned long long g_mpe_phase[8];
 
 struct ProblemShared {
     double W[MPE_NCOMP], A[MPE_NCOMP], B[MPE_NCOMP];
-    double px[MPE_KMAX], py[MPE_KMAX];
-    double c[MPE_KMAX + 1][2 * MPE_KMAX];
-    KmState km[MPE_KMAX + 1];                  // k-means state of the fit with K centres
     double like[MPE_KMAX + 1], last[MPE_KMAX + 1];
     int active[MPE_KMAX + 1], valid[MPE_KMAX + 1], state[MPE_KMAX + 1], zero[MPE_KMAX + 1], ifault[MPE_KMAX + 1];
     int n_seeds, any_active;
 };
+
+// What the three kernels of a wave problem hand to each other (round 4: the k-means start-ups left the wave kernel).
+//   k_mpe_seed         one wave per problem: the arrays all fits share, the runs of equal coordinates, the KKZ seeds
+//   k_mpe_kmeans       ONE LANE PER FIT, 64 fits of similar size per wave: AS 136 from the seeds.  Inside the wave kernel the
+//                      start-ups ran in at most nine of 64 lanes while the others waited (18 % of its wave cycles)
+//   k_mpe_problem_wave one wave per problem: responsibilities from the k-means assignments, EM of all fits, model selection
+struct ProblemSeeds {
+    double px[MPE_KMAX], py[MPE_KMAX];
+    int n_seeds;            // -1: the problem is not fitted at all (fewer mate pairs than a cluster needs)
+    int Gx, Gy, pad_;
+};
+constexpr int KM_NOT_RUN = -1;          // ifault slot of a fit that needs no k-means (K = 1, K = N) or has no seeds
+
+// the arrays shared by the fits of a problem live behind the largest fit's own
+struct SharedArrays { double *XO, *YO, *XYU, *ka, *XG, *YG; int *XfromY, *gmap; };
+__device__ __forceinline__ SharedArrays shared_arrays(double* shared_d, int N)
+{
+    SharedArrays a;
+    a.XO = shared_d; shared_d += N;
+    a.YO = shared_d; shared_d += N;
+    a.XYU = shared_d; shared_d += N;
+    a.ka = shared_d; shared_d += 2 * (size_t)N;
+    a.XfromY = (int*)shared_d; shared_d += N;
+    a.gmap = (int*)shared_d; shared_d += N;             // gx [N], gy [N]
+    a.XG = shared_d; shared_d += N;
+    a.YG = shared_d;
+    return a;
+}
 
 struct FitArrays { double *RXO, *SX, *SY, *kd, *GA, *GB; int *ic1, *ic2; };
 
@@ -967,12 +992,124 @@ __device__ __forceinline__ FitArrays fit_arrays(int N, int K, double* d, int* ip
     return f;
 }
 
+// ---- k_mpe_seed: set-up of the shared arrays and the KKZ seeds (:327-386), one wave per problem
+__global__ __launch_bounds__(WV) void k_mpe_seed(mpe_params prm, const int64_t* __restrict__ prob_off, int p0, const int32_t* __restrict__ order,
+                                                const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ u,
+                                                const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo, const int64_t* __restrict__ wd_off,
+                                                double* __restrict__ wdoubles, ProblemSeeds* __restrict__ seeds)
+{
+    __shared__ double s_px[MPE_KMAX], s_py[MPE_KMAX];
+    __shared__ int s_n_seeds;
+    const int lane = threadIdx.x;
+    const int q = order[blockIdx.x];
+    const int p = p0 + q;
+    const int64_t b = prob_off[p];
+    const int N = (int)(prob_off[p + 1] - b);
+    ProblemSeeds& out = seeds[blockIdx.x];
+    if ((double)N < (double)prm.min_cluster_size || N == 0) {       // :542-545
+        if (lane == 0) out.n_seeds = -1;
+        return;
+    }
+    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
+    const SharedArrays a = shared_arrays(wdoubles + wd_off[q * MPE_KMAX + kmax - 1] + wave_fit_doubles(N, kmax), N);
+    const double *X = x + b, *Y = y + b, *U = u + b;
+    const int32_t *TX = to_xo + b, *TY = to_yo + b;
+    for (int i = lane; i < N; i += WV) {
+        a.XO[TX[i]] = X[i];
+        a.YO[TY[i]] = Y[i];
+        a.XYU[i] = X[i] + Y[i] + U[i];
+        a.XfromY[TY[i]] = TX[i];
+        a.ka[i] = Y[i];                        // both inserts are at begin(): a = [Y..., X...]
+        a.ka[N + i] = X[i];
+    }
+    __syncthreads();
+    // the runs of equal coordinates in x order and in y order, once per problem: group of every rank, coordinate of every group
+    auto runs = [&](const double* O, int* grp, double* coord) {
+        int cnt = 0;
+        for (int base = 0; base < N; base += WV) {
+            const int r = base + lane;
+            const bool first = r < N && (r == 0 || O[r] != O[r - 1]);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
+            const int gi = cnt + __popcll(m & ((1ull << lane) - 1ull)) + (first ? 1 : 0) - 1;
+            if (r < N) {
+                grp[r] = gi;
+                if (first) coord[gi] = O[r];
+            }
+            cnt += __popcll(m);
+        }
+        return cnt;
+    };
+    const int Gx = runs(a.XO, a.gmap, a.XG);
+    const int Gy = runs(a.YO, a.gmap + N, a.YG);
+    // KKZ seeds, once for kmax; a fit needs seeds unless K == 1 or K == N
+    double best = 0.0;
+    int bi = -1;
+    for (int i = lane; i < N; i += WV) {
+        const double l2 = X[i] * Y[i];
+        if (bi < 0 || l2 > best) { best = l2; bi = i; }
+    }
+    double vm;
+    const int imax = wave_first_argmax(best, bi, vm);
+    if (lane == 0) { s_px[0] = X[imax]; s_py[0] = Y[imax]; s_n_seeds = 1; }
+    __syncthreads();
+    for (int na = 1; na < kmax; ++na) {
+        best = 0.0;
+        bi = -1;
+        for (int i = lane; i < N; i += WV) {
+            double md = (X[i] - s_px[0]) * (X[i] - s_px[0]) + (Y[i] - s_py[0]) * (Y[i] - s_py[0]);
+            for (int j = 1; j < na; ++j) {
+                const double dj = (X[i] - s_px[j]) * (X[i] - s_px[j]) + (Y[i] - s_py[j]) * (Y[i] - s_py[j]);
+                md = fmin(md, dj);
+            }
+            if (bi < 0 || md > best) { best = md; bi = i; }
+        }
+        const int idx = wave_first_argmax(best, bi, vm);
+        if (vm == 0.0) break;                              // SelectKKZ fails for every K > na
+        __syncthreads();
+        if (lane == 0) { s_px[na] = X[idx]; s_py[na] = Y[idx]; s_n_seeds = na + 1; }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane < MPE_KMAX) { out.px[lane] = lane < s_n_seeds ? s_px[lane] : 0.0; out.py[lane] = lane < s_n_seeds ? s_py[lane] : 0.0; }
+    if (lane == 0) { out.n_seeds = s_n_seeds; out.Gx = Gx; out.Gy = Gy; out.pad_ = 0; }
+}
+
+// ---- k_mpe_kmeans: the AS 136 start-up of every fit that needs one (:388-450), one lane per fit.  Fit g = (K - 2) * n_large +
+// rank: the lanes of a wave hold fits of one K on problems of neighbouring sizes (the problems are sorted by size), which is as
+// alike as 64 independent sequential k-means runs get.  Per-lane state in LDS (private arrays would live in scratch memory),
+// the lane stride an odd number of 8-byte words.
+struct KmLane { KmState st; double c[2 * MPE_KMAX]; double pad_; };
+static_assert(sizeof(KmLane) % 16 == 8, "lane stride: an odd number of 8-byte words");
+__global__ __launch_bounds__(WV) void k_mpe_kmeans(const int64_t* __restrict__ prob_off, int p0, int n_large, const int32_t* __restrict__ order,
+                                                  const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
+                                                  int* __restrict__ wints, const ProblemSeeds* __restrict__ seeds, int* __restrict__ ifault_out)
+{
+    __shared__ KmLane s_lane[WV];
+    const int64_t g = (int64_t)blockIdx.x * WV + threadIdx.x;
+    const int K = 2 + (int)(g / n_large), r = (int)(g % n_large);
+    if (K > MPE_KMAX) return;
+    const int q = order[r];
+    const int p = p0 + q;
+    const int N = (int)(prob_off[p + 1] - prob_off[p]);
+    const ProblemSeeds& sd = seeds[r];
+    int result = KM_NOT_RUN;
+    const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
+    if (sd.n_seeds >= K && K <= kmax && K != N) {
+        KmLane& L = s_lane[threadIdx.x];
+        const SharedArrays a = shared_arrays(wdoubles + wd_off[q * MPE_KMAX + kmax - 1] + wave_fit_doubles(N, kmax), N);
+        FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+        for (int j = 0; j < K; ++j) { L.c[j] = sd.py[j]; L.c[K + j] = sd.px[j]; }
+        result = kmns(a.ka, N, L.c, K, f.ic1, f.ic2, f.kd, KMEANS_ITER, L.st);
+    }
+    ifault_out[(int64_t)r * (MPE_KMAX + 1) + K] = result;
+}
+
 __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_problem_wave(
     mpe_params prm, const int64_t* __restrict__ prob_off, int p0, const int32_t* __restrict__ order, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ u, const int32_t* __restrict__ to_xo, const int32_t* __restrict__ to_yo,
     const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles, int* __restrict__ wints,
     int32_t* __restrict__ n_clusters, uint16_t* __restrict__ member, int32_t* __restrict__ status, unsigned long long* __restrict__ iters,
-    long long* __restrict__ iters_by_k, double* __restrict__ ll_by_k)
+    long long* __restrict__ iters_by_k, double* __restrict__ ll_by_k, const ProblemSeeds* __restrict__ seeds, const int* __restrict__ km_ifault)
 {
     __shared__ ProblemShared s;
 #ifdef MPE_PHASE_STATS
@@ -997,99 +1134,36 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
             if (l == lane) { myK = K; myJ = j; }
     const int myL = myK ? myK * (myK - 1) / 2 + myJ : 0;
 
-    // arrays shared by the fits live behind the largest fit's own
+    // arrays shared by the fits live behind the largest fit's own; k_mpe_seed has filled them
     const int slot_max = q * MPE_KMAX + kmax - 1;
-    double* shared_d = wdoubles + wd_off[slot_max] + wave_fit_doubles(N, kmax);
+    const SharedArrays sa = shared_arrays(wdoubles + wd_off[slot_max] + wave_fit_doubles(N, kmax), N);
+    const ProblemSeeds& sd = seeds[blockIdx.x];
     Work w;
     w.N = N;
     w.X = x + b; w.Y = y + b; w.U = u + b;
     w.ToXO = to_xo + b; w.ToYO = to_yo + b;
     w.TX = w.ToXO;
-    w.XO = shared_d; shared_d += N;
-    w.YO = shared_d; shared_d += N;
-    double* xyu = shared_d; shared_d += N;
-    w.XYU = xyu;
-    w.ka = shared_d; shared_d += 2 * (size_t)N;
-    w.XfromY = (int*)shared_d; shared_d += N;
-    int* gmap = (int*)shared_d; shared_d += N;             // gx [N], gy [N]
-    double* xg = shared_d; shared_d += N;
-    double* yg = shared_d;
-    w.gx = gmap; w.gy = gmap + N; w.XG = xg; w.YG = yg;
+    w.XO = sa.XO;
+    w.YO = sa.YO;
+    w.XYU = sa.XYU;
+    w.ka = sa.ka;
+    w.XfromY = sa.XfromY;
+    w.gx = sa.gmap; w.gy = sa.gmap + N; w.XG = sa.XG; w.YG = sa.YG;
+    w.Gx = sd.Gx;
+    w.Gy = sd.Gy;
     w.sd = prm.fragment_stddev;
-    for (int i = lane; i < N; i += WV) {
-        w.XO[w.ToXO[i]] = w.X[i];
-        w.YO[w.ToYO[i]] = w.Y[i];
-        xyu[i] = w.X[i] + w.Y[i] + w.U[i];
-        w.XfromY[w.ToYO[i]] = w.ToXO[i];
-        w.ka[i] = w.Y[i];                      // both inserts are at begin(): a = [Y..., X...]
-        w.ka[N + i] = w.X[i];
-    }
     if (lane <= MPE_KMAX) { s.active[lane] = 0; s.valid[lane] = 0; s.state[lane] = 0; s.zero[lane] = 0; s.ifault[lane] = 0; s.like[lane] = 0.0; s.last[lane] = 0.0; }
     if (lane < MPE_NCOMP) { s.W[lane] = 0.0; s.A[lane] = 0.0; s.B[lane] = 0.0; }
+    if (lane == 0) s.n_seeds = sd.n_seeds;
     __syncthreads();
-    // the runs of equal coordinates in x order and in y order, once per problem: group of every rank, coordinate of every group
-    {
-        auto runs = [&](const double* O, int* grp, double* coord) {
-            int cnt = 0;
-            for (int base = 0; base < N; base += WV) {
-                const int r = base + lane;
-                const bool first = r < N && (r == 0 || O[r] != O[r - 1]);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(first);
-                const int gi = cnt + __popcll(m & ((1ull << lane) - 1ull)) + (first ? 1 : 0) - 1;
-                if (r < N) {
-                    grp[r] = gi;
-                    if (first) coord[gi] = O[r];
-                }
-                cnt += __popcll(m);
-            }
-            return cnt;
-        };
-        w.Gx = runs(w.XO, gmap, xg);
-        w.Gy = runs(w.YO, gmap + N, yg);
-    }
-    __syncthreads();
-
     MPE_STAMP(0);
-    // ---- KKZ seeds (:327-386), once for kmax; a fit needs seeds unless K == 1 or K == N
-    {
-        double best = 0.0;
-        int bi = -1;
-        for (int i = lane; i < N; i += WV) {
-            const double l2 = w.X[i] * w.Y[i];
-            if (bi < 0 || l2 > best) { best = l2; bi = i; }
-        }
-        double vm;
-        const int imax = wave_first_argmax(best, bi, vm);
-        if (lane == 0) { s.px[0] = w.X[imax]; s.py[0] = w.Y[imax]; s.n_seeds = 1; }
-        __syncthreads();
-        for (int na = 1; na < kmax; ++na) {
-            best = 0.0;
-            bi = -1;
-            for (int i = lane; i < N; i += WV) {
-                double md = (w.X[i] - s.px[0]) * (w.X[i] - s.px[0]) + (w.Y[i] - s.py[0]) * (w.Y[i] - s.py[0]);
-                for (int j = 1; j < na; ++j) {
-                    const double dj = (w.X[i] - s.px[j]) * (w.X[i] - s.px[j]) + (w.Y[i] - s.py[j]) * (w.Y[i] - s.py[j]);
-                    md = fmin(md, dj);
-                }
-                if (bi < 0 || md > best) { best = md; bi = i; }
-            }
-            const int idx = wave_first_argmax(best, bi, vm);
-            if (vm == 0.0) break;                              // SelectKKZ fails for every K > na
-            __syncthreads();
-            if (lane == 0) { s.px[na] = w.X[idx]; s.py[na] = w.Y[idx]; s.n_seeds = na + 1; }
-            __syncthreads();
-        }
-        __syncthreads();
-    }
     MPE_STAMP(1);
-    // ---- start-up of every fit (:388-450): uniform responsibilities, or k-means from the seeds (one fit per lane)
+    // ---- start-up of every fit (:388-450): uniform responsibilities, or the k-means assignments k_mpe_kmeans left
     if (lane >= 1 && lane <= kmax) {
         const int K = lane;
         if (K == 1 || K == N) s.active[K] = 1;
         else if (s.n_seeds >= K) {
-            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
-            for (int j = 0; j < K; ++j) { s.c[K][j] = s.py[j]; s.c[K][K + j] = s.px[j]; }
-            const int ifault = kmns(w.ka, N, s.c[K], K, f.ic1, f.ic2, f.kd, KMEANS_ITER, s.km[K]);
+            const int ifault = km_ifault[(int64_t)blockIdx.x * (MPE_KMAX + 1) + K];
             s.ifault[K] = ifault;
             if (ifault == 1 || ifault == 3) s.state[K] = 2;    // DebugCheck(ifault != 1 / != 3)
             else s.active[K] = 1;
@@ -1389,6 +1463,8 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
             return prob_off[p0 + a + 1] - prob_off[p0 + a] > prob_off[p0 + b + 1] - prob_off[p0 + b];
         });
         DBuf<int64_t> d_wd, d_wi;
+        DBuf<ProblemSeeds> d_seeds;
+        DBuf<int> d_km_ifault;
         DBuf<int32_t> d_order, d_state;
         DBuf<double> d_work, d_bic;
         DBuf<int> d_iwork;
@@ -1406,10 +1482,18 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         t.n_wave_problems += n_large;
         MPE_HIP(hipEventRecord(e0, 0));
         MPE_HIP(hipStreamWaitEvent(s_wave, e0, 0));
-        if (n_large)                 // order[0 .. n_large): the problems with a wave of their own, largest first
+        if (n_large) {               // order[0 .. n_large): the problems with a wave of their own, largest first
+            MPE_HIP(d_seeds.alloc((size_t)n_large));
+            MPE_HIP(d_km_ifault.alloc((size_t)n_large * (MPE_KMAX + 1)));
+            hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p,
+                               d_tyo.p, d_wd.p, d_work.p, d_seeds.p);
+            const int64_t n_km = (int64_t)n_large * (MPE_KMAX - 1);            // fits with K = 2 .. 10
+            hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)((n_km + WV - 1) / WV)), dim3(WV), 0, s_wave, d_off.p, p0, n_large, d_order.p, d_wd.p, d_wi.p,
+                               d_work.p, d_iwork.p, d_seeds.p, d_km_ifault.p);
             hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
                                d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
-                               d_iters.p, d_by_k.p, d_ll_by_k.p);
+                               d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p, d_km_ifault.p);
+        }
         if (n_small) {
             const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
             hipLaunchKernelGGL(k_mpe_fit, dim3((unsigned)((n_fit + 63) / 64)), dim3(64), 0, 0, *params, d_off.p, p0, n_large, n_small,
