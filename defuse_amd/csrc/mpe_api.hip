@@ -1415,12 +1415,8 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     MPE_HIP(e0.create());
     MPE_HIP(e1.create());
     MPE_HIP(e2.create());
-    hipraii::Stream s_wave, s_wave2;
+    hipraii::Stream s_wave;
     MPE_HIP(s_wave.create(hipStreamNonBlocking));
-    MPE_HIP(s_wave2.create(hipStreamNonBlocking));
-    hipraii::Event e_km0, e_w2;
-    MPE_HIP(e_km0.create());
-    MPE_HIP(e_w2.create());
     // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none).  The wave
     // version is the faster one at every size (profiles/microbench/mpe_sweep.sh); the lane version stays as the literal
     // transcription it is checked against
@@ -1486,45 +1482,17 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         t.n_wave_problems += n_large;
         MPE_HIP(hipEventRecord(e0, 0));
         MPE_HIP(hipStreamWaitEvent(s_wave, e0, 0));
-        MPE_HIP(hipStreamWaitEvent(s_wave2, e0, 0));
         if (n_large) {               // order[0 .. n_large): the problems with a wave of their own, largest first
-            // The k-means kernel (one lane per fit: divergent, 68 ms by itself on the 5 M-fragment probe) and the EM kernel (one
-            // wave per problem: waiting for memory half of its cycles) use different parts of the chip, and a SIMD has room for one
-            // wave of the first beside two of the second.  So the problems are dealt into MPE_PARTS interleaved parts (every part the
-            // whole range of sizes) that go down two streams alternately: part k's k-means runs while part k-1's EM does; only the
-            // first part's k-means stands alone.
-            constexpr int MPE_PARTS = 4;
-            std::vector<int32_t> dealt((size_t)n_large);
-            int part_at[MPE_PARTS + 1];
-            {
-                int at = 0;
-                for (int k = 0; k < MPE_PARTS; ++k) {
-                    part_at[k] = at;
-                    for (int r = k; r < n_large; r += MPE_PARTS) dealt[(size_t)at++] = order[(size_t)r];
-                }
-                part_at[MPE_PARTS] = at;
-            }
-            MPE_HIP(hipMemcpy(d_order.p, dealt.data(), dealt.size() * sizeof(int32_t), hipMemcpyHostToDevice));      // (the lane kernels read order[n_large ..))
             MPE_HIP(d_seeds.alloc((size_t)n_large));
             MPE_HIP(d_km_ifault.alloc((size_t)n_large * (MPE_KMAX + 1)));
-            hipStream_t lanes2[2] = {s_wave, s_wave2};
-            for (int k = 0; k < MPE_PARTS; ++k) {
-                const int at = part_at[k], n_part = part_at[k + 1] - at;
-                if (n_part == 0) continue;
-                hipStream_t st = lanes2[k & 1];
-                if (k == 1) MPE_HIP(hipStreamWaitEvent(st, e_km0, 0));         // part 1's k-means behind part 0's, beside part 0's EM
-                hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_part), dim3(WV), 0, st, *params, d_off.p, p0, d_order.p + at, d_x.p, d_y.p, d_u.p, d_txo.p,
-                                   d_tyo.p, d_wd.p, d_work.p, d_seeds.p + at);
-                const int64_t n_km = (int64_t)n_part * (MPE_KMAX - 1);         // fits with K = 2 .. 10
-                hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)((n_km + WV - 1) / WV)), dim3(WV), 0, st, d_off.p, p0, n_part, d_order.p + at, d_wd.p,
-                                   d_wi.p, d_work.p, d_iwork.p, d_seeds.p + at, d_km_ifault.p + (size_t)at * (MPE_KMAX + 1));
-                if (k == 0) MPE_HIP(hipEventRecord(e_km0, st));
-                hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_part), dim3(WV), 0, st, *params, d_off.p, p0, d_order.p + at, d_x.p,
-                                   d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
-                                   d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p + at, d_km_ifault.p + (size_t)at * (MPE_KMAX + 1));
-            }
-            MPE_HIP(hipEventRecord(e_w2, s_wave2));
-            MPE_HIP(hipStreamWaitEvent(s_wave, e_w2, 0));
+            hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p,
+                               d_tyo.p, d_wd.p, d_work.p, d_seeds.p);
+            const int64_t n_km = (int64_t)n_large * (MPE_KMAX - 1);            // fits with K = 2 .. 10
+            hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)((n_km + WV - 1) / WV)), dim3(WV), 0, s_wave, d_off.p, p0, n_large, d_order.p, d_wd.p, d_wi.p,
+                               d_work.p, d_iwork.p, d_seeds.p, d_km_ifault.p);
+            hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
+                               d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
+                               d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p, d_km_ifault.p);
         }
         if (n_small) {
             const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
