@@ -90,6 +90,7 @@ __device__ __forceinline__ double dist2p(double ax, double ay, const double* c, 
     return s;
 }
 
+template <int S>
 __device__ void transfer(double ax, double ay, double* c, int k, int* nc, double* an1, double* an2, int* ic1, int* ic2, int i,
                          int l1, int l2)
 {
@@ -105,29 +106,35 @@ __device__ void transfer(double ax, double ay, double* c, int k, int* nc, double
     an1[l1 - 1] = 1.0 < alw ? alw / (alw - 1.0) : R8_HUGE;
     an1[l2 - 1] = alt / al2;
     an2[l2 - 1] = alt / (alt + 1.0);
-    ic1[i - 1] = l2;
-    ic2[i - 1] = l1;
+    ic1[(size_t)(i - 1) * S] = l2;
+    ic2[(size_t)(i - 1) * S] = l1;
 }
 
 // AS 136 with n = 2 (tools/asa136.C:13-336 kmns, :339-566 optra, :569-758 qtran); returns ifault
+// S: the stride of the per-point arrays (x / y coordinates a and ay, d, ic1, ic2).  1: a fit's own arrays.  64 (k_mpe_kmeans): the
+// arrays of the 64 fits of a wave interleaved point by point — element i of lane l at [i * 64 + l] — so that a wave's load of "its
+// fits' point i" is one stretch of memory instead of 64 cache lines (the L1 serves a line per cycle: the one-lane-per-fit kernel
+// was bound by exactly that, profiles/r04/clustermatepairs/).
 // The per-cluster state (counts, the two factors, the live sets) is the caller's: k entries each — private arrays of a lane end
 // up in scratch memory, the wave kernel hands in LDS.
 struct KmState { int nc[MPE_KMAX], ncp[MPE_KMAX], itran[MPE_KMAX], live[MPE_KMAX]; double an1[MPE_KMAX], an2[MPE_KMAX]; };
 
-__device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2, double* d, int iter, KmState& st)
+template <int S>
+__device__ int kmns(const double* a, const double* ay_, int m, double* c, int k, int* ic1, int* ic2, double* d, int iter, KmState& st)
 {
+    auto P = [](int i) { return (size_t)i * S; };          // element i of a per-point array
     if (k <= 1 || m <= k) return 3;
     int *nc = st.nc, *ncp = st.ncp, *itran = st.itran, *live = st.live;
     double *an1 = st.an1, *an2 = st.an2;
     for (int i = 1; i <= m; ++i) {
-        ic1[i - 1] = 1;
-        ic2[i - 1] = 2;
+        ic1[P(i - 1)] = 1;
+        ic2[P(i - 1)] = 2;
         double dt[2];
-        const double ax = a[i - 1], ay = a[i - 1 + m];
+        const double ax = a[P(i - 1)], ay = ay_[P(i - 1)];
         for (int il = 1; il <= 2; ++il) dt[il - 1] = dist2p(ax, ay, c, k, il);
         if (dt[1] < dt[0]) {
-            ic1[i - 1] = 2;
-            ic2[i - 1] = 1;
+            ic1[P(i - 1)] = 2;
+            ic2[P(i - 1)] = 1;
             const double t = dt[0];
             dt[0] = dt[1];
             dt[1] = t;
@@ -137,12 +144,12 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             if (db < dt[1]) {
                 if (dt[0] <= db) {
                     dt[1] = db;
-                    ic2[i - 1] = l;
+                    ic2[P(i - 1)] = l;
                 } else {
                     dt[1] = dt[0];
-                    ic2[i - 1] = ic1[i - 1];
+                    ic2[P(i - 1)] = ic1[P(i - 1)];
                     dt[0] = db;
-                    ic1[i - 1] = l;
+                    ic1[P(i - 1)] = l;
                 }
             }
         }
@@ -152,9 +159,9 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
         for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = 0.0;
     }
     for (int i = 1; i <= m; ++i) {
-        const int l = ic1[i - 1];
+        const int l = ic1[P(i - 1)];
         nc[l - 1] += 1;
-        for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = c[l - 1 + (j - 1) * k] + a[i - 1 + (j - 1) * m];
+        for (int j = 1; j <= 2; ++j) c[l - 1 + (j - 1) * k] = c[l - 1 + (j - 1) * k] + (j == 1 ? a[P(i - 1)] : ay_[P(i - 1)]);
     }
     for (int l = 1; l <= k; ++l)
         if (nc[l - 1] == 0) return 1;
@@ -175,7 +182,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             bool early = false;
             // the point's coordinates, clusters and distance are fetched one point ahead: nothing that happens to point i
             // touches those of point i + 1 (a transfer writes ic1 / ic2 of its own point only), and the point array is constant
-            double axn = a[0], ayn = a[m], dn = d[0];
+            double axn = a[0], ayn = ay_[0], dn = d[0];
             int l1n = ic1[0], l2n = ic2[0];
             double cx[MPE_KMAX], cy[MPE_KMAX], a2[MPE_KMAX];     // centres and the factor an2, in registers for the scan below
             auto reload = [&]() {
@@ -190,10 +197,10 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                 double di = dn;
                 const int l1 = l1n;
                 int l2 = l2n;
-                if (i < m) { axn = a[i]; ayn = a[i + m]; dn = d[i]; l1n = ic1[i]; l2n = ic2[i]; }
+                if (i < m) { axn = a[P(i)]; ayn = ay_[P(i)]; dn = d[P(i)]; l1n = ic1[P(i)]; l2n = ic2[P(i)]; }
                 const int ll = l2;
                 if (1 < nc[l1 - 1]) {
-                    if (ncp[l1 - 1] != 0) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[i - 1] = di; }
+                    if (ncp[l1 - 1] != 0) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[P(i - 1)] = di; }
                     double r2 = dist2p(ax, ay, c, k, l2) * an2[l2 - 1];
                     // the scan over the centres from registers (centres and factors change with a transfer only; the live
                     // set of l2 when l2 does): the same quotients, distances and comparisons in the same order
@@ -216,14 +223,14 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                         }
                     }
                     if (di <= r2) {
-                        ic2[i - 1] = l2;
+                        ic2[P(i - 1)] = l2;
                     } else {
                         indx = 0;
                         live[l1 - 1] = m + i;
                         live[l2 - 1] = m + i;
                         ncp[l1 - 1] = i;
                         ncp[l2 - 1] = i;
-                        transfer(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                        transfer<S>(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
                         reload();
                     }
                 }
@@ -241,7 +248,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
             int icoun = 0, istep = 0;
             bool done = false;
             while (!done) {
-                double axn = a[0], ayn = a[m], dn = d[0];          // one point ahead, as in optra
+                double axn = a[0], ayn = ay_[0], dn = d[0];          // one point ahead, as in optra
                 int l1n = ic1[0], l2n = ic2[0];
                 for (int i = 1; i <= m; ++i) {
                     icoun += 1;
@@ -249,9 +256,9 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                     const double ax = axn, ay = ayn;
                     double di = dn;
                     const int l1 = l1n, l2 = l2n;
-                    if (i < m) { axn = a[i]; ayn = a[i + m]; dn = d[i]; l1n = ic1[i]; l2n = ic2[i]; }
+                    if (i < m) { axn = a[P(i)]; ayn = ay_[P(i)]; dn = d[P(i)]; l1n = ic1[P(i)]; l2n = ic2[P(i)]; }
                     if (1 < nc[l1 - 1]) {
-                        if (istep <= ncp[l1 - 1]) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[i - 1] = di; }
+                        if (istep <= ncp[l1 - 1]) { di = dist2p(ax, ay, c, k, l1) * an1[l1 - 1]; d[P(i - 1)] = di; }
                         if (istep < ncp[l1 - 1] || istep < ncp[l2 - 1]) {
                             const double r2 = di / an2[l2 - 1];
                             const double dd = dist2p(ax, ay, c, k, l2);
@@ -262,7 +269,7 @@ __device__ int kmns(const double* a, int m, double* c, int k, int* ic1, int* ic2
                                 itran[l2 - 1] = 1;
                                 ncp[l1 - 1] = istep + m;
                                 ncp[l2 - 1] = istep + m;
-                                transfer(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
+                                transfer<S>(ax, ay, c, k, nc, an1, an2, ic1, ic2, i, l1, l2);
                             }
                         }
                     }
@@ -435,7 +442,7 @@ __device__ bool expectation_maximization(Work& w, int K, double& ll)
             c[K + j] = px[j];
         }
         KmState kst;
-        const int ifault = kmns(w.ka, N, c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER, kst);
+        const int ifault = kmns<1>(w.ka, w.ka + N, N, c, K, w.ic1, w.ic2, w.kd, KMEANS_ITER, kst);
         if (ifault == 1 || ifault == 3) { w.fail = 1; return false; }     // DebugCheck(ifault != 1 / != 3)
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < K; ++j) {
@@ -1019,8 +1026,6 @@ __global__ __launch_bounds__(WV) void k_mpe_seed(mpe_params prm, const int64_t* 
         a.YO[TY[i]] = Y[i];
         a.XYU[i] = X[i] + Y[i] + U[i];
         a.XfromY[TY[i]] = TX[i];
-        a.ka[i] = Y[i];                        // both inserts are at begin(): a = [Y..., X...]
-        a.ka[N + i] = X[i];
     }
     __syncthreads();
     // the runs of equal coordinates in x order and in y order, once per problem: group of every rank, coordinate of every group
@@ -1074,34 +1079,53 @@ __global__ __launch_bounds__(WV) void k_mpe_seed(mpe_params prm, const int64_t* 
     if (lane == 0) { out.n_seeds = s_n_seeds; out.Gx = Gx; out.Gy = Gy; out.pad_ = 0; }
 }
 
-// ---- k_mpe_kmeans: the AS 136 start-up of every fit that needs one (:388-450), one lane per fit.  Fit g = (K - 2) * n_large +
-// rank: the lanes of a wave hold fits of one K on problems of neighbouring sizes (the problems are sorted by size), which is as
-// alike as 64 independent sequential k-means runs get.  Per-lane state in LDS (private arrays would live in scratch memory),
-// the lane stride an odd number of 8-byte words.
+// ---- k_mpe_kmeans: the AS 136 start-up of every fit that needs one (:388-450), one lane per fit.  Block (Kidx, gi): the fits with
+// K = 2 + Kidx centres of the 64 problems of size rank gi * 64 .. gi * 64 + 63 (the problems are sorted by size): as alike as 64
+// independent sequential k-means runs get.  Per-lane cluster state in LDS (private arrays would live in scratch memory), the lane
+// stride an odd number of 8-byte words.  The per-point arrays of the block's 64 fits — coordinates, d, ic1, ic2 — are INTERLEAVED
+// in a scratch slab of the block (kmns<64>): every lane walks its own points, and point i of all lanes is one 512-byte stretch.
 struct KmLane { KmState st; double c[2 * MPE_KMAX]; double pad_; };
 static_assert(sizeof(KmLane) % 16 == 8, "lane stride: an odd number of 8-byte words");
-__global__ __launch_bounds__(WV) void k_mpe_kmeans(const int64_t* __restrict__ prob_off, int p0, int n_large, const int32_t* __restrict__ order,
-                                                  const int64_t* __restrict__ wd_off, const int64_t* __restrict__ wi_off, double* __restrict__ wdoubles,
-                                                  int* __restrict__ wints, const ProblemSeeds* __restrict__ seeds, int* __restrict__ ifault_out)
+constexpr int KM_ROW_DOUBLES = WV * 4;      // per point and block: 64 x (ax, ay, d: 8 B each; ic1, ic2: 4 B each) = 256 doubles
+__global__ __launch_bounds__(WV) void k_mpe_kmeans(const int64_t* __restrict__ prob_off, int p0, int n_large, int n_groups, const int32_t* __restrict__ order,
+                                                  const double* __restrict__ x, const double* __restrict__ y, const int64_t* __restrict__ wi_off,
+                                                  int* __restrict__ wints, const ProblemSeeds* __restrict__ seeds, const int64_t* __restrict__ km_off,
+                                                  int64_t km_total, double* __restrict__ km_scratch, int* __restrict__ ifault_out)
 {
     __shared__ KmLane s_lane[WV];
-    const int64_t g = (int64_t)blockIdx.x * WV + threadIdx.x;
-    const int K = 2 + (int)(g / n_large), r = (int)(g % n_large);
-    if (K > MPE_KMAX) return;
-    const int q = order[r];
+    const int lane = threadIdx.x;
+    const int Kidx = blockIdx.x / n_groups, gi = blockIdx.x % n_groups;
+    const int K = 2 + Kidx, r = gi * WV + lane;
+    const bool in_range = r < n_large;
+    const int q = order[in_range ? r : n_large - 1];
     const int p = p0 + q;
-    const int N = (int)(prob_off[p + 1] - prob_off[p]);
-    const ProblemSeeds& sd = seeds[r];
-    int result = KM_NOT_RUN;
+    const int64_t b = prob_off[p];
+    const int N = in_range ? (int)(prob_off[p + 1] - b) : 0;
+    int nmax = N;
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    const ProblemSeeds& sd = seeds[in_range ? r : n_large - 1];
     const int kmax = N < MPE_KMAX ? N : MPE_KMAX;
-    if (sd.n_seeds >= K && K <= kmax && K != N) {
-        KmLane& L = s_lane[threadIdx.x];
-        const SharedArrays a = shared_arrays(wdoubles + wd_off[q * MPE_KMAX + kmax - 1] + wave_fit_doubles(N, kmax), N);
-        FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+    const bool run = in_range && sd.n_seeds >= K && K <= kmax && K != N;
+    int result = KM_NOT_RUN;
+    if (run) {
+        double* slab = km_scratch + ((size_t)Kidx * (size_t)km_total + (size_t)km_off[gi]) * KM_ROW_DOUBLES;
+        double* ax = slab + lane;                                   // kmns' a = [Y..., X...] (both inserts at begin(), :402-410)
+        double* ay = slab + (size_t)nmax * WV + lane;
+        double* d = slab + 2 * (size_t)nmax * WV + lane;
+        int* ic1 = reinterpret_cast<int*>(slab + 3 * (size_t)nmax * WV) + lane;
+        int* ic2 = ic1 + (size_t)nmax * WV;
+        const double *X = x + b, *Y = y + b;
+        for (int i = 0; i < N; ++i) {
+            ax[(size_t)i * WV] = Y[i];
+            ay[(size_t)i * WV] = X[i];
+        }
+        KmLane& L = s_lane[lane];
         for (int j = 0; j < K; ++j) { L.c[j] = sd.py[j]; L.c[K + j] = sd.px[j]; }
-        result = kmns(a.ka, N, L.c, K, f.ic1, f.ic2, f.kd, KMEANS_ITER, L.st);
+        result = kmns<WV>(ax, ay, N, L.c, K, ic1, ic2, d, KMEANS_ITER, L.st);
+        int* out = wints + wi_off[q * MPE_KMAX + K - 1];            // the fit's ic1, where the wave kernel reads the assignments
+        for (int i = 0; i < N; ++i) out[i] = ic1[(size_t)i * WV];
     }
-    ifault_out[(int64_t)r * (MPE_KMAX + 1) + K] = result;
+    if (in_range) ifault_out[(int64_t)r * (MPE_KMAX + 1) + K] = result;
 }
 
 __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE_WPE))) void k_mpe_problem_wave(
@@ -1465,6 +1489,8 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         DBuf<int64_t> d_wd, d_wi;
         DBuf<ProblemSeeds> d_seeds;
         DBuf<int> d_km_ifault;
+        DBuf<int64_t> d_km_off;
+        DBuf<double> d_km_scratch;
         DBuf<int32_t> d_order, d_state;
         DBuf<double> d_work, d_bic;
         DBuf<int> d_iwork;
@@ -1487,9 +1513,19 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
             MPE_HIP(d_km_ifault.alloc((size_t)n_large * (MPE_KMAX + 1)));
             hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p,
                                d_tyo.p, d_wd.p, d_work.p, d_seeds.p);
-            const int64_t n_km = (int64_t)n_large * (MPE_KMAX - 1);            // fits with K = 2 .. 10
-            hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)((n_km + WV - 1) / WV)), dim3(WV), 0, s_wave, d_off.p, p0, n_large, d_order.p, d_wd.p, d_wi.p,
-                               d_work.p, d_iwork.p, d_seeds.p, d_km_ifault.p);
+            // scratch slabs of the k-means blocks: group gi (64 problems of neighbouring size ranks) needs its largest problem's
+            // number of points, for each of the nine K
+            const int n_groups = (n_large + WV - 1) / WV;
+            std::vector<int64_t> km_off((size_t)n_groups + 1, 0);
+            for (int gi = 0; gi < n_groups; ++gi) {
+                const int first = order[(size_t)gi * WV];              // sorted by size: the group's largest
+                km_off[(size_t)gi + 1] = km_off[(size_t)gi] + (prob_off[p0 + first + 1] - prob_off[p0 + first]);
+            }
+            MPE_HIP(d_km_off.alloc(km_off.size()));
+            MPE_HIP(hipMemcpy(d_km_off.p, km_off.data(), km_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            MPE_HIP(d_km_scratch.alloc((size_t)(MPE_KMAX - 1) * (size_t)km_off.back() * KM_ROW_DOUBLES));
+            hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)(n_groups * (MPE_KMAX - 1))), dim3(WV), 0, s_wave, d_off.p, p0, n_large, n_groups, d_order.p, d_x.p,
+                               d_y.p, d_wi.p, d_iwork.p, d_seeds.p, d_km_off.p, (int64_t)km_off.back(), d_km_scratch.p, d_km_ifault.p);
             hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
                                d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
                                d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p, d_km_ifault.p);
