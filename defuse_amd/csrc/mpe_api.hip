@@ -209,13 +209,18 @@ __device__ int kmns(const double* a, const double* ay_, int m, double* c, int k,
 #pragma unroll
                     for (int l = 1; l <= MPE_KMAX; ++l) {
                         if (l <= k && (i < live1 || i < live2) && l != l1 && l != ll) {
-                            const double rr = r2 / a2[l - 1];
                             double dc = 0.0;
                             const double d1 = ax - cx[l - 1];
                             dc = dc + d1 * d1;
                             const double d2 = ay - cy[l - 1];
                             dc = dc + d2 * d2;
-                            if (dc < rr) {
+                            // the reference compares dc with the quotient rr = r2 / an2[l]: an FP64 division per centre and point,
+                            // most of this loop's time.  dc < fl(r2 / a2) is decided by the product wherever it is not within
+                            // rounding of r2 (fl(dc * a2) = dc a2 (1 + e2), fl(r2 / a2) = (r2 / a2)(1 + e1), |e| <= 2^-53, a2 > 0: the
+                            // two sides differ by a factor inside 1 +- 2^-51); only then is the quotient itself taken
+                            const double t = dc * a2[l - 1], margin = r2 * 1e-15;
+                            const bool closer = t < r2 - margin ? true : t > r2 + margin ? false : dc < r2 / a2[l - 1];
+                            if (closer) {
                                 r2 = dc * a2[l - 1];
                                 l2 = l;
                                 live2 = live[l - 1];
