@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(WV) void k_mpe_kmeans(const int64_t* __restrict__ p
 {
     __shared__ KmLane s_lane[WV];
     const int lane = threadIdx.x;
-    const int Kidx = blockIdx.x / n_groups, gi = blockIdx.x % n_groups;
+    const int Kidx = MPE_KMAX - 2 - (int)blockIdx.x / n_groups, gi = blockIdx.x % n_groups;      // the longest runs (most centres) first
     const int K = 2 + Kidx, r = gi * WV + lane;
     const bool in_range = r < n_large;
     const int q = order[in_range ? r : n_large - 1];
@@ -1444,8 +1444,15 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
     MPE_HIP(e0.create());
     MPE_HIP(e1.create());
     MPE_HIP(e2.create());
-    hipraii::Stream s_wave;
+    constexpr size_t MAX_SHARES = 4;
+    hipraii::Stream s_wave, s_share[MAX_SHARES - 1];
+    hipraii::Event e_seed, e_share[MAX_SHARES - 1];
     MPE_HIP(s_wave.create(hipStreamNonBlocking));
+    MPE_HIP(e_seed.create());
+    for (size_t k = 0; k + 1 < MAX_SHARES; ++k) {
+        MPE_HIP(s_share[k].create(hipStreamNonBlocking));
+        MPE_HIP(e_share[k].create());
+    }
     // problems with at least this many mate pairs get a wave per fit (DEFUSE_MPE_WAVE_MIN; 0 = all, large = none).  The wave
     // version is the faster one at every size (profiles/microbench/mpe_sweep.sh); the lane version stays as the literal
     // transcription it is checked against
@@ -1516,8 +1523,6 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
         if (n_large) {               // order[0 .. n_large): the problems with a wave of their own, largest first
             MPE_HIP(d_seeds.alloc((size_t)n_large));
             MPE_HIP(d_km_ifault.alloc((size_t)n_large * (MPE_KMAX + 1)));
-            hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p,
-                               d_tyo.p, d_wd.p, d_work.p, d_seeds.p);
             // scratch slabs of the k-means blocks: group gi (64 problems of neighbouring size ranks) needs its largest problem's
             // number of points, for each of the nine K
             const int n_groups = (n_large + WV - 1) / WV;
@@ -1529,11 +1534,46 @@ extern "C" int mpe_cluster_batch(int device, const mpe_params* params, const int
             MPE_HIP(d_km_off.alloc(km_off.size()));
             MPE_HIP(hipMemcpy(d_km_off.p, km_off.data(), km_off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
             MPE_HIP(d_km_scratch.alloc((size_t)(MPE_KMAX - 1) * (size_t)km_off.back() * KM_ROW_DOUBLES));
-            hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)(n_groups * (MPE_KMAX - 1))), dim3(WV), 0, s_wave, d_off.p, p0, n_large, n_groups, d_order.p, d_x.p,
-                               d_y.p, d_wi.p, d_iwork.p, d_seeds.p, d_km_off.p, (int64_t)km_off.back(), d_km_scratch.p, d_km_ifault.p);
-            hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p,
-                               d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
-                               d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p, d_km_ifault.p);
+            hipLaunchKernelGGL(k_mpe_seed, dim3((unsigned)n_large), dim3(WV), 0, s_wave, *params, d_off.p, p0, d_order.p, d_x.p, d_y.p, d_u.p, d_txo.p,
+                               d_tyo.p, d_wd.p, d_work.p, d_seeds.p);
+            // The k-means kernel ends in a long tail: its longest waves (64 start-ups of the largest problems in lockstep)
+            // run for tens of milliseconds with most of the card idle.  So the problems go in shares on streams of their own
+            // (k-means, then EM, each): the groups of the largest problems in the first, all smaller ones in the last, whose
+            // short k-means is over at once and whose EM waves fill the card under the first share's tail.
+            std::vector<int> cuts{0};                                  // group boundaries of the shares
+            if (n_groups >= 8) {
+                std::string spec = "0.3";
+                if (const char* e = getenv("DEFUSE_MPE_SHARES")) spec = e;          // cut points as fractions of the groups, comma separated
+                for (size_t at = 0; at < spec.size() && cuts.size() < MAX_SHARES;) {
+                    const size_t comma = std::min(spec.find(',', at), spec.size());
+                    const double f = atof(spec.substr(at, comma - at).c_str());
+                    const int g = (int)(n_groups * std::min(1.0, std::max(0.0, f)));
+                    if (g > cuts.back() && g < n_groups) cuts.push_back(g);
+                    at = comma + 1;
+                }
+            }
+            cuts.push_back(n_groups);
+            auto share = [&](hipStream_t st, int g0, int g1) {         // groups [g0, g1) of the sorted problems
+                if (g0 >= g1) return;
+                const int r0 = g0 * WV, n = std::min(n_large, g1 * WV) - r0;
+                hipLaunchKernelGGL(k_mpe_kmeans, dim3((unsigned)((g1 - g0) * (MPE_KMAX - 1))), dim3(WV), 0, st, d_off.p, p0, n, g1 - g0, d_order.p + r0, d_x.p,
+                                   d_y.p, d_wi.p, d_iwork.p, d_seeds.p + r0, d_km_off.p + g0, (int64_t)km_off.back(), d_km_scratch.p,
+                                   d_km_ifault.p + (size_t)r0 * (MPE_KMAX + 1));
+                hipLaunchKernelGGL(k_mpe_problem_wave, dim3((unsigned)n), dim3(WV), 0, st, *params, d_off.p, p0, d_order.p + r0, d_x.p,
+                                   d_y.p, d_u.p, d_txo.p, d_tyo.p, d_wd.p, d_wi.p, d_work.p, d_iwork.p, d_nc.p, d_member.p, d_status.p,
+                                   d_iters.p, d_by_k.p, d_ll_by_k.p, d_seeds.p + r0, d_km_ifault.p + (size_t)r0 * (MPE_KMAX + 1));
+            };
+            const int n_shares = (int)cuts.size() - 1;                 // the last share on s_wave itself, the others on streams of their own
+            if (n_shares > 1) MPE_HIP(hipEventRecord(e_seed, s_wave));
+            for (int k = 0; k + 1 < n_shares; ++k) {
+                MPE_HIP(hipStreamWaitEvent(s_share[k], e_seed, 0));
+                share(s_share[k], cuts[(size_t)k], cuts[(size_t)k + 1]);
+            }
+            share(s_wave, cuts[(size_t)n_shares - 1], n_groups);
+            for (int k = 0; k + 1 < n_shares; ++k) {
+                MPE_HIP(hipEventRecord(e_share[k], s_share[k]));
+                MPE_HIP(hipStreamWaitEvent(s_wave, e_share[k], 0));
+            }
         }
         if (n_small) {
             const int64_t n_fit = (int64_t)n_small * MPE_KMAX;
