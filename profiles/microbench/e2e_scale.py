@@ -14,6 +14,7 @@ dosplitalign (its mate is a record of improper.sam, the crossing read comes from
 every chunk holds a couple of reads of every fusion, which is what a chunk of a real run looks like to dosplitalign (few
 candidates per fusion and chunk) — the opposite corner from bench.py's 100 reads per fusion."""
 import argparse
+import shutil
 import json
 import os
 import re
@@ -259,6 +260,71 @@ def pipeline(out, n_chunks, stages, parallel=1, threads=16):
     return P("splitreads.break")
 
 
+def fused_legs(out, n_chunks):
+    """The back half of the chain (get_align_regions -> dosplitalign -> sort -> evalsplitalign) in dosplitalign's fused mode
+    (DEFUSE_FUSED=1, SURVEY 8(f)-2), after pipeline() has run: (1) per chunk with --sorted (regions file as in the chain), so that GNU sort only merges;
+    (2) one process over all reads, from the clusters to the three final files.  Both must give pipeline()'s final files."""
+    P = lambda n: os.path.join(out, n)
+    T = lambda n: os.path.join(BIN, n)
+    cm = ["-u", str(UFRAG), "-s", str(SFRAG)]
+    base = ["-f", P("ref.fa"), "-e", P("exons.txt")] + cm + ["-n", str(RL), "-x", str(RL)]
+    env = dict(os.environ, DEFUSE_FUSED="1", DEFUSE_TIMING="1")
+    final = [P("splitreads.seq"), P("splitreads.break"), P("splitreads.predalign")]
+    want = [open(f, "rb").read() for f in final]
+    legs = {}
+    # (1) per chunk, sorted in the process
+    rows = []
+    t0 = time.time()
+    per = []
+    for c in range(n_chunks):
+        t1 = time.time()
+        r = subprocess.run([T("dosplitalign")] + base + ["-r", P("clusters.sc.regions"), "--sorted", "-i", P("improper.%d.sam" % c),
+                                                         "-1", P("reads.%d.1.fastq" % c), "-2", P("reads.%d.2.fastq" % c), "-a", P("fsplit.%d" % c)],
+                           env=env, capture_output=True, text=True)
+        if r.returncode:
+            raise SystemExit("fused dosplitalign, chunk %d: %s" % (c, r.stderr[-2000:]))
+        per.append(round(time.time() - t1, 3))
+    rows.append({"stage": "dosplitalign --sorted x %d chunks (alignments in sort order)" % n_chunks, "wall_s": round(time.time() - t0, 3),
+                 "per_chunk_wall_s": per})
+    t0 = time.time()
+    subprocess.check_call("LC_ALL=C sort -m -n -k 1 %s > %s" % (" ".join(P("fsplit.%d" % c) for c in range(n_chunks)), P("f.alignments")), shell=True)
+    rows.append({"stage": "sort -m", "wall_s": round(time.time() - t0, 3)})
+    t0 = time.time()
+    subprocess.check_call([T("evalsplitalign")] + base + ["-r", P("clusters.sc.regions"), "-a", P("f.alignments"), "-q", P("f.seq"), "-b", P("f.break"), "-p", P("f.predalign")])
+    rows.append({"stage": "evalsplitalign", "wall_s": round(time.time() - t0, 3)})
+    got = [open(P(n), "rb").read() for n in ("f.seq", "f.break", "f.predalign")]
+    legs["per_chunk_sorted"] = {"stages": rows, "wall_s": round(sum(r["wall_s"] for r in rows), 3),
+                                "replaces": "dosplitalign x chunks + sort + evalsplitalign of the chain above",
+                                "same_alignments_file": open(P("f.alignments"), "rb").read() == open(P("splitreads.alignments"), "rb").read(),
+                                "same_final_files": got == want}
+    # (2) one process: the chunks' inputs concatenated (the pipeline cuts them from such files), everything else in the tool
+    t0 = time.time()
+    for kind in ("improper.%d.sam", "reads.%d.1.fastq", "reads.%d.2.fastq"):
+        with open(P("all." + kind.replace("%d.", "")), "wb") as fh:
+            for c in range(n_chunks):
+                with open(P(kind % c), "rb") as src:
+                    if kind.endswith(".sam") and c > 0:
+                        for line in src:                     # one header is enough
+                            if not line.startswith(b"@"):
+                                fh.write(line)
+                                break
+                    shutil.copyfileobj(src, fh, 16 << 20)
+    prep = time.time() - t0
+    t0 = time.time()
+    r = subprocess.run([T("dosplitalign")] + base + ["-c", P("clusters.sc"), "-r", P("g.regions"), "--sorted", "-i", P("all.improper.sam"), "-1", P("all.reads.1.fastq"),
+                                                     "-2", P("all.reads.2.fastq"), "-a", P("g.alignments"), "-q", P("g.seq"), "-b", P("g.break"), "-p", P("g.predalign")],
+                       env=env, capture_output=True, text=True)
+    if r.returncode:
+        raise SystemExit("fused dosplitalign, one process: %s" % r.stderr[-2000:])
+    wall = time.time() - t0
+    got = [open(P(n), "rb").read() for n in ("g.seq", "g.break", "g.predalign")]
+    legs["one_process"] = {"wall_s": round(wall, 3), "inputs_concatenated_s_not_counted": round(prep, 3),
+                           "replaces": "get_align_regions + dosplitalign x chunks + sort + evalsplitalign of the chain above",
+                           "same_alignments_file": open(P("g.alignments"), "rb").read() == open(P("splitreads.alignments"), "rb").read(),
+                           "same_final_files": got == want, "timing": [l for l in r.stderr.splitlines() if l.startswith("[dosplitalign]")]}
+    return legs
+
+
 def recovered(break_file, planted, names):
     """How many of the planted junctions with enough support come back exactly (both ends) among the predicted breakpoints."""
     found = set()
@@ -319,6 +385,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16, help="DEFUSE_THREADS of clustermatepairs and setcover (dosplitalign: its own default)")
     ap.add_argument("--check", action="store_true", help="small sizes: compare the final files with the oracle chain and time it (the CPU baseline)")
     ap.add_argument("--generate-only", action="store_true")
+    ap.add_argument("--no-fused", dest="fused", action="store_false", help="skip the two fused-mode legs (DEFUSE_FUSED=1, SURVEY 8(f)-2)")
     args = ap.parse_args()
     info, planted, names = generate(args.out, args.fragments, chrom_len=args.chrom_len, chunk=args.chunk, lo=args.support[0], hi=args.support[1])
     info["fragments_per_fusion"] = args.support
@@ -355,6 +422,8 @@ def main():
         same = all(open(P("psplit.%d" % c), "rb").read() == open(P("split.%d" % c), "rb").read() for c in range(info["chunks"]))
         res["dosplitalign_chunks_in_parallel"] = {"at_a_time": args.parallel, "wall_s": round(time.time() - t1, 3), "all_ok": all(r == 0 for r in rcs),
                                                   "same_files_as_one_at_a_time": same}
+    if args.fused:
+        res["fused"] = fused_legs(args.out, info["chunks"])
     if args.check:
         (seq, brk_txt, pred), regions, t = oracle_chain(args.out, info["chunks"])
         P = lambda nme: os.path.join(args.out, nme)
