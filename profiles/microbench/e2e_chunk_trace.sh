@@ -5,7 +5,7 @@ python3 $R/profiles/microbench/e2e_scale.py --fragments ${1:-2000000} --support 
 C="$R/bin/dosplitalign -f $D/ref.fa -e $D/exons.txt -u 450 -s 45 -n 150 -x 150 -r $D/clusters.sc.regions -i $D/improper.0.sam -1 $D/reads.0.1.fastq -2 $D/reads.0.2.fastq -a $D/trace.split"
 DEFUSE_TIMING=1 DEFUSE_DSA_INPROCESS=1 DEFUSE_DSA_STREAM_TRACE=1 $C 2> $O/chunk_trace.txt || { tail -20 $O/chunk_trace.txt; exit 1; }
 grep -E "dsa_stream|batches:|main\(\)" $O/chunk_trace.txt
-cd /tmp && export TMPDIR=/tmp && DEFUSE_DSA_INPROCESS=1 DEFUSE_DSA_FULL_EXIT=1 rocprofv3 --kernel-trace --stats -d $O/chunk_kt -o kt --output-format csv -- $C > $O/chunk_kt.log 2>&1 || { tail -20 $O/chunk_kt.log; exit 1; }
+cd /tmp && export TMPDIR=/tmp && DEFUSE_DSA_INPROCESS=1 DEFUSE_FULL_EXIT=1 rocprofv3 --kernel-trace --stats -d $O/chunk_kt -o kt --output-format csv -- $C > $O/chunk_kt.log 2>&1 || { tail -20 $O/chunk_kt.log; exit 1; }
 python3 - <<'PY'
 import csv, glob, os
 O = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r04_e2e"

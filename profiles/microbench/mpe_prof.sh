@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 D=/tmp/cmp_scale
 python3 $R/profiles/microbench/cmp_scale.py --fragments ${1:-5000000} --out $D --keep > $R/gpurun_out/mpe_prof_base.json || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/mpe_prof -o mpe --output-format csv -- $R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.prof > $R/gpurun_out/mpe_prof.log 2>&1 || exit 1
+DEFUSE_FULL_EXIT=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/mpe_prof -o mpe --output-format csv -- $R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.prof > $R/gpurun_out/mpe_prof.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob, os
 R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())

@@ -11,7 +11,7 @@ mkdir -p $O
 python3 $R/profiles/microbench/cmp_scale.py --fragments ${1:-5000000} --out $D --generate-only > $O/gen.json || exit 1
 cd /tmp
 T="$R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.pmc"
-export DEFUSE_CMP_CHUNKS=1 DEFUSE_TIMING=1
+export DEFUSE_CMP_CHUNKS=1 DEFUSE_TIMING=1 DEFUSE_FULL_EXIT=1
 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- $T > $O/kt.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq -o p --output-format csv -- $T > $O/sq.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_INSTS_SMEM -d $O/sq2 -o p --output-format csv -- $T > $O/sq2.log 2>&1 || exit 1
@@ -49,16 +49,26 @@ bin_pairs, mate_pairs, em_iters = (int(v) for v in m.groups())
 mb = re.search(r"EM kernels? ([0-9.]+) ms", log) or re.search(r"kernel[s]? ([0-9.]+) ms", log)
 batch_ms = float(mb.group(1)) if mb else None
 sq, sq2, fe, wr, tcc = counters("sq"), counters("sq2"), counters("fetch"), counters("write"), counters("tcc")
-cycles = ms * 1e-3 * 2.4e9                       # nominal clock
+others = {k: {"sq": counters("sq", k), "fetch": counters("fetch", k), "write": counters("write", k)} for k in ("k_mpe_kmeans", "k_mpe_seed")}
+# the batch as a whole: elapsed time of the tool's HIP events around the three kernels (the shares' launches overlap), all
+# three kernels' instructions and bytes
+elapsed_ms = batch_ms if batch_ms else ms
+cycles = elapsed_ms * 1e-3 * 2.4e9                       # nominal clock
 simds = 256 * 4
-issue = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (cycles * simds)          # SQ counts quad-cycles
-lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+valu_all = sq["SQ_ACTIVE_INST_VALU"] + sum(o["sq"].get("SQ_ACTIVE_INST_VALU", 0.0) for o in others.values())
+thread_all = sq["SQ_THREAD_CYCLES_VALU"] + sum(o["sq"].get("SQ_THREAD_CYCLES_VALU", 0.0) for o in others.values())
+issue = 4.0 * valu_all / (cycles * simds)          # SQ counts quad-cycles
+lanes = thread_all / valu_all
+for o in others.values():
+    fe["FETCH_SIZE"] = fe.get("FETCH_SIZE", 0.0) + o["fetch"].get("FETCH_SIZE", 0.0)
+    wr["WRITE_SIZE"] = wr.get("WRITE_SIZE", 0.0) + o["write"].get("WRITE_SIZE", 0.0)
+ms_work, ms = ms, elapsed_ms
 fetch_b, write_b = fe.get("FETCH_SIZE", 0.0) * 1024, wr.get("WRITE_SIZE", 0.0) * 1024
 out = {
     "kernel": K, "source_hash": bench.library_hash(), "workload": json.load(open(O + "/gen.json")),
     "kernel_ms": ms, "launches": calls,
-    "kernel_ms_note": "sum over the launches of the shares, which overlap: device work of this kernel, not elapsed time",
-    "batch_elapsed_ms": batch_ms,
+    "kernel_ms_note": "elapsed time of the batch (HIP events of mpe_cluster_batch around k_mpe_seed, k_mpe_kmeans, k_mpe_problem_wave; the shares' launches overlap); every fraction below is over this time and over all three kernels",
+    "sum_of_k_mpe_problem_wave_launch_durations_ms": ms_work,
     "other_kernels": {k: dict(zip(("ms", "launches"), kernel_time(k)), **{"sq": counters("sq", k), "fetch_KB": counters("fetch", k).get("FETCH_SIZE"), "write_KB": counters("write", k).get("WRITE_SIZE")})
                       for k in ("k_mpe_kmeans", "k_mpe_seed")},
     "bin_pairs": bin_pairs, "mate_pairs": mate_pairs, "em_iterations": em_iters,

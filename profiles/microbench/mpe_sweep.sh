@@ -11,6 +11,6 @@ for w in 0 8 12 16 24 40; do
   cmp -s $D/clusters.txt $D/cl.$w && echo "  identical" || echo "  DIFFERENT"
   rm -f $D/cl.$w
 done
-rocprofv3 --kernel-trace --stats -d gpurun_out/mpe_prof -o mpe -- bin/clustermatepairs $A -c $D/cl.prof > /dev/null 2>&1 || true
+DEFUSE_FULL_EXIT=1 rocprofv3 --kernel-trace --stats -d gpurun_out/mpe_prof -o mpe -- bin/clustermatepairs $A -c $D/cl.prof > /dev/null 2>&1 || true
 find gpurun_out/mpe_prof -name "*kernel_stats.csv" -exec cat {} \; | cut -d, -f1-8 | head -12
 rm -rf $D

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 D=/tmp/cmp_scale
 python3 $R/profiles/microbench/cmp_scale.py --fragments ${1:-1000000} --out $D --keep > /dev/null || exit 1
 cd /tmp
-rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVES} -d $R/gpurun_out/pmc_mpe -o p --output-format csv -- $R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.pmc > $R/gpurun_out/pmc_mpe.log 2>&1 || exit 1
+DEFUSE_FULL_EXIT=1 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAVES} -d $R/gpurun_out/pmc_mpe -o p --output-format csv -- $R/bin/clustermatepairs -a $D/spanning.txt -u 300 -s 30 -p 0.95 -m 5 -c $D/cl.pmc > $R/gpurun_out/pmc_mpe.log 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob, os, collections, json
 R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())

@@ -1098,6 +1098,6 @@ int main(int argc, char* argv[])
     std::cout.flush();
     std::cerr.flush();
     fflush(nullptr);
-    if (inprocess && std::getenv("DEFUSE_DSA_FULL_EXIT")) return 0;        // under a profiler that writes its files at exit (rocprofv3)
+    if (inprocess && std::getenv("DEFUSE_FULL_EXIT")) return 0;            // under a profiler that writes its files at exit (rocprofv3)
     _exit(0);
 }
