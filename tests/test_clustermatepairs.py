@@ -499,3 +499,31 @@ def test_em_breakpoint_search_on_runs_and_ties(built):
             os.environ.pop("DEFUSE_MPE_NO_JUMP", None)
         else:
             os.environ["DEFUSE_MPE_NO_JUMP"] = old
+
+
+@pytest.mark.gpu
+def test_em_shares_on_streams_give_the_same_memberships(built):
+    """mpe_cluster_batch runs the sorted bin pairs in shares on streams of their own (k-means start-ups, then EM, each; the small
+    problems' EM under the tail of the large problems' k-means).  Whatever the cut points (DEFUSE_MPE_SHARES; 0 = one share):
+    the C oracle's memberships bit for bit, and the same EM iteration count as every other cut."""
+    from defuse_amd import mpe
+    from oracle import mpe_c
+    mp = mpe_c.lib().ora_min_probability(30.0, 0.95)
+    old = os.environ.get("DEFUSE_MPE_SHARES")
+    try:
+        for make, seed, n in ((cmp_cases.adversarial_em_batch, 3, 4000), (cmp_cases.tie_heavy_em_batch, 9, 1100)):
+            args = (300.0, 30.0, mp, 5) + make(seed, n)
+            o_ncl, o_member, o_status, dg, _ = mpe_c.cluster_batch(*args)
+            iters = set()
+            for shares in ("0", "0.3", "0.5", "0.05,0.2,0.6", "0.9"):
+                os.environ["DEFUSE_MPE_SHARES"] = shares
+                g_ncl, g_member, g_status, t = mpe.cluster_batch(*args)
+                assert (g_status != 0).tolist() == (o_status != 0).tolist() and (g_ncl == o_ncl).all(), shares
+                assert g_member.tobytes() == o_member.tobytes(), (make.__name__, shares)
+                iters.add(int(t.em_iterations))
+            assert len(iters) == 1
+    finally:
+        if old is None:
+            os.environ.pop("DEFUSE_MPE_SHARES", None)
+        else:
+            os.environ["DEFUSE_MPE_SHARES"] = old
