@@ -534,7 +534,7 @@ __device__ unsigned long long g_mpe_path[10];      // lanes: no hint, hint accep
 constexpr int MPE_TIE_SCAN = 4;                   // ties counted one by one up to here, by bisection beyond
 
 __device__ int max_likelihood_groups(const Work& w, const double* RXO_base, double* GA_base, double* GB_base, int stride, int& hint_g,
-                                     int& hint_h, double& a, double& b, double& nk, const double* LLX, const double* LLY, double& ll MPE_WALK_ARG)
+                                     int& hint_h, double& a, double& b, double& nk MPE_WALK_ARG)
 {
 #ifdef MPE_PHASE_STATS
     const unsigned long long tw0 = __builtin_readcyclecounter();
@@ -549,9 +549,6 @@ __device__ int max_likelihood_groups(const Work& w, const double* RXO_base, doub
     const int* TX = w.TX;
     const int* XfromY = w.XfromY;
     double NK = 0.0, RXYU = 0.0, px = 0.0, py = 0.0;
-    // LLX != nullptr (one lane per fit): the fit's log-likelihood chain (:96-137, LL = LL + log(sum_i) + maxexp_i in the caller's
-    // order) rides in this pass — a fifth serial chain beside the four sums, instead of a pass of its own with ten lanes busy
-    double LL = 0.0;
     int t = 0;
     // Loads in batches so that only the additions are serial, and the batches overlap: a batch's responsibilities are gathered
     // through indices that were fetched while the batch before it was summed (one round trip to memory per batch, not two).
@@ -561,17 +558,13 @@ __device__ int max_likelihood_groups(const Work& w, const double* RXO_base, doub
         for (int v = 0; v < MPE_CHAIN; ++v) { ixn[v] = TX[v]; iyn[v] = XfromY[v]; }
     }
     for (; t + MPE_CHAIN <= N; t += MPE_CHAIN) {
-        double r[MPE_CHAIN], q[MPE_CHAIN], rx[MPE_CHAIN], ry[MPE_CHAIN], l1[MPE_CHAIN], l2[MPE_CHAIN];
+        double r[MPE_CHAIN], q[MPE_CHAIN], rx[MPE_CHAIN], ry[MPE_CHAIN];
         int gxc[MPE_CHAIN], gyc[MPE_CHAIN];
 #pragma unroll
         for (int v = 0; v < MPE_CHAIN; ++v) {
             r[v] = RXO(ixn[v]); q[v] = w.XYU[t + v];
             rx[v] = RXO(t + v); ry[v] = RXO(iyn[v]);
             gxc[v] = w.gx[t + v]; gyc[v] = w.gy[t + v];
-        }
-        if (LLX) {
-#pragma unroll
-            for (int v = 0; v < MPE_CHAIN; ++v) { l1[v] = LLX[t + v]; l2[v] = LLY[t + v]; }
         }
         if (t + 2 * MPE_CHAIN <= N) {
 #pragma unroll
@@ -584,14 +577,9 @@ __device__ int max_likelihood_groups(const Work& w, const double* RXO_base, doub
             GA_base[(size_t)gxc[v] * stride] = px;           // the last element of a group writes last
             GB_base[(size_t)gyc[v] * stride] = py;
         }
-        if (LLX) {
-#pragma unroll
-            for (int v = 0; v < MPE_CHAIN; ++v) LL = LL + l1[v] + l2[v];
-        }
     }
     for (; t < N; ++t) {
         const double r = RXO(TX[t]);
-        if (LLX) LL = LL + LLX[t] + LLY[t];
         NK += r;
         RXYU += r * w.XYU[t];
         px += RXO(t);
@@ -600,7 +588,6 @@ __device__ int max_likelihood_groups(const Work& w, const double* RXO_base, doub
         GB_base[(size_t)w.gy[t] * stride] = py;
     }
     nk = NK;
-    ll = LL;
 #ifdef MPE_PHASE_STATS
     const unsigned long long tw1 = __builtin_readcyclecounter();
 #endif
@@ -968,7 +955,7 @@ __device__ unsigned long long g_mpe_phase[8];
 
 struct ProblemShared {
     double W[MPE_NCOMP], A[MPE_NCOMP], B[MPE_NCOMP];
-    double like[MPE_KMAX + 1], last[MPE_KMAX + 1], ll[MPE_KMAX + 1];     // ll: the likelihood chain the M step's pass carried
+    double like[MPE_KMAX + 1], last[MPE_KMAX + 1];
     int active[MPE_KMAX + 1], valid[MPE_KMAX + 1], state[MPE_KMAX + 1], zero[MPE_KMAX + 1], ifault[MPE_KMAX + 1];
     int n_seeds, any_active;
 };
@@ -1231,34 +1218,20 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
     // ---- EM of all fits
     long long my_iters = 0;
     int hint_g = -1, hint_h = 0;               // where this lane's component ended its last M step (the next one starts its search there)
-    // The reference's iteration is M step, weights, likelihood, convergence test, E step (:455-492).  Here: the first M step; then
-    // per iteration the E step's pass (exponents, mixture sums and — from the same registers — the responsibilities the NEXT
-    // M step reads), the next M step taken AHEAD of the convergence test with the likelihood chain of this iteration riding in
-    // its caller-order pass, the test, and the commit of that M step's result for the fits that go on (a fit that stops has
-    // run one M step for nothing — one in about thirty).
-    auto m_step = [&](bool with_chain, double& a, double& bb, double& nk, int& rc) {
-        FitArrays f = fit_arrays(N, myK, wdoubles + wd_off[q * MPE_KMAX + myK - 1], wints + wi_off[q * MPE_KMAX + myK - 1]);
-        const bool chain = with_chain && myJ == 0;
-        double ll = 0.0;
-        rc = max_likelihood_groups(w, f.RXO + myJ, f.GA + myJ, f.GB + myJ, myK, hint_g, hint_h, a, bb, nk, chain ? f.SX : nullptr, f.SY, ll MPE_WALK_PASS);
-        if (chain) s.ll[myK] = ll;
-    };
-    auto commit = [&](double a, double bb, double nk, int rc) {
-        if (rc < 0) s.state[myK] = 2;                          // the reference would read past the end: DebugCheck
-        if (rc > 0) { s.A[myL] = a; s.B[myL] = bb; }
-        s.W[myL] = nk / N;
-    };
-    if (myK && s.active[myK]) {
-        double a = 0.0, bb = 0.0, nk = 0.0;
-        int rc = 0;
-        m_step(false, a, bb, nk, rc);
-        commit(a, bb, nk, rc);
-    }
-    __syncthreads();
-    if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
-    __syncthreads();
-    MPE_STAMP(3);
     for (;;) {
+        // M step: every component of every running fit
+        if (myK && s.active[myK]) {
+            double a = 0.0, bb = 0.0, nk = 0.0;
+            FitArrays f = fit_arrays(N, myK, wdoubles + wd_off[q * MPE_KMAX + myK - 1], wints + wi_off[q * MPE_KMAX + myK - 1]);
+            const int rc = max_likelihood_groups(w, f.RXO + myJ, f.GA + myJ, f.GB + myJ, myK, hint_g, hint_h, a, bb, nk MPE_WALK_PASS);
+            if (rc < 0) s.state[myK] = 2;                      // the reference would read past the end: DebugCheck
+            if (rc > 0) { s.A[myL] = a; s.B[myL] = bb; }
+            s.W[myL] = nk / N;
+        }
+        __syncthreads();
+        if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
+        __syncthreads();
+        MPE_STAMP(3);
         // E step: exponents, exp, mixture sum, log — and, from the same registers, the responsibilities
         // W_j e_j / sum of UpdateResponsibilities (:139-181).  The reference updates them after the convergence test; nothing
         // reads them between here and the next M step, and a fit that stops in this iteration never reads them again, so
@@ -1304,17 +1277,23 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
         }
         __syncthreads();
         MPE_STAMP(4);
-        // the next M step of every running fit, ahead of the test, and the likelihood chain (:96-137) in component 0's pass
-        double a = 0.0, bb = 0.0, nk = 0.0;
-        int rc = 0;
-        const bool ran = myK && s.active[myK];
-        if (ran) m_step(true, a, bb, nk, rc);
-        __syncthreads();
-        MPE_STAMP(3);
-        // the loop control of ExpectationMaximization (:455-492), one fit per lane
+        // log-likelihood chains (:96-137) and the loop control of ExpectationMaximization (:455-492), one fit per lane
         if (lane >= 1 && lane <= kmax && s.active[lane]) {
             const int K = lane;
-            const double LL = s.zero[K] ? -DBL_MAX_ : s.ll[K];
+            FitArrays f = fit_arrays(N, K, wdoubles + wd_off[q * MPE_KMAX + K - 1], wints + wi_off[q * MPE_KMAX + K - 1]);
+            double LL = 0.0;
+            if (s.zero[K]) LL = -DBL_MAX_;
+            else {
+                int i = 0;
+                for (; i + 8 <= N; i += 8) {
+                    double l1[8], l2[8];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { l1[v] = f.SX[i + v]; l2[v] = f.SY[i + v]; }
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) LL = LL + l1[v] + l2[v];
+                }
+                for (; i < N; ++i) LL = LL + f.SX[i] + f.SY[i];
+            }
             my_iters += 1;
             const double like = LL, last = s.last[K];
             const bool valid = s.valid[K] != 0;
@@ -1327,10 +1306,6 @@ __global__ __launch_bounds__(WV) __attribute__((amdgpu_waves_per_eu(MPE_WPE, MPE
                 if (s.zero[K]) { s.active[K] = 0; s.state[K] = 2; }                                                // DebugCheck(norm != 0.0), :172
             }
         }
-        __syncthreads();
-        if (ran && s.active[myK]) commit(a, bb, nk, rc);       // the fit goes on: this was its M step
-        __syncthreads();
-        if (lane >= 1 && lane <= kmax && s.state[lane] == 2) s.active[lane] = 0;
         __syncthreads();
         if (lane == 0) {
             int any = 0;
