@@ -82,7 +82,7 @@ struct PipeLane {
     unsigned tier_hint = 0xFu;  // fill kernels the lane's last slice needed (bit t: k_fill_fast<t>, bit 3: k_fill_generic): the ones launched
     unsigned tiers_launched = 0;    // ... for the slice in flight
     DevBuf<uint8_t> d_wg_tier;  // which fill kernel owns each workgroup (written by k_fill_fast<0>)
-    DevBuf<uint32_t> d_rowcodes, d_bnd, d_cmax, d_rmax, d_tmask;
+    DevBuf<uint32_t> d_rowcodes, d_rowbytes, d_bnd, d_cmax, d_rmax, d_tmask;
     DevBuf<PairState> d_state;
     DevBuf<KeptRow> d_kept;
     DevBuf<int64_t> d_rec_count, d_rec_offset;
@@ -97,7 +97,7 @@ struct PipeLane {
 #endif
     void release()
     {
-        d_wg_tier.release(); d_rowcodes.release();
+        d_wg_tier.release(); d_rowcodes.release(); d_rowbytes.release();
         d_bnd.release(); d_cmax.release(); d_rmax.release(); d_tmask.release(); d_state.release(); d_kept.release();
         d_rec_count.release(); d_rec_offset.release(); d_tasks.release(); d_masks.release(); d_gtasks.release();
         d_ctr.release(); d_scan_tmp.release(); d_tstop.release();
@@ -232,7 +232,7 @@ int min_score_for(int lq)
 size_t slice_scratch_bytes(int64_t n_waves, int lq1, int nch)
 {
     size_t rows = (size_t)n_waves * lq1 * WAVE * 4;
-    return 3 * rows + 2 * rows * (size_t)nch;
+    return 3 * rows + rows / 4 + 2 * rows * (size_t)nch;      // rowcodes, rmax, tmask; the byte plane of the table sweeps; bnd, cmax
 }
 
 // Slices bound the scratch footprint: contiguous ranges of the caller's pair order that fit the budget (and
@@ -455,7 +455,7 @@ int launch_compute(dsa_ctx* ctx, PipeLane& L, const Slice& s)
     // windows beyond 512 bases, e.g. 2x150 bp reads)
 #define DSA_LAUNCH_FILL(TIER, WIDE)                                                                                                              \
     hipLaunchKernelGGL((k_fill_fast<TIER, WIDE>), dim3((unsigned)g.n_wgs), dim3(WG_LANES), 0, st, pairs, L.d_wg_tier.p, ctx->d_refcodes.p, \
-                       ctx->d_reads.p, L.d_rowcodes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g)
+                       ctx->d_reads.p, L.d_rowcodes.p, L.d_rowbytes.p, ctx->d_min_score.p, ctx->d_fusions.p, L.d_bnd.p, L.d_cmax.p, L.d_rmax.p, L.d_tmask.p, fb, g)
     const bool wide = g.nch > 8 && g.nch <= 16;
     if (wide) DSA_LAUNCH_FILL(0, true); else DSA_LAUNCH_FILL(0, false);
     if (mask & 2u) { if (wide) DSA_LAUNCH_FILL(1, true); else DSA_LAUNCH_FILL(1, false); }
@@ -508,6 +508,7 @@ int phase1(dsa_ctx* ctx, PipeLane& L, int slice_idx)
     const size_t n_rows = (size_t)g.n_waves * g.lq1 * WAVE;
     HIPC(L.d_wg_tier.reserve((size_t)g.n_wgs));
     HIPC(L.d_rowcodes.reserve(n_rows));
+    HIPC(L.d_rowbytes.reserve(n_rows / 4));        // one byte per row for the table sweeps (lq1 is a multiple of 4)
     HIPC(L.d_bnd.reserve(n_rows * g.nch));
     HIPC(L.d_cmax.reserve(n_rows * g.nch));
     HIPC(L.d_rmax.reserve(n_rows));

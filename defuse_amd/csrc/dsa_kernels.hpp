@@ -342,17 +342,24 @@ __device__ __forceinline__ void build_tables(uint32_t* __restrict__ T, int n_gro
 
 // Row codes of one wave's pairs, written by the wave itself in the prologue of the fill kernels (each lane
 // its own pair, four rows per dwordx4).  Returns whether the lane met a read byte outside {A,C,G,T,N}.
+// The table kernels sweep from a plane of ONE BYTE per row (row_bytes: four rows per dword and lane, [wave][lq1/4][64]): all a
+// table sweep needs of a row is its table row (25-row tables) or its two classes (split tables), and the sweeps read the row
+// codes once per tile — a quarter of the bytes of the full codes, which the replays still take from `rowcodes`.
+template <int BYTE_KIND>     // 0: no byte plane (generic kernel), 1: table row, 2: classes k1 | k2 << 4
 __device__ __forceinline__ bool pack_rows_wave(const uint8_t* __restrict__ read_bytes, const dsa_pair* __restrict__ pairs,
-                                               uint32_t* __restrict__ rowcodes, const Geom& g, int w, int lane, int lq_wave)
+                                               uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ row_bytes, const Geom& g, int w,
+                                               int lane, int lq_wave)
 {
     const int64_t p = (int64_t)w * WAVE + lane;
     const bool valid = p < g.n_pairs;
     dsa_pair pr{};
     if (valid) pr = pairs[p];
     uint4* out = reinterpret_cast<uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+    uint32_t* out1 = BYTE_KIND ? row_bytes + (int64_t)w * (g.lq1 >> 2) * WAVE + lane : nullptr;
     bool exotic = false;
     for (int gq = 0; gq <= (lq_wave >> 2); ++gq) {
         uint32_t code[4];
+        uint32_t bytes = 0;
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
             const int j = 4 * gq + sidx;
@@ -363,9 +370,11 @@ __device__ __forceinline__ bool pack_rows_wave(const uint8_t* __restrict__ read_
                 exotic |= !is_fast_base(b0);                       // b1 is some other row's b0
                 const uint32_t k1 = base_class(b0), k2 = base_class(b1);
                 code[sidx] = (b0 << 8) | (b1 << 24) | table_row(k1, k2) | ((k1 | (k2 << 4)) << 16);   // byte 2: classes, split tables
+                if (BYTE_KIND) bytes |= (BYTE_KIND == 1 ? table_row(k1, k2) : (k1 | (k2 << 4))) << (8 * sidx);
             }
         }
         out[(int64_t)gq * WAVE] = make_uint4(code[0], code[1], code[2], code[3]);
+        if (BYTE_KIND) out1[(int64_t)gq * WAVE] = bytes;
     }
     return exotic;
 }
@@ -1289,7 +1298,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
         WaveInfo wi;                             // rows and tiles of the wave, from its own pairs
         wi.lq_max = wave_max(in_batch ? (int)pairs[p].read_len : 0);
         wi.nch_max = wave_max(in_batch ? max(cdiv_dev(fu.ref0_len, W), cdiv_dev(fu.ref1_len, W)) : 0);
-        (void)pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);   // the fast kernel packs only what it keeps
+        (void)pack_rows_wave<0>(read_bytes, pairs, rowcodes, nullptr, g, w, lane, wi.lq_max);   // the fast kernel packs only what it keeps
         const uint32_t* rc = refcodes + (int64_t)f * g.lrp;
         const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
         int lq_lane = 0, slack = 0;
@@ -1338,7 +1347,7 @@ __global__ __launch_bounds__(WG_LANES) void k_fill_generic(const dsa_pair* __res
 // (instruction cache, register allocation) than the quarter-width seventh pass saves.  Exact pruning as described at the
 // kernel.  Returns the row groups stored for the tile; last_bnd = last row whose outgoing boundary is alive (this lane).
 template <int NW, bool SPLIT, bool LAST>
-__device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, const uint4* __restrict__ rows4, const uint4* __restrict__ bi4,
+__device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, const uint32_t* __restrict__ rows1, const uint4* __restrict__ bi4,
                                                uint4* __restrict__ cm4, uint4* __restrict__ bo4, bool first_tile, int lq_max, int lq_lane,
                                                int slack, int l_in, int stop_prev, int& last_bnd, const Geom& g)
 {
@@ -1350,17 +1359,18 @@ __device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, 
     const uint4 bias4 = make_uint4(BIAS2, BIAS2, BIAS2, BIAS2);
     uint32_t bprev = BIAS2;
     const int ngq = (lq_max >> 2) + 1;
-    uint4 rc_n = rows4[0];
+    uint32_t rc_n = rows1[0];                               // four rows' bytes: table row / classes
     uint4 b_n = first_tile ? bias4 : bi4[0];                // every tile stores at least its first row group
     last_bnd = 0;
     int gq = 0;
     int n_gap_groups = 0;
     for (; gq < ngq; ++gq) {
-        const uint4 rc = rc_n, b = b_n;
+        const uint32_t rc = rc_n;
+        const uint4 b = b_n;
         const int gn = gq + 1 < ngq ? gq + 1 : gq;          // prefetch the next four rows' operands
-        rc_n = rows4[(int64_t)gn * WAVE];
+        rc_n = rows1[(int64_t)gn * WAVE];
         b_n = gn < stop_prev ? bi4[(int64_t)gn * WAVE] : bias4;   // past the left tile's stop: dead, V = 0
-        const uint32_t rcv[4] = {rc.x, rc.y, rc.z, rc.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        const uint32_t bv[4] = {b.x, b.y, b.z, b.w};
         uint32_t cmv[4] = {BIAS2, BIAS2, BIAS2, BIAS2}, bov[4] = {BIAS2, BIAS2, BIAS2, BIAS2};
         uint32_t alive_bits = 0;
 #pragma unroll
@@ -1369,7 +1379,7 @@ __device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, 
             const uint32_t bcur = bv[sidx];
             if (j >= 1 && j <= lq_max) {                    // wave-uniform
                 if constexpr (SPLIT) {
-                    const uint32_t k1 = (rcv[sidx] >> 16) & 0xFu, k2 = (rcv[sidx] >> 20) & 0xFu;
+                    const uint32_t k1 = (rc >> (8 * sidx)) & 0xFu, k2 = (rc >> (8 * sidx + 4)) & 0xFu;
                     uint4 v = split_terms(tb, k1, k2, 0);
                     uint32_t a = bprev + v.x;
                     uint32_t up = bcur - TWO2;
@@ -1394,7 +1404,7 @@ __device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, 
                         v = vn;
                     }
                 } else {
-                    const uint4* trow = reinterpret_cast<const uint4*>(tb + (rcv[sidx] & 0xFFu) * TROW);
+                    const uint4* trow = reinterpret_cast<const uint4*>(tb + ((rc >> (8 * sidx)) & 0xFFu) * TROW);
                     uint4 vq[FILL_PF + 1];                  // table reads in flight
 #pragma unroll
                     for (int k = 0; k <= FILL_PF; ++k) vq[k] = trow[k];
@@ -1482,7 +1492,7 @@ __device__ __forceinline__ int sweep_tile_fast(const uint32_t* __restrict__ tb, 
                 for (int i = 0; i < NW; ++i) X[i] = BIAS2 + drift2(i);
                 bprev = in_prev;
                 b_n = bb;
-                rc_n = rows4[(int64_t)g2 * WAVE];
+                rc_n = rows1[(int64_t)g2 * WAVE];
                 gq = g2 - 1;
             }
         }
@@ -1516,7 +1526,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
                                                            uint8_t* __restrict__ wg_tier,
                                                            const uint32_t* __restrict__ refcodes,
                                                            const uint8_t* __restrict__ read_bytes,
-                                                           uint32_t* __restrict__ rowcodes,
+                                                           uint32_t* __restrict__ rowcodes, uint32_t* __restrict__ row_bytes,
                                                            const int32_t* __restrict__ min_score_tab,
                                                            const dsa_fusion* __restrict__ fusions,
                                                            uint32_t* __restrict__ bnd, uint32_t* __restrict__ cmax,
@@ -1574,7 +1584,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     int l_in = wave_max(lq_lane > 0 ? min(slack >> 2, lq_lane) : 0);
     // Row codes are packed here, by the wave that uses them.  A read byte outside {A,C,G,T,N} hands the
     // whole workgroup to the generic kernel, which is launched after this one and re-packs its rows.
-    const bool exotic = live && pack_rows_wave(read_bytes, pairs, rowcodes, g, w, lane, wi.lq_max);
+    const bool exotic = live && pack_rows_wave<SPLIT ? 2 : 1>(read_bytes, pairs, rowcodes, row_bytes, g, w, lane, wi.lq_max);
     if (threadIdx.x == 0) { s_nch = 0; s_exotic = 0; }
     __syncthreads();
     if (lane == 0 && live) atomicMax(&s_nch, wi.nch_max);
@@ -1590,7 +1600,7 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
     const int nch_wg = s_nch;
 
     const uint32_t* tb = T + my_group * (SPLIT ? TGROUP_SPLIT : TGROUP);
-    const uint4* rows4 = reinterpret_cast<const uint4*>(rowcodes + (int64_t)w * g.lq1 * WAVE) + lane;
+    const uint32_t* rows1 = row_bytes + (int64_t)w * (g.lq1 >> 2) * WAVE + lane;
     int stop_prev = 0;                   // stored row groups of the tile to the left
     TileStops stops = {};
 
@@ -1617,11 +1627,11 @@ __global__ __launch_bounds__(WG_LANES, TIER == 2 ? 2 : DSA_FAST_WGS) void k_fill
         const uint4* bi4 = reinterpret_cast<const uint4*>(bnd + ((int64_t)w * g.nch + (c - 1)) * g.lq1 * WAVE) + lane;
         int last_bnd = 0, gq;
         if (c + 1 < wi.nch_max)
-            gq = sweep_tile_fast<W, SPLIT, false>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
+            gq = sweep_tile_fast<W, SPLIT, false>(tb, rows1, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
         else if (!DIAG_NARROW || tail_cols > 16)
-            gq = sweep_tile_fast<W, SPLIT, true>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
+            gq = sweep_tile_fast<W, SPLIT, true>(tb, rows1, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
         else       // (-DDSA_NARROW builds only, see dsa_diag.hpp)
-            gq = sweep_tile_fast<16, SPLIT, true>(tb, rows4, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
+            gq = sweep_tile_fast<16, SPLIT, true>(tb, rows1, bi4, cm4, bo4, c == 0, wi.lq_max, lq_lane, slack, l_in, stop_prev, last_bnd, g);
         // the dead remainder of the tile is not stored: its readers substitute V = 0 past the stop
         if (lane == 0) fb.tstop[(int64_t)w * g.nch + c] = gq;
         stop_prev = gq;
