@@ -129,3 +129,47 @@ def test_script_name_selects_the_step(glue, tmp_path):
     os.symlink(glue, link)
     got = run(str(link), ["merge_in0.txt", "merge_in1.txt", "merge_in2.txt"], cwd=G)
     assert got == read("merge_out.txt")
+
+
+@pytest.mark.parametrize("step,args,name", [("get_align_regions", [], "regions_in.txt"), ("remove_duplicates", ["3"], "dups_in.txt")])
+def test_cluster_steps_in_pieces_give_the_one_pass_output(glue, tmp_path, step, args, name):
+    """get_align_regions and remove_duplicates cut their input into pieces at changes of the cluster id and work on them side by
+    side (a file redirected into stdin is mapped); whatever the number of pieces, a pipe or a file: the one-pass output."""
+    inp = read(name)
+    if step == "remove_duplicates":          # the same clusters again under new ids, and one id that comes back later
+        lines = inp.splitlines(True)
+        shifted = ["\t".join([str(int(l.split("\t")[0]) + 1000)] + l.split("\t")[1:]) for l in lines]
+        inp = inp + "".join(shifted) + "".join(lines[:40])
+    else:                                    # a cluster whose lines come in two runs far apart: extent of all, name of the last
+        inp = inp + "900\t0\t1\t0\tchrA\t+\t500\t560\n900\t1\t1\t1\tchrB\t-\t100\t160\n" + inp.replace("\n", "\n", 1) + \
+            "900\t0\t2\t0\tchrC\t-\t40\t90\n900\t1\t2\t1\tchrB\t-\t300\t460\n"
+        # (the fixture's own ids repeat: every cluster of it now has two runs)
+    one = subprocess.run([glue, step] + args, input=inp, capture_output=True, text=True, env=dict(os.environ, DEFUSE_THREADS="1"))
+    assert one.returncode == 0, one.stderr
+    path = tmp_path / "in.txt"
+    path.write_text(inp)
+    for threads in ("2", "5", "16"):
+        env = dict(os.environ, DEFUSE_THREADS=threads, DEFUSE_GLUE_MIN_BYTES="1")
+        with open(path) as fh:
+            r = subprocess.run([glue, step] + args, stdin=fh, capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and r.stdout == one.stdout, (threads, r.stderr)
+        r = subprocess.run([glue, step] + args, input=inp, capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and r.stdout == one.stdout, threads
+    if step == "get_align_regions":
+        assert "900\t0\tchrC\t-\t40\t560\n900\t1\tchrB\t-\t100\t460\n" in one.stdout
+
+
+def test_cluster_steps_report_the_first_error_in_file_order(glue, tmp_path):
+    good = read("dups_in.txt")
+    lines = good.splitlines(True)
+    bad = "".join(lines[:30]) + "x7\t0\t1\n" + "".join(lines[30:]) + "12\tnot-a-number\t1\t0\tchr1\t+\t5\t9\n"
+    path = tmp_path / "bad.txt"
+    path.write_text(bad)
+    msgs = set()
+    for threads in ("1", "4", "9"):
+        with open(path) as fh:
+            r = subprocess.run([glue, "remove_duplicates", "3"], stdin=fh, capture_output=True, text=True,
+                               env=dict(os.environ, DEFUSE_THREADS=threads, DEFUSE_GLUE_MIN_BYTES="1"))
+        assert r.returncode != 0
+        msgs.add(r.stderr.strip())
+    assert len(msgs) == 1 and "fewer than 8 fields" in msgs.pop()

@@ -13,6 +13,8 @@
 // clustermatepairs, setcover and dosplitalign and were the slowest links once those ran on the GPU.
 // Where a script's output order follows Perl's hash order (randomised per process), the canonical order of
 // SURVEY 8(c) is used: ascending numeric ids, chromosome names in string order.
+#include <chrono>
+
 #include "defuse_host.hpp"
 
 using namespace defuse;
@@ -40,12 +42,88 @@ void split_fields(const char* line, size_t len, int want, Fields& f)
     }
 }
 
+// what a step would have died of: thrown, so that a team of threads working on pieces of the input can report the FIRST one in
+// file order, as the one-pass scripts do; main() turns it into die()
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct GlueError { std::string msg; };
+[[noreturn]] void fail(const std::string& msg) { throw GlueError{msg}; }
+
 long long num(const Fields& f, int k, const char* what)
 {
     int v;
-    if (k >= f.n || !field_int(f.p[k], f.len(k), v)) die(std::string("Error: bad ") + what + " '" + (k < f.n ? f.str(k) : std::string()) + "'");
+    if (k >= f.n || !field_int(f.p[k], f.len(k), v)) fail(std::string("Error: bad ") + what + " '" + (k < f.n ? f.str(k) : std::string()) + "'");
     return v;
 }
+
+// The cluster files these steps read are hundreds of megabytes of text in runs of lines with one cluster id.  The input
+// (stdin: mapped if it is a file) is cut into pieces that begin where the first column changes, every thread of a team works
+// through its piece as the one-pass script would, and the pieces' outputs and errors are taken in file order.
+struct ClusterPieces {
+    MappedText text;
+    std::vector<size_t> cut;
+    unsigned pieces = 1;
+    void load()
+    {
+        if (!text.try_load("-", true, false)) fail("Error: Unable to read the clusters");
+        size_t min_bytes = (size_t)1 << 22;                                 // below this one thread is as fast (DEFUSE_GLUE_MIN_BYTES: tests)
+        if (const char* e = std::getenv("DEFUSE_GLUE_MIN_BYTES")) min_bytes = (size_t)std::atoll(e);
+        const unsigned want = text.size() < std::max<size_t>(min_bytes, 1) ? 1u : host_threads();
+        cut = text.cut_lines(0, text.size(), want);
+        pieces = want;
+        auto first_id = [&](size_t pos, bool& ok) -> long long {          // numeric value of the first column of the line at pos
+            const size_t e = text.line_end(pos);
+            size_t n = e - pos;
+            if (n && text[e - 1] == '\n') --n;
+            Fields f;
+            split_fields(text.data() + pos, n, 2, f);
+            int v = 0;
+            ok = field_int(f.p[0], f.len(0), v);
+            return v;
+        };
+        for (unsigned t = 1; t < pieces; ++t) {                             // forward to the next change of the cluster id
+            size_t pos = std::max(cut[t], cut[t - 1]);
+            if (pos > 0 && pos < text.size()) {
+                size_t prev = pos - 1;                                      // start of the line before pos
+                while (prev > 0 && text[prev - 1] != '\n') --prev;
+                bool ok_a, ok_b;
+                long long a = first_id(prev, ok_a);
+                while (pos < text.size()) {
+                    const long long b = first_id(pos, ok_b);
+                    if (!ok_a || !ok_b || a != b) break;                   // (a bad line ends the search: its piece reports it)
+                    pos = text.line_end(pos);
+                }
+            }
+            cut[t] = pos;
+        }
+        for (unsigned t = 1; t <= pieces; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    }
+    // fn(piece, line, len) for every line of every piece, pieces side by side; the first error in file order is thrown
+    template <class Fn, class Done>
+    void run(Fn&& fn, Done&& done)
+    {
+        std::vector<std::string> err(pieces);
+        std::vector<char> failed(pieces, 0);
+        run_threads(pieces, [&](unsigned t) {
+            try {
+                size_t pos = cut[t];
+                const size_t hi = cut[t + 1];
+                while (pos < hi) {
+                    const size_t e = text.line_end(pos);
+                    size_t n = e - pos;
+                    if (n && text[e - 1] == '\n') --n;
+                    fn(t, text.data() + pos, n);
+                    pos = e;
+                }
+                done(t);
+            } catch (const GlueError& g) {
+                err[t] = g.msg;
+                failed[t] = 1;
+            }
+        });
+        for (unsigned t = 0; t < pieces; ++t)
+            if (failed[t]) fail(err[t]);
+    }
+};
 
 class Out {
 public:
@@ -97,25 +175,41 @@ int merge_clusters(int argc, char** argv)
 int get_align_regions()
 {
     struct EndInfo { std::string ref, strand; long long start = 0, end = 0; bool have = false; };
-    std::map<long long, std::map<long long, EndInfo>> clusters;
-    LineReader reader(stdin);
-    const char* line;
-    size_t len;
-    Fields f;
-    while (reader.next(line, len)) {
+    typedef std::map<long long, std::map<long long, EndInfo>> Clusters;
+    ClusterPieces in;
+    in.load();
+    std::vector<Clusters> part(in.pieces);
+    in.run([&](unsigned t, const char* line, size_t len) {
+        Fields f;
         split_fields(line, len, 9, f);
-        if (f.n < 8) die("Error: cluster line with fewer than 8 fields");
+        if (f.n < 8) fail("Error: cluster line with fewer than 8 fields");
         const long long id = num(f, 0, "cluster id"), ce = num(f, 1, "cluster end"), start = num(f, 6, "start"), end = num(f, 7, "end");
-        EndInfo& e = clusters[id][ce];
-        e.ref = f.str(4);
-        e.strand = f.str(5);
+        EndInfo& e = part[t][id][ce];
+        e.ref.assign(f.p[4], f.len(4));
+        e.strand.assign(f.p[5], f.len(5));
         if (!e.have) { e.start = start; e.end = end; e.have = true; }
         e.start = std::min(e.start, start);
         e.end = std::max(e.end, end);
-    }
+    }, [](unsigned) {});
+    // a cluster id that comes back in a later piece: name and strand of the LAST line, the extent of all of them
+    Clusters& clusters = part[0];
+    for (unsigned t = 1; t < in.pieces; ++t)
+        for (auto& c : part[t]) {
+            auto at = clusters.find(c.first);
+            if (at == clusters.end()) { clusters.emplace_hint(clusters.end(), c.first, std::move(c.second)); continue; }
+            for (auto& e : c.second) {
+                EndInfo& into = at->second[e.first];
+                const EndInfo& from = e.second;
+                if (!into.have) { into = from; continue; }
+                into.ref = from.ref;
+                into.strand = from.strand;
+                into.start = std::min(into.start, from.start);
+                into.end = std::max(into.end, from.end);
+            }
+        }
     Out out(stdout);
     for (const auto& c : clusters) {
-        if (c.second.size() != 2) die("Error: Did not find 2 ends for cluster " + std::to_string(c.first));
+        if (c.second.size() != 2) fail("Error: Did not find 2 ends for cluster " + std::to_string(c.first));
         for (const auto& e : c.second) {
             append_int(out.buf(), c.first); out.buf() += '\t';
             append_int(out.buf(), e.first); out.buf() += '\t';
@@ -137,44 +231,96 @@ int remove_duplicates(int argc, char** argv)
 {
     int min_size;
     if (argc < 1 || !field_int(argv[0], strlen(argv[0]), min_size)) { std::cerr << "Usage: remove_duplicates min_cluster_size < in_clusters > out_clusters\n"; return 1; }
-    struct Frag { long long pos[2] = {0, 0}; bool have[2] = {false, false}; std::string line[2]; };
-    std::map<long long, Frag> frags;
-    Out out(stdout);
-    auto emit = [&]() {
-        std::set<std::pair<long long, long long>> seen;
-        std::vector<const Frag*> kept;
-        for (const auto& kv : frags) {
-            const Frag& fr = kv.second;
-            if (!fr.have[0] || !fr.have[1]) die("Error: fragment " + std::to_string(kv.first) + " lacks a cluster end");   // the script dies on the undefined value
-            if (!seen.insert(std::make_pair(fr.pos[0], fr.pos[1])).second) continue;
-            kept.push_back(&fr);
-        }
-        if ((long long)kept.size() * 2 >= 2LL * min_size)
-            for (const Frag* fr : kept)
-                for (int e = 0; e < 2; ++e) { out.buf() += fr->line[e]; out.buf() += '\n'; }
-        out.maybe_flush();
-        frags.clear();
+    struct Line { long long frag; int ce; long long pos; const char* text; size_t len; };
+    struct Frag { long long frag, pos[2]; const char* text[2]; size_t len[2]; };
+    struct Piece {
+        std::vector<Line> lines;                 // of the current cluster, in file order
+        std::vector<Frag> frags;
+        std::vector<size_t> by_pos;
+        std::vector<char> keep;
+        std::string out;
+        bool have = false;
+        long long current = 0;
     };
-    LineReader reader(stdin);
-    const char* line;
-    size_t len;
-    Fields f;
-    bool have = false;
-    long long current = 0;
-    while (reader.next(line, len)) {
+    const double t_start = now();
+    const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
+    ClusterPieces in;
+    in.load();
+    std::vector<Piece> part(in.pieces);
+    // a cluster's fragments ascending (the script: Perl hash order), of a fragment's lines per end the last one; of the fragments
+    // with one pair of positions the smallest stays
+    auto emit = [&](Piece& pc) {
+        std::stable_sort(pc.lines.begin(), pc.lines.end(), [](const Line& a, const Line& b) { return a.frag < b.frag; });
+        pc.frags.clear();
+        for (size_t i = 0; i < pc.lines.size();) {
+            Frag fr{pc.lines[i].frag, {0, 0}, {nullptr, nullptr}, {0, 0}};
+            size_t j = i;
+            for (; j < pc.lines.size() && pc.lines[j].frag == fr.frag; ++j) {
+                const Line& l = pc.lines[j];
+                fr.pos[l.ce] = l.pos; fr.text[l.ce] = l.text; fr.len[l.ce] = l.len;
+            }
+            if (!fr.text[0] || !fr.text[1]) fail("Error: fragment " + std::to_string(fr.frag) + " lacks a cluster end");   // the script dies on the undefined value
+            pc.frags.push_back(fr);
+            i = j;
+        }
+        pc.by_pos.resize(pc.frags.size());
+        for (size_t k = 0; k < pc.by_pos.size(); ++k) pc.by_pos[k] = k;
+        std::sort(pc.by_pos.begin(), pc.by_pos.end(), [&](size_t a, size_t b) {
+            const Frag &x = pc.frags[a], &y = pc.frags[b];
+            if (x.pos[0] != y.pos[0]) return x.pos[0] < y.pos[0];
+            if (x.pos[1] != y.pos[1]) return x.pos[1] < y.pos[1];
+            return a < b;                                    // ascending fragment id
+        });
+        pc.keep.assign(pc.frags.size(), 0);
+        size_t kept = 0;
+        for (size_t k = 0; k < pc.by_pos.size(); ++k) {
+            const Frag& x = pc.frags[pc.by_pos[k]];
+            if (k == 0 || x.pos[0] != pc.frags[pc.by_pos[k - 1]].pos[0] || x.pos[1] != pc.frags[pc.by_pos[k - 1]].pos[1]) { pc.keep[pc.by_pos[k]] = 1; ++kept; }
+        }
+        if ((long long)kept * 2 >= 2LL * min_size)
+            for (size_t k = 0; k < pc.frags.size(); ++k)
+                if (pc.keep[k])
+                    for (int e = 0; e < 2; ++e) { pc.out.append(pc.frags[k].text[e], pc.frags[k].len[e]); pc.out += '\n'; }
+        pc.lines.clear();
+    };
+    for (unsigned t = 0; t < in.pieces; ++t) part[t].out.reserve(in.cut[t + 1] - in.cut[t] + 1);      // never more than came in
+    in.run([&](unsigned t, const char* line, size_t len) {
+        Piece& pc = part[t];
+        Fields f;
         split_fields(line, len, 9, f);
-        if (f.n < 8) die("Error: cluster line with fewer than 8 fields");
+        if (f.n < 8) fail("Error: cluster line with fewer than 8 fields");
         const long long id = num(f, 0, "cluster id"), ce = num(f, 1, "cluster end"), frag = num(f, 2, "fragment id");
-        if (have && current != id) emit();
-        current = id;
-        have = true;
-        if (ce != 0 && ce != 1) continue;                       // the script stores it and never looks at it again
-        Frag& fr = frags[frag];
-        fr.pos[ce] = (f.len(5) == 1 && f.p[5][0] == '+') ? num(f, 6, "start") : num(f, 7, "end");
-        fr.have[ce] = true;
-        fr.line[ce].assign(line, len);
+        if (pc.have && pc.current != id) emit(pc);
+        pc.current = id;
+        pc.have = true;
+        if (ce != 0 && ce != 1) return;                         // the script stores it and never looks at it again
+        const long long pos = (f.len(5) == 1 && f.p[5][0] == '+') ? num(f, 6, "start") : num(f, 7, "end");
+        pc.lines.push_back(Line{frag, (int)ce, pos, line, len});    // the text stays mapped
+    }, [&](unsigned t) { if (part[t].have) emit(part[t]); });
+    if (timing) std::cerr << "[remove_duplicates] " << in.pieces << " piece(s) done " << now() - t_start << " s" << std::endl;
+    // a file behind stdout: every thread copies its piece's output to its place; anything else: one after the other
+    struct stat st;
+    const off_t base = lseek(STDOUT_FILENO, 0, SEEK_CUR);
+    if (in.pieces > 1 && fstat(STDOUT_FILENO, &st) == 0 && S_ISREG(st.st_mode) && base >= 0 && !(fcntl(STDOUT_FILENO, F_GETFL) & O_APPEND)) {
+        std::vector<off_t> at(in.pieces + 1, base);
+        for (unsigned t = 0; t < in.pieces; ++t) at[t + 1] = at[t] + (off_t)part[t].out.size();
+        std::vector<char> bad(in.pieces, 0);
+        run_threads(in.pieces, [&](unsigned t) {
+            const std::string& o = part[t].out;
+            for (size_t done = 0; done < o.size();) {
+                const ssize_t w = pwrite(STDOUT_FILENO, o.data() + done, o.size() - done, at[t] + (off_t)done);
+                if (w <= 0) { bad[t] = 1; return; }
+                done += (size_t)w;
+            }
+        });
+        for (char b : bad)
+            if (b) fail("Error: failed writing the clusters");
+        (void)lseek(STDOUT_FILENO, at[in.pieces], SEEK_SET);
+    } else {
+        for (const Piece& pc : part)
+            if (!pc.out.empty() && fwrite(pc.out.data(), 1, pc.out.size(), stdout) != pc.out.size()) fail("Error: failed writing the clusters");
     }
-    if (have) emit();
+    if (timing) std::cerr << "[remove_duplicates] written " << now() - t_start << " s" << std::endl;
     return 0;
 }
 
@@ -329,11 +475,15 @@ int main(int argc, char* argv[])
         prog = argv[1];
         first = 2;
     }
-    if (prog == "merge_clusters") return merge_clusters(argc - first, argv + first);
-    if (prog == "get_align_regions") return get_align_regions();
-    if (prog == "remove_duplicates") return remove_duplicates(argc - first, argv + first);
-    if (prog == "filter_unmatched") return filter_unmatched();
-    if (prog == "divide_sam_chr_pairs") return divide_sam_chr_pairs(argc - first, argv + first);
+    try {
+        if (prog == "merge_clusters") return merge_clusters(argc - first, argv + first);
+        if (prog == "get_align_regions") return get_align_regions();
+        if (prog == "remove_duplicates") return remove_duplicates(argc - first, argv + first);
+        if (prog == "filter_unmatched") return filter_unmatched();
+        if (prog == "divide_sam_chr_pairs") return divide_sam_chr_pairs(argc - first, argv + first);
+    } catch (const GlueError& g) {
+        die(g.msg);
+    }
     std::cerr << "defuse_glue: unknown subcommand " << prog << "\n";
     return 1;
 }

@@ -327,6 +327,14 @@ struct MappedText {
     bool try_load(const std::string& name, bool dash_is_stdin = true, bool populate = true)
     {
         FILE* in = stdin;
+        if (name == "-" && dash_is_stdin) {
+            // a file redirected into stdin (`tool < file`, as the pipeline calls its text steps) is mapped like a named one
+            struct stat st;
+            if (fstat(STDIN_FILENO, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && lseek(STDIN_FILENO, 0, SEEK_CUR) == 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | (populate ? MAP_POPULATE : 0), STDIN_FILENO, 0);
+                if (m != MAP_FAILED) { p = (char*)m; n = (size_t)st.st_size; mapped = true; return true; }
+            }
+        }
         if (name != "-" || !dash_is_stdin) {
             const int fd = open(name.c_str(), O_RDONLY);
             if (fd < 0) return false;
