@@ -392,6 +392,163 @@ struct MappedText {
     }
 };
 
+// ---- cluster files (the text between clustermatepairs, setcover and dosplitalign) on a team of threads -----------------------
+inline void append_int(std::string& buf, long long v);
+struct Fields {
+    const char* p[16];
+    int n = 0;
+    const char* end = nullptr;
+    size_t len(int k) const { return (size_t)((k + 1 < n ? p[k + 1] - 1 : end) - p[k]); }
+    std::string str(int k) const { return std::string(p[k], len(k)); }
+};
+
+// up to `want` leading tab-separated fields of a line (more are left inside the last one's tail)
+inline void split_fields(const char* line, size_t len, int want, Fields& f)
+{
+    f.n = 0;
+    f.end = line + len;
+    f.p[f.n++] = line;
+    for (const char* q = line; f.n < want;) {
+        const char* tab = (const char*)memchr(q, '\t', (size_t)(f.end - q));
+        if (!tab) break;
+        f.p[f.n++] = q = tab + 1;
+    }
+}
+
+// what a step would have died of: thrown, so that a team of threads working on pieces of the input can report the FIRST one in
+// file order, as the one-pass scripts do; main() turns it into die()
+struct GlueError { std::string msg; };
+[[noreturn]] inline void fail(const std::string& msg) { throw GlueError{msg}; }
+
+inline long long num(const Fields& f, int k, const char* what)
+{
+    int v;
+    if (k >= f.n || !field_int(f.p[k], f.len(k), v)) fail(std::string("Error: bad ") + what + " '" + (k < f.n ? f.str(k) : std::string()) + "'");
+    return v;
+}
+
+// The cluster files these steps read are hundreds of megabytes of text in runs of lines with one cluster id.  The input
+// (stdin: mapped if it is a file) is cut into pieces that begin where the first column changes, every thread of a team works
+// through its piece as the one-pass script would, and the pieces' outputs and errors are taken in file order.
+struct ClusterPieces {
+    MappedText text;
+    std::vector<size_t> cut;
+    unsigned pieces = 1;
+    void load(const std::string& name)                                    // "-" = stdin
+    {
+        if (!text.try_load(name, true, false)) fail("Error: Unable to open clusters file " + name);
+        size_t min_bytes = (size_t)1 << 22;                                 // below this one thread is as fast (DEFUSE_GLUE_MIN_BYTES: tests)
+        if (const char* e = std::getenv("DEFUSE_GLUE_MIN_BYTES")) min_bytes = (size_t)std::atoll(e);
+        const unsigned want = text.size() < std::max<size_t>(min_bytes, 1) ? 1u : host_threads();
+        cut = text.cut_lines(0, text.size(), want);
+        pieces = want;
+        auto first_id = [&](size_t pos, bool& ok) -> long long {          // numeric value of the first column of the line at pos
+            const size_t e = text.line_end(pos);
+            size_t n = e - pos;
+            if (n && text[e - 1] == '\n') --n;
+            Fields f;
+            split_fields(text.data() + pos, n, 2, f);
+            int v = 0;
+            ok = field_int(f.p[0], f.len(0), v);
+            return v;
+        };
+        for (unsigned t = 1; t < pieces; ++t) {                             // forward to the next change of the cluster id
+            size_t pos = std::max(cut[t], cut[t - 1]);
+            if (pos > 0 && pos < text.size()) {
+                size_t prev = pos - 1;                                      // start of the line before pos
+                while (prev > 0 && text[prev - 1] != '\n') --prev;
+                bool ok_a, ok_b;
+                long long a = first_id(prev, ok_a);
+                while (pos < text.size()) {
+                    const long long b = first_id(pos, ok_b);
+                    if (!ok_a || !ok_b || a != b) break;                   // (a bad line ends the search: its piece reports it)
+                    pos = text.line_end(pos);
+                }
+            }
+            cut[t] = pos;
+        }
+        for (unsigned t = 1; t <= pieces; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    }
+    // fn(piece, line, len) for every line of every piece, pieces side by side; the first error in file order is thrown
+    template <class Fn, class Done>
+    void run(Fn&& fn, Done&& done)
+    {
+        std::vector<std::string> err(pieces);
+        std::vector<char> failed(pieces, 0);
+        run_threads(pieces, [&](unsigned t) {
+            try {
+                size_t pos = cut[t];
+                const size_t hi = cut[t + 1];
+                while (pos < hi) {
+                    const size_t e = text.line_end(pos);
+                    size_t n = e - pos;
+                    if (n && text[e - 1] == '\n') --n;
+                    fn(t, text.data() + pos, n);
+                    pos = e;
+                }
+                done(t);
+            } catch (const GlueError& g) {
+                err[t] = g.msg;
+                failed[t] = 1;
+            }
+        });
+        for (unsigned t = 0; t < pieces; ++t)
+            if (failed[t]) fail(err[t]);
+    }
+};
+
+
+// scripts/get_align_regions.pl:14-53: per (cluster, end) the reference name and strand of its last line and the extent of all
+// its alignments; clusters ascending, end 0 then 1; a cluster without exactly two ends is an error.  (bin/defuse_glue
+// get_align_regions and the fused mode of dosplitalign.)
+inline std::string align_regions_text(ClusterPieces& in)
+{
+    struct EndInfo { std::string ref, strand; long long start = 0, end = 0; bool have = false; };
+    typedef std::map<long long, std::map<long long, EndInfo>> Clusters;
+    std::vector<Clusters> part(in.pieces);
+    in.run([&](unsigned t, const char* line, size_t len) {
+        Fields f;
+        split_fields(line, len, 9, f);
+        if (f.n < 8) fail("Error: cluster line with fewer than 8 fields");
+        const long long id = num(f, 0, "cluster id"), ce = num(f, 1, "cluster end"), start = num(f, 6, "start"), end = num(f, 7, "end");
+        EndInfo& e = part[t][id][ce];
+        e.ref.assign(f.p[4], f.len(4));
+        e.strand.assign(f.p[5], f.len(5));
+        if (!e.have) { e.start = start; e.end = end; e.have = true; }
+        e.start = std::min(e.start, start);
+        e.end = std::max(e.end, end);
+    }, [](unsigned) {});
+    // a cluster id that comes back in a later piece: name and strand of the LAST line, the extent of all of them
+    Clusters& clusters = part[0];
+    for (unsigned t = 1; t < in.pieces; ++t)
+        for (auto& c : part[t]) {
+            auto at = clusters.find(c.first);
+            if (at == clusters.end()) { clusters.emplace_hint(clusters.end(), c.first, std::move(c.second)); continue; }
+            for (auto& e : c.second) {
+                EndInfo& into = at->second[e.first];
+                const EndInfo& from = e.second;
+                if (!into.have) { into = from; continue; }
+                into.ref = from.ref;
+                into.strand = from.strand;
+                into.start = std::min(into.start, from.start);
+                into.end = std::max(into.end, from.end);
+            }
+        }
+    std::string out;
+    for (const auto& c : clusters) {
+        if (c.second.size() != 2) fail("Error: Did not find 2 ends for cluster " + std::to_string(c.first));
+        for (const auto& e : c.second) {
+            append_int(out, c.first); out += '\t';
+            append_int(out, e.first); out += '\t';
+            out += e.second.ref; out += '\t';
+            out += e.second.strand; out += '\t';
+            append_int(out, e.second.start); out += '\t';
+            append_int(out, e.second.end); out += '\n';
+        }
+    }
+    return out;
+}
+
 // An output file written in order by several threads: the texts of one round get consecutive ranges of the file (a prefix
 // sum of their sizes) and every thread copies its own with pwrite, so the copy into the page cache runs side by side.
 class OrderedFileWriter {

@@ -320,36 +320,13 @@ int main(int argc, char* argv[])
     if (!opt_clusters.empty()) {
         // scripts/get_align_regions.pl:14-53 (as bin/defuse_glue get_align_regions): per cluster end the reference, the strand
         // and the span of its alignments; clusters ascending, end 0 then 1
-        struct EndInfo { std::string ref, strand; int start = 0, end = 0; bool have = false; };
-        std::map<int, std::map<int, EndInfo>> clusters;
-        MappedText ctext;
-        ctext.load(opt_clusters, "Error: Unable to open clusters file ");
-        for (size_t pos = 0; pos < ctext.size();) {
-            const size_t e = ctext.line_end(pos);
-            const size_t len = (e > pos && ctext[e - 1] == '\n') ? e - 1 - pos : e - pos;
-            const std::vector<std::string> f = split_tabs(std::string(ctext.data() + pos, len));
-            pos = e;
-            if (f.size() < 8) die("Error: cluster line with fewer than 8 fields");
-            const int id = lexical_int_or_die(f[0], "as cluster id"), ce = lexical_int_or_die(f[1], "as cluster end");
-            const int start = lexical_int_or_die(f[6], "as start"), end = lexical_int_or_die(f[7], "as end");
-            EndInfo& ei = clusters[id][ce];
-            ei.ref = f[4];
-            ei.strand = f[5];
-            if (!ei.have) { ei.start = start; ei.end = end; ei.have = true; }
-            ei.start = std::min(ei.start, start);
-            ei.end = std::max(ei.end, end);
-        }
         std::string text;
-        for (const auto& c : clusters) {
-            if (c.second.size() != 2) die("Error: Did not find 2 ends for cluster " + std::to_string(c.first));
-            for (const auto& en : c.second) {
-                append_int(text, c.first); text += '\t';
-                append_int(text, en.first); text += '\t';
-                text += en.second.ref; text += '\t';
-                text += en.second.strand; text += '\t';
-                append_int(text, en.second.start); text += '\t';
-                append_int(text, en.second.end); text += '\n';
-            }
+        try {
+            ClusterPieces pieces;                 // (its threads end before the worker is forked)
+            pieces.load(opt_clusters);
+            text = align_regions_text(pieces);
+        } catch (const GlueError& g) {
+            die(g.msg);
         }
         OrderedFileWriter rf;
         if (!rf.open_file(cmd.str("regions"))) die("Error: unable to write " + cmd.str("regions"));
