@@ -176,3 +176,18 @@ def test_the_whole_host_pipeline_under_sanitizers(double, case, kind):
         assert not any(b in r.stderr for b in BAD), r.stderr[-3000:]
         assert r.returncode == 0, r.stderr[-2000:]
         assert open(out).read() == exp
+
+
+@pytest.mark.parametrize("env", [{"DEFUSE_THREADS": "1"}, {"DEFUSE_THREADS": "5", "DEFUSE_DSA_BATCH_PAIRS": "9"}, {"DEFUSE_THREADS": "16", "DEFUSE_DSA_BATCH_PAIRS": "40"}],
+                         ids=lambda e: ",".join("%s=%s" % (k.replace("DEFUSE_", ""), v) for k, v in e.items()))
+def test_sorted_output_is_gnu_sorts(double, case, env):
+    """Fused mode's --sorted (DEFUSE_FUSED=1): the alignments in the order of `LC_ALL=C sort -n -k 1` — indexed by a team over
+    the batches' texts, brought into fusion order by a counting sort (stable: ties keep the order of arrival), every fusion's
+    lines in byte order.  Against GNU sort on the oracle's text, with one text and with dozens."""
+    c, exp, d = case
+    out = str(d / ("sorted_%d.align" % abs(hash(tuple(sorted(env.items()))))))
+    e = dict(os.environ, DEFUSE_DSA_LIB=double, DEFUSE_FUSED="1", **env)
+    r = subprocess.run([TOOL] + pipeline_case.tool_args(c, out) + ["--sorted"], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = subprocess.run(["sort", "-n", "-k", "1"], input=exp, capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout
+    assert open(out).read() == want

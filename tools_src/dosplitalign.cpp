@@ -27,6 +27,7 @@
 // ordinal is relative to the visible set); DEFUSE_THREADS host threads per team (default 8); DEFUSE_DSA_BATCH_PAIRS
 // candidates per batch (default 262144: a chunk of a million candidates is four batches, three in flight).
 #include <chrono>
+#include <climits>
 #include <new>
 #include <numeric>
 
@@ -986,17 +987,65 @@ int main(int argc, char* argv[])
         // are independent — are ordered, written and (fused evaluation) evaluated by contiguous shares of the groups.
         struct Line { int id; uint32_t len; const char* p; };
         std::vector<Line> lines;
-        for (const std::string& tx : collected)
-            for (size_t pos = 0; pos < tx.size();) {
-                const char* nl = (const char*)memchr(tx.data() + pos, '\n', tx.size() - pos);
-                const size_t e = nl ? (size_t)(nl - tx.data()) + 1 : tx.size();
-                int id = 0;
-                const char* tab = (const char*)memchr(tx.data() + pos, '\t', e - pos);
-                field_int(tx.data() + pos, tab ? (size_t)(tab - (tx.data() + pos)) : 0, id);
-                lines.push_back(Line{id, (uint32_t)(e - pos), tx.data() + pos});
-                pos = e;
+        {
+            // the texts are indexed by contiguous shares of them, one per thread, and brought into id order by a counting sort
+            // over the range of the ids (per-thread histograms, a thread's lines behind those of the threads before it: stable)
+            const unsigned nt = collected.size() < 4 ? 1u : nThreads;
+            std::vector<std::vector<Line>> mine(nt);
+            std::vector<int> id_lo(nt, INT_MAX), id_hi(nt, INT_MIN);
+            size_t total_bytes = 0;
+            for (const std::string& tx : collected) total_bytes += tx.size();
+            std::vector<size_t> first_text(nt + 1, collected.size());
+            {
+                size_t acc = 0;
+                unsigned t = 0;
+                first_text[0] = 0;
+                for (size_t k = 0; k < collected.size(); ++k) {
+                    while (t + 1 < nt && acc >= total_bytes / nt * (t + 1)) first_text[++t] = k;
+                    acc += collected[k].size();
+                }
+                while (t + 1 < nt) first_text[++t] = collected.size();
             }
-        std::stable_sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) { return a.id < b.id; });
+            run_threads(nt, [&](unsigned t) {
+                std::vector<Line>& v = mine[t];
+                for (size_t k = first_text[t]; k < first_text[t + 1]; ++k) {
+                    const std::string& tx = collected[k];
+                    for (size_t pos = 0; pos < tx.size();) {
+                        const char* nl = (const char*)memchr(tx.data() + pos, '\n', tx.size() - pos);
+                        const size_t e = nl ? (size_t)(nl - tx.data()) + 1 : tx.size();
+                        int id = 0;
+                        const char* tab = (const char*)memchr(tx.data() + pos, '\t', e - pos);
+                        field_int(tx.data() + pos, tab ? (size_t)(tab - (tx.data() + pos)) : 0, id);
+                        v.push_back(Line{id, (uint32_t)(e - pos), tx.data() + pos});
+                        id_lo[t] = std::min(id_lo[t], id);
+                        id_hi[t] = std::max(id_hi[t], id);
+                        pos = e;
+                    }
+                }
+            });
+            size_t n_lines = 0;
+            int lo_id = INT_MAX, hi_id = INT_MIN;
+            for (unsigned t = 0; t < nt; ++t) { n_lines += mine[t].size(); lo_id = std::min(lo_id, id_lo[t]); hi_id = std::max(hi_id, id_hi[t]); }
+            lines.resize(n_lines);
+            const uint64_t range = n_lines ? (uint64_t)((int64_t)hi_id - (int64_t)lo_id) + 1 : 0;
+            if (n_lines && range <= std::max<uint64_t>(4 * (uint64_t)n_lines, (uint64_t)1 << 20) && range * nt <= ((uint64_t)1 << 28)) {
+                std::vector<std::vector<size_t>> at(nt, std::vector<size_t>((size_t)range, 0));
+                run_threads(nt, [&](unsigned t) {
+                    for (const Line& l : mine[t]) ++at[t][(size_t)(l.id - lo_id)];
+                });
+                size_t run = 0;
+                for (size_t v = 0; v < (size_t)range; ++v)
+                    for (unsigned t = 0; t < nt; ++t) { const size_t c = at[t][v]; at[t][v] = run; run += c; }
+                run_threads(nt, [&](unsigned t) {
+                    for (const Line& l : mine[t]) lines[at[t][(size_t)(l.id - lo_id)]++] = l;
+                });
+            } else {
+                size_t k = 0;
+                for (unsigned t = 0; t < nt; ++t)
+                    for (const Line& l : mine[t]) lines[k++] = l;
+                std::stable_sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) { return a.id < b.id; });
+            }
+        }
         std::vector<size_t> group(1, 0);
         for (size_t k = 1; k < lines.size(); ++k)
             if (lines[k].id != lines[k - 1].id) group.push_back(k);
