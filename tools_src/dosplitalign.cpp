@@ -1007,7 +1007,11 @@ int main(int argc, char* argv[])
                 while (t + 1 < nt) first_text[++t] = collected.size();
             }
             run_threads(nt, [&](unsigned t) {
-                std::vector<Line>& v = mine[t];
+                std::vector<Line> v;                         // (local: neighbouring vectors' headers share cache lines)
+                int lo_seen = INT_MAX, hi_seen = INT_MIN;
+                size_t bytes = 0;
+                for (size_t k = first_text[t]; k < first_text[t + 1]; ++k) bytes += collected[k].size();
+                v.reserve(bytes / 48 + 16);                  // alignment lines are longer than this
                 for (size_t k = first_text[t]; k < first_text[t + 1]; ++k) {
                     const std::string& tx = collected[k];
                     for (size_t pos = 0; pos < tx.size();) {
@@ -1017,11 +1021,14 @@ int main(int argc, char* argv[])
                         const char* tab = (const char*)memchr(tx.data() + pos, '\t', e - pos);
                         field_int(tx.data() + pos, tab ? (size_t)(tab - (tx.data() + pos)) : 0, id);
                         v.push_back(Line{id, (uint32_t)(e - pos), tx.data() + pos});
-                        id_lo[t] = std::min(id_lo[t], id);
-                        id_hi[t] = std::max(id_hi[t], id);
+                        lo_seen = std::min(lo_seen, id);
+                        hi_seen = std::max(hi_seen, id);
                         pos = e;
                     }
                 }
+                id_lo[t] = lo_seen;
+                id_hi[t] = hi_seen;
+                mine[t].swap(v);
             });
             size_t n_lines = 0;
             int lo_id = INT_MAX, hi_id = INT_MIN;
@@ -1031,13 +1038,16 @@ int main(int argc, char* argv[])
             if (n_lines && range <= std::max<uint64_t>(4 * (uint64_t)n_lines, (uint64_t)1 << 20) && range * nt <= ((uint64_t)1 << 28)) {
                 std::vector<std::vector<size_t>> at(nt, std::vector<size_t>((size_t)range, 0));
                 run_threads(nt, [&](unsigned t) {
-                    for (const Line& l : mine[t]) ++at[t][(size_t)(l.id - lo_id)];
+                    size_t* mine_at = at[t].data();
+                    for (const Line& l : mine[t]) ++mine_at[(size_t)(l.id - lo_id)];
                 });
                 size_t run = 0;
                 for (size_t v = 0; v < (size_t)range; ++v)
                     for (unsigned t = 0; t < nt; ++t) { const size_t c = at[t][v]; at[t][v] = run; run += c; }
                 run_threads(nt, [&](unsigned t) {
-                    for (const Line& l : mine[t]) lines[at[t][(size_t)(l.id - lo_id)]++] = l;
+                    size_t* mine_at = at[t].data();
+                    Line* to = lines.data();
+                    for (const Line& l : mine[t]) to[mine_at[(size_t)(l.id - lo_id)]++] = l;
                 });
             } else {
                 size_t k = 0;
@@ -1059,6 +1069,13 @@ int main(int argc, char* argv[])
             std::vector<SplitAlignment> alignments;
             std::vector<const SplitAlignment*> kept;
             std::map<std::pair<int, int>, int> splitScore;
+            std::string my_text;                             // (local, handed over at the end: the shared vectors' elements are neighbours in memory)
+            EvalTexts my_ev;
+            {
+                size_t bytes = 0;
+                for (size_t k = group[ng * t / nt]; k < group[ng * (t + 1) / nt]; ++k) bytes += lines[k].len;
+                my_text.reserve(bytes);
+            }
             for (size_t g = ng * t / nt; g < ng * (t + 1) / nt; ++g) {
                 std::sort(lines.begin() + (std::ptrdiff_t)group[g], lines.begin() + (std::ptrdiff_t)group[g + 1], [](const Line& a, const Line& b) {
                     const int c = memcmp(a.p, b.p, std::min(a.len, b.len));
@@ -1066,7 +1083,7 @@ int main(int argc, char* argv[])
                 });
                 alignments.clear();
                 for (size_t k = group[g]; k < group[g + 1]; ++k) {
-                    sorted_text[t].append(lines[k].p, lines[k].len);
+                    my_text.append(lines[k].p, lines[k].len);
                     if (fused_eval) {
                         SplitAlignment a;
                         bool id_read;
@@ -1077,9 +1094,11 @@ int main(int argc, char* argv[])
                 }
                 if (fused_eval) {
                     auto ti = tasks.find(lines[group[g]].id);
-                    EvaluateGroup(ti == tasks.end() ? emptyTask : ti->second, alignments, ev[t], kept, splitScore);
+                    EvaluateGroup(ti == tasks.end() ? emptyTask : ti->second, alignments, my_ev, kept, splitScore);
                 }
             }
+            sorted_text[t].swap(my_text);
+            ev[t].seq.swap(my_ev.seq); ev[t].brk.swap(my_ev.brk); ev[t].pred.swap(my_ev.pred);
         });
         out.write_round(sorted_text, nt);
         if (fused_eval) {
