@@ -1366,7 +1366,7 @@ struct SplitAlignmentTask {
 
 inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, const std::string& exonsFile, double fragMean,
                                                      double fragStdDev, int minRead, int maxRead,
-                                                     const std::map<int, std::vector<Location>>& regions)
+                                                     const std::map<int, std::vector<Location>>& regions, unsigned threads = 0)
 {
     FastaIndex reference;
     ExonRegions exons;
@@ -1381,7 +1381,7 @@ inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, c
         ids.push_back(kv.first);
     }
     // the fusions are independent and everything they read (index, exon tables, the FASTA through pread) is read-only
-    const unsigned n = work.size() < 64 ? 1u : host_threads();
+    const unsigned n = work.size() < 64 ? 1u : (threads ? threads : host_threads());
     run_threads(n, [&](unsigned t) {
         for (size_t i = t; i < work.size(); i += n)
             work[i].first->Initialize(ids[i], *work[i].second, reference, exons, fragMean, fragStdDev, minRead, maxRead);
@@ -1389,7 +1389,10 @@ inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, c
     return tasks;
 }
 
-// tools/SplitAlignment.cpp:177-229
+// tools/SplitAlignment.cpp:177-229.  The reference keeps a hash map of bins per strand and reference name; here the (strand,
+// reference, bin, region) entries are collected flat, sorted once (Finish) and looked up through a table of bin starts per
+// (strand, reference): a hundred thousand fusions' regions are binned in milliseconds, and a lookup is one hash of the name
+// and an index.  Within a bin the regions keep the order in which they were added.
 class BinnedLocations {
 public:
     explicit BinnedLocations(int spacing) : spacing_(spacing) {}
@@ -1398,20 +1401,57 @@ public:
         const int idx = (int)ids_.size();
         ids_.push_back(id);
         regions_.push_back(Region{loc.start, loc.end});
-        for (int b = loc.start / spacing_; b <= loc.end / spacing_; ++b) binned_[loc.strand][loc.refName][b].push_back(idx);
+        auto it = ref_index_[loc.strand].find(loc.refName);
+        int ref;
+        if (it == ref_index_[loc.strand].end()) {
+            ref = (int)refs_.size();
+            ref_index_[loc.strand].emplace(loc.refName, ref);
+            refs_.emplace_back();
+        } else {
+            ref = it->second;
+        }
+        for (int b = loc.start / spacing_; b <= loc.end / spacing_; ++b) entries_.push_back(Entry{ref, b, idx});
+        finished_ = false;
+    }
+    // after the last Add, before the first Overlapping
+    void Finish()
+    {
+        std::sort(entries_.begin(), entries_.end(), [](const Entry& a, const Entry& b) {
+            if (a.ref != b.ref) return a.ref < b.ref;
+            if (a.bin != b.bin) return a.bin < b.bin;
+            return a.idx < b.idx;
+        });
+        flat_.resize(entries_.size());
+        for (size_t k = 0; k < entries_.size(); ++k) flat_[k] = entries_[k].idx;
+        for (size_t k = 0; k < entries_.size();) {                      // per reference: its bins' starts in flat_, from its first bin on
+            const int ref = entries_[k].ref;
+            size_t e = k;
+            while (e < entries_.size() && entries_[e].ref == ref) ++e;
+            RefBins& rb = refs_[(size_t)ref];
+            rb.first_bin = entries_[k].bin;
+            const int n_bins = entries_[e - 1].bin - rb.first_bin + 1;
+            rb.start.assign((size_t)n_bins + 1, 0);
+            for (size_t x = k; x < e; ++x) ++rb.start[(size_t)(entries_[x].bin - rb.first_bin) + 1];
+            rb.start[0] = (uint32_t)k;
+            for (int v = 0; v < n_bins; ++v) rb.start[(size_t)v + 1] += rb.start[(size_t)v];
+            k = e;
+        }
+        std::vector<Entry>().swap(entries_);
+        finished_ = true;
     }
     // ids of the regions that overlap, each once, ascending as signed ints (the canonical visiting order)
     void Overlapping(const std::string& ref, int strand, const Region& region, std::vector<int>& ids) const
     {
         ids.clear();
-        auto ri = binned_[strand].find(ref);
-        if (ri == binned_[strand].end()) return;
-        for (int b = region.start / spacing_; b <= region.end / spacing_; ++b) {
-            auto bi = ri->second.find(b);
-            if (bi == ri->second.end()) continue;
-            for (int idx : bi->second)
+        auto ri = ref_index_[strand].find(ref);
+        if (ri == ref_index_[strand].end() || !finished_) return;
+        const RefBins& rb = refs_[(size_t)ri->second];
+        const int n_bins = (int)rb.start.size() - 1;
+        for (int b = std::max(region.start / spacing_, rb.first_bin); b <= region.end / spacing_ && b - rb.first_bin < n_bins; ++b)
+            for (uint32_t x = rb.start[(size_t)(b - rb.first_bin)]; x < rb.start[(size_t)(b - rb.first_bin) + 1]; ++x) {
+                const int idx = flat_[x];
                 if (regions_[idx].start <= region.end && regions_[idx].end >= region.start) ids.push_back(ids_[idx]);
-        }
+            }
         if (ids.size() > 1) {
             std::sort(ids.begin(), ids.end());
             ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
@@ -1419,8 +1459,14 @@ public:
     }
 
 private:
+    struct Entry { int ref, bin, idx; };
+    struct RefBins { int first_bin = 0; std::vector<uint32_t> start; };
     int spacing_;
-    std::unordered_map<std::string, std::unordered_map<int, std::vector<int>>> binned_[2];
+    bool finished_ = true;
+    std::unordered_map<std::string, int> ref_index_[2];       // (strand, name) -> refs_
+    std::vector<RefBins> refs_;
+    std::vector<Entry> entries_;
+    std::vector<int> flat_;
     std::vector<int> ids_;
     std::vector<Region> regions_;
 };

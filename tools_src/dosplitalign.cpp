@@ -454,7 +454,7 @@ int main(int argc, char* argv[])
         ~Joiner() { if (th.joinable()) th.join(); }
     } reads_joiner{reads_thread};
     std::map<int, SplitAlignmentTask> tasks = CreateTasks(cmd.str("fasta"), cmd.str("exons"), cmd.real("ufrag"), cmd.real("sfrag"),
-                                                         cmd.integer("minread"), cmd.integer("maxread"), regions);
+                                                         cmd.integer("minread"), cmd.integer("maxread"), regions, nThreads);
     stage("  tasks (windows from the FASTA, mate regions)");
 
     // SplitReadRealigner::AddTask (tools/SplitAlignment.cpp:236-251): 2000 bp bins over the mate regions
@@ -470,6 +470,7 @@ int main(int argc, char* argv[])
         task_of.push_back(&kv.second);
         fusion_id_of.push_back(kv.second.mFusionID);
     }
+    binned.Finish();
     const size_t n_tasks = task_of.size();
     stage("fasta index + exons + windows");
     bool reads_reported = false;
@@ -503,7 +504,13 @@ int main(int argc, char* argv[])
     std::condition_variable q_cv;
     uint64_t n_built = 0;                    // batches handed to the worker
     bool no_more = false;
-    std::vector<std::string> collected;
+    struct Text {                            // a formatted batch share kept for the fused tail: the writer's buffer itself, not a copy
+        std::unique_ptr<char[]> p;
+        size_t len = 0;
+        const char* data() const { return p.get(); }
+        size_t size() const { return len; }
+    };
+    std::vector<Text> collected;
     double t_wait_gpu = 0, t_format = 0, t_service = 0, t_first_wait = 0;
     uint64_t n_batches = 0;
     double svc_ms[8][2] = {};
@@ -584,7 +591,13 @@ int main(int argc, char* argv[])
                 out.write_part(B.p.get(), B.len, at[t]);
             });
             if (collect)
-                for (const Buf& B : bufs) collected.emplace_back(B.p.get(), B.len);       // fused mode: sorted and evaluated at the end
+                for (Buf& B : bufs) {                    // fused mode: sorted and evaluated at the end
+                    if (!B.len) continue;
+                    collected.emplace_back();
+                    collected.back().p = std::move(B.p);
+                    collected.back().len = B.len;
+                    B.cap = B.len = 0;
+                }
             else if (!out.seekable())
                 for (const Buf& B : bufs) out.append(B.p.get(), B.len);
             t_format += now() - t1;
@@ -994,7 +1007,7 @@ int main(int argc, char* argv[])
             std::vector<std::vector<Line>> mine(nt);
             std::vector<int> id_lo(nt, INT_MAX), id_hi(nt, INT_MIN);
             size_t total_bytes = 0;
-            for (const std::string& tx : collected) total_bytes += tx.size();
+            for (const Text& tx : collected) total_bytes += tx.size();
             std::vector<size_t> first_text(nt + 1, collected.size());
             {
                 size_t acc = 0;
@@ -1013,7 +1026,7 @@ int main(int argc, char* argv[])
                 for (size_t k = first_text[t]; k < first_text[t + 1]; ++k) bytes += collected[k].size();
                 v.reserve(bytes / 48 + 16);                  // alignment lines are longer than this
                 for (size_t k = first_text[t]; k < first_text[t + 1]; ++k) {
-                    const std::string& tx = collected[k];
+                    const Text& tx = collected[k];
                     for (size_t pos = 0; pos < tx.size();) {
                         const char* nl = (const char*)memchr(tx.data() + pos, '\n', tx.size() - pos);
                         const size_t e = nl ? (size_t)(nl - tx.data()) + 1 : tx.size();
