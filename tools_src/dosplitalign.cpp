@@ -318,26 +318,6 @@ int main(int argc, char* argv[])
         _exit(1);
     };
 
-    if (!opt_clusters.empty()) {
-        // scripts/get_align_regions.pl:14-53 (as bin/defuse_glue get_align_regions): per cluster end the reference, the strand
-        // and the span of its alignments; clusters ascending, end 0 then 1
-        std::string text;
-        try {
-            ClusterPieces pieces;                 // (its threads end before the worker is forked)
-            pieces.load(opt_clusters);
-            text = align_regions_text(pieces);
-        } catch (const GlueError& g) {
-            die(g.msg);
-        }
-        OrderedFileWriter rf;
-        if (!rf.open_file(cmd.str("regions"))) die("Error: unable to write " + cmd.str("regions"));
-        rf.write_round({text}, 1);
-        if (!rf.close_file()) die("Error: failed writing " + cmd.str("regions"));
-        stage("clusters -> regions file");
-    }
-    const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
-    stage("regions");
-
     // ---- the slots and the worker (before any thread of this process exists) ----------------------------------------------
     size_t batch_pairs = (size_t)1 << 18;
     if (const char* e = std::getenv("DEFUSE_DSA_BATCH_PAIRS")) batch_pairs = std::max<size_t>(1, (size_t)std::atoll(e));
@@ -349,9 +329,9 @@ int main(int argc, char* argv[])
     Channel* ch = nullptr;
     bool have_worker = false, inprocess = false;
     std::thread worker_thread;
-    if (!regions.empty()) {
-        R.cap_pairs = std::min<size_t>(batch_pairs + 2 * regions.size() + 4096, ((size_t)1 << 31) - 1);
-        R.cap_fusions = std::min(R.cap_pairs, regions.size()) + 1;
+    auto start_worker = [&](size_t n_fusions) {          // n_fusions: the regions' count, or a bound of it (it sizes address space only)
+        R.cap_pairs = std::min<size_t>(batch_pairs + 2 * n_fusions + 4096, ((size_t)1 << 31) - 1);
+        R.cap_fusions = std::min(R.cap_pairs, n_fusions) + 1;
         R.cap_ref = ((size_t)1 << 31) - 1;
         R.cap_reads = ((size_t)1 << 31) - 1;
         R.cap_recs = std::max<size_t>(8 * R.cap_pairs, (size_t)64 << 20);
@@ -398,7 +378,40 @@ int main(int argc, char* argv[])
         }
         if (inprocess) worker_thread = std::thread(worker_main, ch, &R);
         have_worker = true;
+    };
+    // The worker is started as early as the sizes allow: the HIP runtime takes 0.15-0.35 s to come up, as long as this process
+    // needs for regions, tasks and bins.  The slots are address space (MAP_NORESERVE): a bound of the number of fusions from the
+    // size of the regions (or clusters) file is as good as the count.  An input that is not a plain file, or a very large one,
+    // starts the worker after the regions are read, by their count.
+    {
+        const std::string& sized_by = opt_clusters.empty() ? cmd.str("regions") : opt_clusters;
+        struct stat st;
+        if (sized_by != "-" && stat(sized_by.c_str(), &st) == 0 && S_ISREG(st.st_mode)) {
+            const size_t bound = (size_t)st.st_size / (opt_clusters.empty() ? 12 : 32) + 16;      // two lines per fusion, this short at least
+            if (bound <= ((size_t)4 << 20)) start_worker(bound);
+        }
     }
+    if (!opt_clusters.empty()) {
+        // scripts/get_align_regions.pl:14-53 (as bin/defuse_glue get_align_regions): per cluster end the reference, the strand
+        // and the span of its alignments; clusters ascending, end 0 then 1
+        std::string text;
+        try {
+            ClusterPieces pieces;                 // (its threads end before the worker is forked)
+            pieces.load(opt_clusters);
+            text = align_regions_text(pieces);
+        } catch (const GlueError& g) {
+            die(g.msg);
+        }
+        OrderedFileWriter rf;
+        if (!rf.open_file(cmd.str("regions"))) die("Error: unable to write " + cmd.str("regions"));
+        rf.write_round({text}, 1);
+        if (!rf.close_file()) die("Error: failed writing " + cmd.str("regions"));
+        stage("clusters -> regions file");
+    }
+    const std::map<int, std::vector<Location>> regions = ReadAlignRegionPairs(cmd.str("regions"));
+    stage("regions");
+
+    if (!have_worker && !regions.empty()) start_worker(regions.size());
     std::thread inputs_ahead;
     if (have_worker) {
         inputs_ahead = std::thread([&R] {             // the pages the first batches are built in
