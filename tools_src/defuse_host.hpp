@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <cctype>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1368,24 +1369,36 @@ inline std::map<int, SplitAlignmentTask> CreateTasks(const std::string& fasta, c
                                                      double fragStdDev, int minRead, int maxRead,
                                                      const std::map<int, std::vector<Location>>& regions, unsigned threads = 0)
 {
+    const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
+    auto clock_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = clock_now();
+    auto lap = [&](const char* what) {
+        const double t = clock_now();
+        if (timing) std::cerr << "[tasks]     " << what << " " << (t - t0) << " s" << std::endl;
+        t0 = t;
+    };
     FastaIndex reference;
     ExonRegions exons;
     reference.Open(fasta);
+    lap("fasta index");
     std::ifstream ef(exonsFile.c_str());
     if (!ef.good() || !exons.Read(ef)) die("Error: Unable to read exon regions file " + exonsFile);
+    lap("exon regions");
     std::map<int, SplitAlignmentTask> tasks;   // canonical iteration order: ascending fusion id
     std::vector<std::pair<SplitAlignmentTask*, const std::vector<Location>*>> work;
     std::vector<int> ids;
     for (const auto& kv : regions) {
-        work.emplace_back(&tasks[kv.first], &kv.second);
+        work.emplace_back(&tasks.emplace_hint(tasks.end(), kv.first, SplitAlignmentTask())->second, &kv.second);
         ids.push_back(kv.first);
     }
+    lap("task table");
     // the fusions are independent and everything they read (index, exon tables, the FASTA through pread) is read-only
     const unsigned n = work.size() < 64 ? 1u : (threads ? threads : host_threads());
     run_threads(n, [&](unsigned t) {
         for (size_t i = t; i < work.size(); i += n)
             work[i].first->Initialize(ids[i], *work[i].second, reference, exons, fragMean, fragStdDev, minRead, maxRead);
     });
+    lap("windows and mate regions");
     return tasks;
 }
 
