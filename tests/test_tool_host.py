@@ -191,3 +191,16 @@ def test_sorted_output_is_gnu_sorts(double, case, env):
     assert r.returncode == 0, r.stderr[-2000:]
     want = subprocess.run(["sort", "-n", "-k", "1"], input=exp, capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout
     assert open(out).read() == want
+
+
+def test_runs_inside_a_limit_on_address_space(double, case):
+    """the pipeline's submitters give a job 6 GB.  Where that is enforced on ADDRESS SPACE (`ulimit -v`, h_vmem) the
+    batch slots — reserved at their largest useful size, which is address space only — are reserved smaller instead of failing, and
+    the batches are cut to fit: the same file.  (The HIP runtime itself wants more address space than such a limit leaves: on a GPU
+    box the limit has to be on resident memory.  The test double has no runtime.)"""
+    c, exp, d = case
+    out = str(d / "vlimit.align")
+    cmd = "ulimit -v 6000000; exec %s %s" % (TOOL, " ".join(pipeline_case.tool_args(c, out)))
+    r = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, env=dict(os.environ, DEFUSE_DSA_LIB=double, DEFUSE_THREADS="4"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == exp

@@ -332,22 +332,39 @@ int main(int argc, char* argv[])
     auto start_worker = [&](size_t n_fusions) {          // n_fusions: the regions' count, or a bound of it (it sizes address space only)
         R.cap_pairs = std::min<size_t>(batch_pairs + 2 * n_fusions + 4096, ((size_t)1 << 31) - 1);
         R.cap_fusions = std::min(R.cap_pairs, n_fusions) + 1;
-        R.cap_ref = ((size_t)1 << 31) - 1;
-        R.cap_reads = ((size_t)1 << 31) - 1;
-        R.cap_recs = std::max<size_t>(8 * R.cap_pairs, (size_t)64 << 20);
         R.hint_pairs = std::min(batch_pairs, R.cap_pairs);
         R.hint_read_bytes = std::min<size_t>(R.hint_pairs * (size_t)std::max(cmd.integer("maxread"), 32), (size_t)256 << 20);
         ch = (Channel*)map_shared(sizeof(Channel));
-        bool ok = ch != nullptr;
-        for (int s = 0; s < DEPTH && ok; ++s) {
-            R.ref[s] = (uint8_t*)map_shared(R.cap_ref);
-            R.reads[s] = (uint8_t*)map_shared(R.cap_reads);
-            R.fusions[s] = (dsa_fusion*)map_shared(R.cap_fusions * sizeof(dsa_fusion));
-            R.pairs[s] = (dsa_pair*)map_shared(R.cap_pairs * sizeof(dsa_pair));
-            R.recs[s] = (dsa_record*)map_shared(R.cap_recs * sizeof(dsa_record));
-            ok = R.ref[s] && R.reads[s] && R.fusions[s] && R.pairs[s] && R.recs[s];
+        // The slots are reserved at their largest useful size (address space, not memory).  Under a limit on address space
+        // (`ulimit -v`, a scheduler's h_vmem) that may be refused: the byte buffers are then reserved at half the size, and half
+        // again, and the batches are cut to what was had.
+        bool ok = false;
+        for (int attempt = 0; attempt < 7 && ch && !ok; ++attempt) {
+            R.cap_ref = (((size_t)1 << 31) - 1) >> attempt;
+            R.cap_reads = (((size_t)1 << 31) - 1) >> attempt;
+            R.cap_recs = std::max<size_t>(8 * R.cap_pairs, ((size_t)64 << 20) >> attempt);
+            ok = true;
+            for (int s = 0; s < DEPTH && ok; ++s) {
+                R.ref[s] = (uint8_t*)map_shared(R.cap_ref);
+                R.reads[s] = (uint8_t*)map_shared(R.cap_reads);
+                R.fusions[s] = (dsa_fusion*)map_shared(R.cap_fusions * sizeof(dsa_fusion));
+                R.pairs[s] = (dsa_pair*)map_shared(R.cap_pairs * sizeof(dsa_pair));
+                R.recs[s] = (dsa_record*)map_shared(R.cap_recs * sizeof(dsa_record));
+                ok = R.ref[s] && R.reads[s] && R.fusions[s] && R.pairs[s] && R.recs[s];
+            }
+            if (!ok)
+                for (int s = 0; s < DEPTH; ++s) {
+                    if (R.ref[s]) munmap(R.ref[s], std::max<size_t>(R.cap_ref, 4096));
+                    if (R.reads[s]) munmap(R.reads[s], std::max<size_t>(R.cap_reads, 4096));
+                    if (R.fusions[s]) munmap(R.fusions[s], std::max<size_t>(R.cap_fusions * sizeof(dsa_fusion), 4096));
+                    if (R.pairs[s]) munmap(R.pairs[s], std::max<size_t>(R.cap_pairs * sizeof(dsa_pair), 4096));
+                    if (R.recs[s]) munmap(R.recs[s], std::max<size_t>(R.cap_recs * sizeof(dsa_record), 4096));
+                    R.ref[s] = R.reads[s] = nullptr; R.fusions[s] = nullptr; R.pairs[s] = nullptr; R.recs[s] = nullptr;
+                }
         }
         if (!ok) die("Error: cannot reserve the batch buffers");
+        limit_read_bytes = std::min(limit_read_bytes, R.cap_reads);
+        limit_ref_bytes = std::min(limit_ref_bytes, R.cap_ref);
         new (ch) Channel();
         sem_init(&ch->submit_sem, 1, 0);
         sem_init(&ch->collect_sem, 1, 0);
@@ -717,7 +734,7 @@ int main(int argc, char* argv[])
                 for (unsigned u = 0; u < nt; ++u) { part_a[u + 1] += part_a[u]; part_b[u + 1] += part_b[u]; }
                 n_slots = part_a[nt];
                 ref_total = part_b[nt];
-                fits = ref_total <= (single_record ? ((size_t)1 << 31) - 1 : limit_ref_bytes) && n_slots <= R.cap_fusions;       // one record's candidates cannot be split
+                fits = ref_total <= (single_record ? R.cap_ref : limit_ref_bytes) && n_slots <= R.cap_fusions;       // one record's candidates cannot be split
                 slot_start.resize(n_slots + 1);
                 slot_count.resize(n_slots + 1);
             }
@@ -820,7 +837,7 @@ int main(int argc, char* argv[])
         for (size_t c = c0 + 1; c < c1 && single; ++c) single = !cands[c].first_of_record;
         if (!build_batch(c0, c1, s, single)) {
             sem_post(&free_sem);
-            if (single) die("Error: the reference windows of one alignment's candidates exceed 2 GiB");
+            if (single) die("Error: the reference windows of one alignment's candidates exceed the batch buffer (" + std::to_string(R.cap_ref) + " bytes)");
             size_t mid = c0 + (c1 - c0) / 2;                             // the windows of the batch's fusions exceed the limit: two halves,
             while (mid < c1 && !cands[mid].first_of_record) ++mid;       // cut between two records
             if (mid >= c1) {
@@ -984,7 +1001,7 @@ int main(int argc, char* argv[])
                 if (e == c0) {                                           // the first record by itself is over the limit: it goes alone, if it can
                     e = c0 + 1;
                     while (e < n_round && !cands[e].first_of_record) ++e;
-                    if (bytes_of(e) >= ((uint64_t)1 << 31)) die("Error: the reads of one alignment's candidates exceed 2 GiB");
+                    if (bytes_of(e) > (uint64_t)R.cap_reads) die("Error: the reads of one alignment's candidates exceed the batch buffer (" + std::to_string(R.cap_reads) + " bytes)");
                 }
                 c1 = e;
             }
