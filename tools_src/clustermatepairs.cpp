@@ -16,6 +16,7 @@
 #include "../include/defuse_cmp.h"
 #include "../include/defuse_dsa.h"
 #include "../include/defuse_mpe.h"
+#define DEFUSE_HUGE_NEW          // large blocks from huge-page mappings (defuse_host.hpp)
 #include "defuse_host.hpp"
 
 using namespace defuse;

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <new>
 #include <cerrno>
 #include <cctype>
 #include <cmath>
@@ -163,6 +164,71 @@ inline void keep_freed_memory()
     mallopt(M_TRIM_THRESHOLD, INT_MAX);
     mallopt(M_TOP_PAD, 256 << 20);
 }
+
+// For a tool that defines DEFUSE_HUGE_NEW before this header (clustermatepairs): large blocks (tables, parsed records and output
+// texts: gigabytes at full size) come from mappings of their own that ask for transparent huge pages.  Where the system grants them on request only (/sys/kernel/mm/transparent_hugepage/enabled =
+// madvise, as on the MI355X boxes) a table's first touch is then one fault per 2 MiB instead of one per 4 KiB: clustermatepairs at
+// 50 M fragments 5.7 -> 5.0-5.2 s (profiles/r04/tools/cmp50_huge_pages.txt; setcover, whose tables are indexed by fragment id and
+// touched sparsely, loses 0.6 s with it and does not use it).  Everything below the
+// threshold is malloc's.  DEFUSE_NO_HUGE_BLOCKS=1 (or DEFUSE_MALLOC_DEFAULT=1) switches it off; sanitizer builds keep their own
+// operator new.
+#if defined(DEFUSE_HUGE_NEW) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
+namespace huge_blocks {
+constexpr size_t THRESHOLD = (size_t)8 << 20, ALIGN = (size_t)2 << 20;
+struct Block { void* base; size_t len; };
+struct Registry {
+    std::mutex m;
+    std::unordered_map<void*, Block> blocks;        // by the pointer handed out (2 MiB aligned)
+};
+inline Registry& registry() { static Registry* r = new Registry; return *r; }     // never destroyed: deletes may come late
+inline bool enabled() { static const bool on = !std::getenv("DEFUSE_MALLOC_DEFAULT") && !std::getenv("DEFUSE_NO_HUGE_BLOCKS"); return on; }
+inline void* take(size_t n)
+{
+    const size_t len = ((n + 4095) & ~(size_t)4095) + ALIGN;
+    void* base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) return nullptr;
+    void* user = (void*)(((uintptr_t)base + ALIGN - 1) & ~(uintptr_t)(ALIGN - 1));
+    (void)madvise(user, len - ((uintptr_t)user - (uintptr_t)base), MADV_HUGEPAGE);
+    Registry& r = registry();
+    std::lock_guard<std::mutex> lk(r.m);
+    r.blocks[user] = Block{base, len};
+    return user;
+}
+inline bool give_back(void* p)
+{
+    if ((uintptr_t)p & (ALIGN - 1)) return false;       // (malloc's blocks are never 2 MiB aligned in practice; the table decides)
+    Registry& r = registry();
+    Block b;
+    {
+        std::lock_guard<std::mutex> lk(r.m);
+        auto it = r.blocks.find(p);
+        if (it == r.blocks.end()) return false;
+        b = it->second;
+        r.blocks.erase(it);
+    }
+    munmap(b.base, b.len);
+    return true;
+}
+}  // namespace huge_blocks
+}  // namespace defuse
+void* operator new(size_t n)
+{
+    if (n >= defuse::huge_blocks::THRESHOLD && defuse::huge_blocks::enabled())
+        if (void* p = defuse::huge_blocks::take(n)) return p;
+    void* p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void* operator new[](size_t n) { return operator new(n); }
+void operator delete(void* p) noexcept
+{
+    if (p && !defuse::huge_blocks::give_back(p)) std::free(p);
+}
+void operator delete[](void* p) noexcept { operator delete(p); }
+void operator delete(void* p, size_t) noexcept { operator delete(p); }
+void operator delete[](void* p, size_t) noexcept { operator delete(p); }
+namespace defuse {
+#endif
 
 // host threads of a tool: DEFUSE_THREADS, else 8 (profiles/microbench/cmp_threads.sh: beyond that the joins cost more than
 // the pieces save), never more than the machine has
