@@ -174,7 +174,12 @@ inline void keep_freed_memory()
 // operator new.
 #if defined(DEFUSE_HUGE_NEW) && !defined(__SANITIZE_ADDRESS__) && !defined(__SANITIZE_THREAD__)
 namespace huge_blocks {
-constexpr size_t THRESHOLD = (size_t)8 << 20, ALIGN = (size_t)2 << 20;
+constexpr size_t ALIGN = (size_t)2 << 20;
+inline size_t threshold()          // DEFUSE_HUGE_BLOCK_MIN (bytes): measurements
+{
+    static const size_t v = [] { const char* e = std::getenv("DEFUSE_HUGE_BLOCK_MIN"); return e ? (size_t)std::max(4096LL, std::atoll(e)) : (size_t)8 << 20; }();
+    return v;
+}
 struct Block { void* base; size_t len; };
 struct Registry {
     std::mutex m;
@@ -213,7 +218,7 @@ inline bool give_back(void* p)
 }  // namespace defuse
 void* operator new(size_t n)
 {
-    if (n >= defuse::huge_blocks::THRESHOLD && defuse::huge_blocks::enabled())
+    if (n >= defuse::huge_blocks::threshold() && defuse::huge_blocks::enabled())
         if (void* p = defuse::huge_blocks::take(n)) return p;
     void* p = std::malloc(n ? n : 1);
     if (!p) throw std::bad_alloc();
