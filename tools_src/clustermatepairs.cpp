@@ -176,6 +176,31 @@ int main(int argc, char* argv[])
         if (timing) std::cerr << "[clustermatepairs] " << name << " " << (t - t_stage) << " s" << std::endl;
         t_stage = t;
     };
+    // The HIP runtime takes 0.15-0.25 s to come up: the bin-pair builder — this process's first GPU call — is created
+    // on a thread of its own while the input is read and parsed.  An error exit while that thread is inside the runtime must not run
+    // exit handlers beside it: die() flushes and leaves at once, as the success path does.
+    die_hook() = [] {
+        std::cout.flush();
+        std::cerr.flush();
+        fflush(nullptr);
+        _exit(1);
+    };
+    const bool host_binning = [] { const char* e = std::getenv("DEFUSE_CMP_HOST_BINNING"); return e && std::atoi(e) != 0; }();
+    int gpu_device = -1;                                                      // the device of this process's first GPU call
+    cmp_binner* binner = nullptr;
+    int binner_rc = DSA_OK;
+    std::string binner_error;
+    std::thread binner_thread;
+    if (!host_binning)
+        binner_thread = std::thread([&] {
+            gpu_device = dsa_pick_device();
+            binner_rc = cmp_bin_create(&binner, gpu_device);
+            if (binner_rc != DSA_OK) binner_error = cmp_last_error();
+        });
+    struct ThreadJoiner {                    // (an exception that unwinds main must not meet a joinable thread)
+        std::thread& th;
+        ~ThreadJoiner() { if (th.joinable()) th.join(); }
+    } binner_joiner{binner_thread};
     std::cout << "Finding pairs of reference sequences connected by pairs of alignments" << std::endl;
     // The input is taken into memory whole and cut into one piece per host thread at fragment boundaries.  Every piece is
     // parsed, then (with reference indices in order of first appearance over the whole file, as a serial reader gives
@@ -323,14 +348,13 @@ int main(int argc, char* argv[])
     // The bin pairs: key (first.id << 32 | second.id) and the two lists of each.  By default they are built on the GPU
     // (include/defuse_cmp.h); DEFUSE_CMP_HOST_BINNING=1 runs the host transcription below instead — a cross-check the tests
     // hold against the device path, never a fallback.
-    const bool host_binning = [] { const char* e = std::getenv("DEFUSE_CMP_HOST_BINNING"); return e && std::atoi(e) != 0; }();
     std::vector<uint64_t> binPairKey;
     std::vector<PairView> binPairStore;
     struct Joined { std::vector<uint64_t> key; std::vector<PackedPair> store; };
     std::vector<Joined> joined(host_binning ? nThreads : 0);                  // owner of the lists (host path)
     std::unique_ptr<AlignmentPacked[]> devFirst, devSecond;                   // owner of the lists (device path)
-    int gpu_device = -1;                                                      // the device of this process's first GPU call
     auto first_device = [&] {
+        if (binner_thread.joinable()) binner_thread.join();
         if (gpu_device < 0) gpu_device = dsa_pick_device();
         return gpu_device;
     };
@@ -477,8 +501,8 @@ int main(int argc, char* argv[])
             recBase[t + 1] = recBase[t] + pieces[t].recs.size();
             fragBase[t + 1] = fragBase[t] + pieces[t].fragStart.size() - 1;
         }
-        cmp_binner* binner = nullptr;
-        if (cmp_bin_create(&binner, first_device()) != DSA_OK) die(std::string("Error: no usable MI355X/HIP device (") + cmp_last_error() + ")");
+        if (binner_thread.joinable()) binner_thread.join();
+        if (binner_rc != DSA_OK || !binner) die(std::string("Error: no usable MI355X/HIP device (") + binner_error + ")");
         if (cmp_bin_reserve(binner, (int64_t)recBase[nThreads], (int64_t)fragBase[nThreads]) != DSA_OK) die(std::string("Error: ") + cmp_last_error());
         std::vector<int> rcs(nThreads, DSA_OK);
         run_threads([&](unsigned t) {
