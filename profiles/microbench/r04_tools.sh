@@ -21,7 +21,7 @@ for r in d["stages"]:
     print(r["stage"], r["wall_s"], r["gpu_s"])
 print(d.get("dosplitalign_chunks_in_parallel"))
 for k, v in d.get("fused", {}).items():
-    print("fused", k, v["wall_s"], "same alignments", v["same_alignments_file"], "same final files", v["same_final_files"])
+    print("fused", k, v["wall_s"], "same alignments", v["same_alignments_file"], "same final files", v.get("same_final_files"), [(r["stage"][:40], r["wall_s"]) for r in v.get("stages", [])])
 PY
 rm -rf /tmp/e2e /tmp/e2e_small
 timeout -k 10 900 bash profiles/microbench/mpe_roofline.sh > $O/mpe_roofline.log 2>&1 || { tail -30 $O/mpe_roofline.log; exit 1; }

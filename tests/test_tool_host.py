@@ -204,3 +204,13 @@ def test_runs_inside_a_limit_on_address_space(double, case):
     r = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, env=dict(os.environ, DEFUSE_DSA_LIB=double, DEFUSE_THREADS="4"), timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out).read() == exp
+
+
+def test_sorted_by_environment_keeps_the_reference_command_line(double, case):
+    """DEFUSE_DSA_SORTED=1 (no fused-mode options): the same alignments in the order of `LC_ALL=C sort -n -k 1`."""
+    c, exp, d = case
+    out = str(d / "sorted_env.align")
+    r = run_tool(c, out, double, {"DEFUSE_DSA_SORTED": "1", "DEFUSE_THREADS": "3", "DEFUSE_DSA_BATCH_PAIRS": "30"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = subprocess.run(["sort", "-n", "-k", "1"], input=exp, capture_output=True, text=True, env=dict(os.environ, LC_ALL="C"), check=True).stdout
+    assert open(out).read() == want

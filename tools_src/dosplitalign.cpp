@@ -295,7 +295,11 @@ int main(int argc, char* argv[])
     const bool fused_eval = !opt_seq.empty() || !opt_break.empty() || !opt_predalign.empty();
     if (fused_eval && (opt_seq.empty() || opt_break.empty() || opt_predalign.empty()))
         die("Error: the fused mode needs all of --seq, --break and --predalign");
-    const bool collect = fused_eval || (fused_cli && cmd.is_set("sorted"));
+    // DEFUSE_DSA_SORTED=1: the reference's command line, the alignments written in the order of `LC_ALL=C sort -n -k 1` (the order
+    // inside the file is free — the pipeline sorts every chunk's file next, scripts/defuse_run.pl:528 — and GNU sort runs 2.6 times
+    // faster over input that is in order already)
+    const bool sorted_env = [] { const char* e = std::getenv("DEFUSE_DSA_SORTED"); return e && std::atoi(e) != 0; }();
+    const bool collect = fused_eval || (fused_cli && cmd.is_set("sorted")) || sorted_env;
     const bool timing = std::getenv("DEFUSE_TIMING") != nullptr;
     const double t_main = now();
     double t_stage = now();
