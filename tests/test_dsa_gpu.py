@@ -416,6 +416,23 @@ def test_workload_mixes_equal_the_oracle(built, mix):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(33334, 3, 76, 389), (20000, 5, 150, 590), (100000, 1, 76, 389)], ids=["3-per-fusion", "5-per-fusion-2x150", "1-per-fusion"])
+def test_many_fusions_with_few_reads_equal_the_oracle(built, shape):
+    """The shape of a pipeline chunk (a million reads against every fusion: a handful of candidates per fusion and batch,
+    profiles/r04/reads_per_fusion.txt): workgroups hold more fusions than the table kernels take and run in k_fill_generic, the
+    planner works on fusions of one to five reads.  100 000 pairs, every record against the CPU oracle."""
+    import bench
+    from defuse_amd import dsa, synth
+    fusions, reads, lq, lr = shape
+    batch = synth.make_batch(fusions, reads, lq=lq, lr=lr, seed=17)
+    exp = bench.oracle_records(batch, len(batch[3]))
+    ctx = dsa.Context(0)
+    got = ctx.align_batch(*batch)
+    assert len(got) == len(exp) and got.tobytes() == exp.tobytes(), shape
+    assert ctx.timing().n_generic_tasks > 0
+    ctx.close()
+
+
 def test_timing_cells_is_exact_on_every_planning_path(built):
     """dsa_timing.cells = sum over pairs of (Lref0 + 1 + Lref1 + 1) * (Lread + 1), whatever the planning did: the planned
     sweep, the caller's order (PLAN_NO_REORDER), a fusion whose pairs are not contiguous (the identity path of the slice),
